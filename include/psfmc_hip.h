@@ -1,0 +1,140 @@
+/*
+ * psfmc_hip.h -- C ABI of libpsfmc_hip.so: the MI355X (gfx950) implementation of
+ * psfMC's per-sample log-likelihood, batched over ensemble-sampler walkers.
+ *
+ * Drop-in boundary.  The reference evaluates one walker at a time inside
+ *   MultiComponentModel.log_posterior          psfMC/models.py:193-243
+ * which emcee reaches through `lnpostfn` / `pool.map` (psfMC/fitting.py:56-58).
+ * Everything below the prior early-out (models.py:213-241) is replaced by
+ * psfmc_eval_batch(); the one-time setup that feeds it (Configuration.py:41-52,
+ * PSFSelector.py:32-43, utils.py:9-22 `pad_and_rfft_image`, :126-133
+ * `pre_fft_psf`) is replaced by psfmc_ctx_create().  The Python host side
+ * (psfmc_amd/engine.py) binds these entry points with ctypes; see INTEGRATION.md
+ * for the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; caller owns every host buffer for the
+ *     duration of the call; the context owns all device memory.
+ *   - return 0 on success, a negative PSFMC_E* code otherwise, message in
+ *     psfmc_last_error().  Numeric trouble is never an error: a NaN / inf
+ *     log-likelihood is written to the output and the host maps it to -inf
+ *     (psfMC/models.py:238-241).
+ *   - a context is bound to one device and is not thread-safe.
+ *   - images are row-major [ny][nx], x = column index = fastest axis, pixel
+ *     centres at integer coordinates (psfMC/utils.py:35-42).  ny and nx must
+ *     be even (psfMC/models.py:276 is broken for odd sizes too).
+ */
+#ifndef PSFMC_HIP_H
+#define PSFMC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct psfmc_ctx psfmc_ctx;
+
+/* error codes */
+#define PSFMC_OK            0
+#define PSFMC_EINVAL       -1   /* bad argument / unsupported shape        */
+#define PSFMC_EHIP         -2   /* HIP runtime / hipFFT failure            */
+#define PSFMC_ENOMEM       -3
+#define PSFMC_ENODEV       -4   /* no usable gfx950 device                 */
+
+/* convolution back ends (both run entirely on the GPU) */
+#define PSFMC_BACKEND_FUSED   0  /* hand-written LDS FFT fused with rasteriser / spectral multiply / chi^2 */
+#define PSFMC_BACKEND_HIPFFT  1  /* batched hipFFT D2Z/Z2D between separate kernels (cross-check path) */
+
+/* point-source shift methods (psfMC/ModelComponents/PointSource.py:40-51) */
+#define PSFMC_PS_LANCZOS3   0
+#define PSFMC_PS_BILINEAR   1
+
+/*
+ * Per-walker derived-parameter row (doubles), length psfmc_row_len():
+ *   [0]                      sky level, ADU                      (Sky.py:14-16)
+ *   per point source  (4):   flux, x0, y0, method                (PointSource.py:24-57; flux = utils.py:160-164)
+ *   per Sersic        (9):   x0, y0, m00, m01, m10, m11, kappa, p, sb_eff
+ *                            (M = inverse scale * inverse rotation, Sersic.py:80-91;
+ *                             kappa = gammaincinv(2n, 1/2), Sersic.py:47-53; p = 0.5/n,
+ *                             Sersic.py:121; sb_eff Sersic.py:55-71)
+ *   [last]                   psf index (already rounded; PSFSelector.py:54-66)
+ * Component groups are summed in the order sky, point sources, Sersics.
+ */
+#define PSFMC_ROW_SKY      1
+#define PSFMC_ROW_PS       4
+#define PSFMC_ROW_SERSIC   9
+
+/*
+ * Create a context for one observed field.
+ *   sci, obs_var, bad_px  [ny][nx]  Configuration.obs_data / obs_var / bad_px
+ *                                   (Configuration.py:44-46; obs_var = +inf at bad pixels,
+ *                                   utils.py:68-70; bad_px nonzero = excluded from the sum)
+ *   psf, psf_var          [n_psf][psf_ny][psf_nx]  normalised PSFs and their variance maps
+ *                                   as returned by preprocess_psf / calculate_psf_variability
+ *                                   (utils.py:106-157).  They are centre-padded to [ny][nx]
+ *                                   at offset pad/2 and Fourier transformed ON THE DEVICE
+ *                                   (replaces utils.py:9-22, :126-133).
+ *   n_ps, n_sersic        component counts of the model (fixed per context)
+ *   max_walkers           largest W a later call may pass
+ */
+int psfmc_ctx_create(psfmc_ctx** out, int device, int ny, int nx,
+                     const double* sci, const double* obs_var, const uint8_t* bad_px,
+                     int n_psf, int psf_ny, int psf_nx,
+                     const double* psf, const double* psf_var,
+                     int n_ps, int n_sersic, int max_walkers, int backend);
+
+int psfmc_ctx_destroy(psfmc_ctx* ctx);
+
+/* doubles per walker row: 2 + 4*n_ps + 9*n_sersic */
+int psfmc_row_len(const psfmc_ctx* ctx);
+
+/*
+ * Log-likelihood of W walkers (models.py:213-216, 233-236 for each):
+ *   loglike[w] = -0.5 * sum_{good px} ( resid^2 * ivm - ln(ivm / 2pi) )
+ * rows [W][row_len] and skip [W] (nonzero = prior was not finite: the walker is
+ * not evaluated and gets -inf, models.py:208-211; may be NULL) are HOST buffers;
+ * the call returns after loglike[W] has been copied back.
+ */
+int psfmc_eval_batch(psfmc_ctx* ctx, int W, const double* rows,
+                     const uint8_t* skip, double* loglike);
+
+/*
+ * Same, with DEVICE pointers, enqueued on `stream` (a hipStream_t, NULL = the
+ * context's own stream) and not synchronised: for callers that keep walkers
+ * resident in HBM (bench.py, the multi-GPU all-gather path).
+ */
+int psfmc_eval_batch_device(psfmc_ctx* ctx, int W, const double* d_rows,
+                            const uint8_t* d_skip, double* d_loglike, void* stream);
+
+/*
+ * The five per-sample images of models.py:222-226 for W walkers, each
+ * [W][ny][nx] host output or NULL: raw_model (models.py:245-253),
+ * convolved_model (:255-263), residual (:282-294), composite_ivm (:265-280),
+ * point_source_subtracted (:296-306).
+ */
+int psfmc_eval_images(psfmc_ctx* ctx, int W, const double* rows,
+                      double* raw, double* conv, double* resid, double* ivm,
+                      double* ps_sub);
+
+/*
+ * Device-computed PSF spectra, for checking the on-device replacement of
+ * pre_fft_psf (utils.py:126-133): out arrays [n_psf][ny][nx/2+1][2] (re, im),
+ * equal to numpy.fft.rfft2 of the centre-padded images.
+ */
+int psfmc_get_spectra(psfmc_ctx* ctx, double* psf_spec, double* var_spec);
+
+/* tuning knobs: "chunk_walkers" (walkers per internal pass) */
+int psfmc_set_option(psfmc_ctx* ctx, const char* key, double value);
+double psfmc_get_option(const psfmc_ctx* ctx, const char* key);
+
+/* message of the last failing call on this thread ("" if none) */
+const char* psfmc_last_error(void);
+
+/* library/ABI version (bumped when a signature changes) */
+int psfmc_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSFMC_HIP_H */

@@ -1,0 +1,157 @@
+// psfmc_device.h -- device-side building blocks shared by every kernel of
+// libpsfmc_hip: the per-walker "prep" record, the rasteriser pixel function
+// (Sky + PointSource + Sersic) and the Gaussian chi^2 term.
+//
+// Written for gfx950 (CDNA4, wave64) only.  All arithmetic is fp64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace psfmc {
+
+constexpr int kRowSky = 1;      // doubles in a caller row (include/psfmc_hip.h)
+constexpr int kRowPs = 4;
+constexpr int kRowSersic = 9;
+
+constexpr int kTaps = 7;        // widest point-source window (lanczos3)
+// prep record (doubles): [0] sky | per PS: ylo, yn, xlo, xn, wy[7], wx[7] (flux
+// folded into wx) | per Sersic: x0 y0 m00 m01 m10 m11 kappa p sb_eff | psf index
+constexpr int kPrepPs = 4 + 2 * kTaps;
+constexpr int kPrepSersic = 9;
+
+__host__ __device__ inline int row_len(int n_ps, int n_sersic) {
+    return kRowSky + kRowPs * n_ps + kRowSersic * n_sersic + 1;
+}
+__host__ __device__ inline int prep_len(int n_ps, int n_sersic) {
+    return 1 + kPrepPs * n_ps + kPrepSersic * n_sersic + 1;
+}
+
+// ---------------------------------------------------------------------------
+// Point-source window and 1-D weights.
+// psfMC/ModelComponents/PointSource.py:60-81 (minimal_slice: clip, then numpy
+// round-half-even), :84-97 (sinc, lanczos), :40-51 (separable product; the
+// differences use the UNCLIPPED position; weights are not normalised).
+// ---------------------------------------------------------------------------
+__device__ inline double sinc_pi(double x) {
+    const double pix = M_PI * x;
+    return x != 0.0 ? sin(pix) / pix : 1.0;
+}
+
+__device__ inline double ps_weight(double d, int method) {
+    if (method == 1)                       // bilinear
+        return 1.0 - fabs(d);
+    return fabs(d) < 3.0 ? sinc_pi(d) * sinc_pi(d / 3.0) : 0.0;
+}
+
+// one axis: centre c, axis length n -> first tap lo, tap count cnt (0..7)
+__device__ inline void ps_window(double c, int n, int method, int* lo, int* cnt) {
+    const double r = method == 1 ? 0.5 : 3.0;
+    double cc = fmin(fmax(c, r - 0.5), (double)n - (r + 0.5));
+    int a = (int)rint(cc - r);
+    int b = (int)rint(cc + r);
+    if (a < 0) a = 0;                      // numpy slicing truncates at the edges
+    if (b > n - 1) b = n - 1;
+    *lo = a;
+    *cnt = b >= a ? b - a + 1 : 0;
+    if (*cnt > kTaps) *cnt = kTaps;
+}
+
+// Expand one caller row into a prep record.  One thread per walker.
+__device__ inline void build_prep(const double* __restrict__ row, double* __restrict__ prep,
+                                  int n_ps, int n_sersic, int ny, int nx) {
+    prep[0] = row[0];
+    const double* r = row + kRowSky;
+    double* p = prep + 1;
+    for (int k = 0; k < n_ps; ++k, r += kRowPs, p += kPrepPs) {
+        const double flux = r[0], x0 = r[1], y0 = r[2];
+        const int method = (int)r[3];
+        int ylo, yn, xlo, xn;
+        ps_window(y0, ny, method, &ylo, &yn);
+        ps_window(x0, nx, method, &xlo, &xn);
+        p[0] = ylo; p[1] = yn; p[2] = xlo; p[3] = xn;
+        for (int t = 0; t < kTaps; ++t) {
+            p[4 + t] = t < yn ? ps_weight((double)(ylo + t) - y0, method) : 0.0;
+            p[4 + kTaps + t] = t < xn ? ps_weight((double)(xlo + t) - x0, method) * flux : 0.0;
+        }
+    }
+    for (int k = 0; k < n_sersic * kRowSersic; ++k) p[k] = r[k];
+    p[n_sersic * kRowSersic] = r[n_sersic * kRowSersic];     // psf index
+}
+
+// ---------------------------------------------------------------------------
+// Sersic surface brightness of one pixel, with the reference's 1-D
+// pixel-centroid correction.  psfMC/ModelComponents/Sersic.py:73-96
+// (coordinate_sq_radii), :98-134 (add_to_array), :136-153 (_normed_grad).
+//   rho2 = |M (dx,dy)|^2 ; q = rho2 / (dx^2+dy^2) ; L = ln rho2
+//   sb = exp(-kappa expm1(L p)) ; g = -2 kappa p exp(L (p - 1/2))
+//   value = sb_eff * sb * (1 + g * (q/12 * g))
+// At dx = dy = 0 the reference evaluates 0/0 -> NaN; so does this code.
+// ---------------------------------------------------------------------------
+struct SersicPar {
+    double x0, y0, m00, m01, m10, m11, kappa, p, sbeff;
+};
+
+__device__ inline SersicPar load_sersic(const double* __restrict__ s) {
+    return SersicPar{s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], s[8]};
+}
+
+__device__ inline double sersic_pixel(const SersicPar& s, double x, double y) {
+    const double dx = x - s.x0, dy = y - s.y0;
+    const double u = s.m00 * dx + s.m01 * dy;
+    const double v = s.m10 * dx + s.m11 * dy;
+    const double rho2 = u * u + v * v;
+    const double q = rho2 / (dx * dx + dy * dy);
+    const double L = log(rho2);
+    const double sb = exp(-s.kappa * expm1(L * s.p));
+    const double g = -s.kappa * 2.0 * s.p * exp(L * (s.p - 0.5));
+    return s.sbeff * sb * (1.0 + g * (q / 12.0 * g));
+}
+
+// point-source contribution at integer pixel (ix, iy) from one prep PS block
+__device__ inline double ps_pixel(const double* __restrict__ p, int ix, int iy) {
+    const int ty = iy - (int)p[0];
+    const int tx = ix - (int)p[2];
+    if (ty < 0 || ty >= (int)p[1] || tx < 0 || tx >= (int)p[3]) return 0.0;
+    return p[4 + ty] * p[4 + kTaps + tx];
+}
+
+// raw model value of one pixel: models.py:245-253 (Sky, PointSource..., Sersic...)
+__device__ inline double raster_pixel(const double* __restrict__ prep, int n_ps, int n_sersic,
+                                      int ix, int iy, bool ps_only) {
+    double val = ps_only ? 0.0 : prep[0];
+    const double* p = prep + 1;
+    for (int k = 0; k < n_ps; ++k, p += kPrepPs) val += ps_pixel(p, ix, iy);
+    if (!ps_only) {
+        const double x = (double)ix, y = (double)iy;
+        for (int k = 0; k < n_sersic; ++k, p += kPrepSersic)
+            val += sersic_pixel(load_sersic(p), x, y);
+    }
+    return val;
+}
+
+// ---------------------------------------------------------------------------
+// Gaussian chi^2 + log-normalisation term of one good pixel, models.py:233-236:
+//   resid^2 * ivm - ln(0.5/pi * ivm),  ivm = 1/(model_var + obs_var) (:278-279)
+// ---------------------------------------------------------------------------
+__device__ inline double chi2_term(double sci, double obs_var, double conv, double mvar) {
+    const double ivm = 1.0 / (mvar + obs_var);
+    const double r = sci - conv;
+    return r * r * ivm - log(0.5 / M_PI * ivm);
+}
+
+// wave64 + LDS block sum; result valid in thread 0.  blockDim.x multiple of 64.
+__device__ inline double block_sum(double v, double* lds /* >= blockDim/64 doubles */) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    double total = 0.0;
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int i = 0; i < nw; ++i) total += lds[i];
+    }
+    return total;
+}
+
+}  // namespace psfmc

@@ -1,0 +1,215 @@
+"""
+ctypes binding of libpsfmc_hip.so (include/psfmc_hip.h) -- the only way the
+Python host reaches the GPU.  There is deliberately no CPU fallback: if the
+library is missing or no gfx950 device is present, construction raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+BACKEND_FUSED = 0
+BACKEND_HIPFFT = 1
+BACKENDS = {'fused': BACKEND_FUSED, 'hipfft': BACKEND_HIPFFT}
+
+ROW_SKY, ROW_PS, ROW_SERSIC = 1, 4, 9
+
+_LIB_NAME = 'libpsfmc_hip.so'
+_lib = None
+
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+_c_u8_p = ctypes.POINTER(ctypes.c_uint8)
+
+
+class NativeError(RuntimeError):
+    """A libpsfmc_hip call failed (code + message of psfmc_last_error)."""
+
+    def __init__(self, code, message):
+        super(NativeError, self).__init__('libpsfmc_hip error {}: {}'.format(code, message))
+        self.code = code
+
+
+def library_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+
+
+def load_library():
+    """Load (once) and type the C ABI.  Raises ImportError when the extension
+    has not been built -- the product never runs without it."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            '{} not found: build it with `make -C psfmc_amd/csrc` (or '
+            '`python -c "import __graft_entry__ as g; g.build()"`). psfmc_amd has no '
+            'CPU fallback.'.format(path))
+    # torch (device memory / streams / torch.distributed plumbing) ships its own
+    # libamdhip64 with the same SONAME; importing it first makes this process use
+    # ONE HIP runtime for both.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    vp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+    lib.psfmc_abi_version.restype = ci
+    lib.psfmc_abi_version.argtypes = []
+    lib.psfmc_last_error.restype = ctypes.c_char_p
+    lib.psfmc_last_error.argtypes = []
+    lib.psfmc_ctx_create.restype = ci
+    lib.psfmc_ctx_create.argtypes = [ctypes.POINTER(vp), ci, ci, ci, _c_double_p, _c_double_p,
+                                     _c_u8_p, ci, ci, ci, _c_double_p, _c_double_p, ci, ci, ci, ci]
+    lib.psfmc_ctx_destroy.restype = ci
+    lib.psfmc_ctx_destroy.argtypes = [vp]
+    lib.psfmc_row_len.restype = ci
+    lib.psfmc_row_len.argtypes = [vp]
+    lib.psfmc_eval_batch.restype = ci
+    lib.psfmc_eval_batch.argtypes = [vp, ci, _c_double_p, _c_u8_p, _c_double_p]
+    lib.psfmc_eval_batch_device.restype = ci
+    lib.psfmc_eval_batch_device.argtypes = [vp, ci, vp, vp, vp, vp]
+    lib.psfmc_eval_images.restype = ci
+    lib.psfmc_eval_images.argtypes = [vp, ci, _c_double_p] + [_c_double_p] * 5
+    lib.psfmc_get_spectra.restype = ci
+    lib.psfmc_get_spectra.argtypes = [vp, _c_double_p, _c_double_p]
+    lib.psfmc_set_option.restype = ci
+    lib.psfmc_set_option.argtypes = [vp, ctypes.c_char_p, cd]
+    lib.psfmc_get_option.restype = cd
+    lib.psfmc_get_option.argtypes = [vp, ctypes.c_char_p]
+    if lib.psfmc_abi_version() != 1:
+        raise ImportError('libpsfmc_hip ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def _dp(arr):
+    return arr.ctypes.data_as(_c_double_p)
+
+
+def _f64(arr):
+    return np.ascontiguousarray(arr, dtype=np.float64)
+
+
+class Context(object):
+    """One observed field resident on one GPU (wraps `psfmc_ctx`)."""
+
+    IMAGE_KINDS = ('raw_model', 'convolved_model', 'residual', 'composite_ivm',
+                   'point_source_subtracted')
+
+    def __init__(self, sci, obs_var, bad_px, psfs, psf_vars, n_ps, n_sersic,
+                 max_walkers=4096, device=0, backend='fused'):
+        self._lib = load_library()
+        self._ctx = None
+        sci = _f64(sci)
+        obs_var = _f64(obs_var)
+        if sci.ndim != 2 or obs_var.shape != sci.shape:
+            raise ValueError('sci / obs_var must be 2-D arrays of one shape')
+        bad = np.ascontiguousarray(np.asarray(bad_px).astype(bool), dtype=np.uint8)
+        psfs = _f64(psfs)
+        psf_vars = _f64(psf_vars)
+        if psfs.ndim != 3 or psf_vars.shape != psfs.shape:
+            raise ValueError('psfs / psf_vars must be [n_psf, py, px]')
+        self.shape = sci.shape
+        self.n_psf = psfs.shape[0]
+        self.n_ps, self.n_sersic = int(n_ps), int(n_sersic)
+        self.max_walkers = int(max_walkers)
+        self.device = int(device)
+        self.backend = backend
+        handle = ctypes.c_void_p()
+        rc = self._lib.psfmc_ctx_create(
+            ctypes.byref(handle), self.device, sci.shape[0], sci.shape[1], _dp(sci),
+            _dp(obs_var), bad.ctypes.data_as(_c_u8_p), self.n_psf, psfs.shape[1],
+            psfs.shape[2], _dp(psfs), _dp(psf_vars), self.n_ps, self.n_sersic,
+            self.max_walkers, BACKENDS[backend] if isinstance(backend, str) else int(backend))
+        self._check(rc)
+        self._ctx = handle
+        self.row_len = self._lib.psfmc_row_len(self._ctx)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise NativeError(rc, self._lib.psfmc_last_error().decode('utf-8', 'replace'))
+
+    def close(self):
+        if self._ctx is not None:
+            self._lib.psfmc_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ------------------------------------------------------------------
+    def _rows(self, rows):
+        rows = _f64(rows)
+        if rows.ndim != 2 or rows.shape[1] != self.row_len:
+            raise ValueError('rows must be [W, {}], got {}'.format(self.row_len, rows.shape))
+        if rows.shape[0] > self.max_walkers:
+            raise ValueError('W={} exceeds max_walkers={}'.format(rows.shape[0], self.max_walkers))
+        return rows
+
+    def loglike(self, rows, skip=None):
+        """[W, row_len] derived rows -> [W] log-likelihoods (NaN/inf preserved;
+        skipped walkers -inf)."""
+        rows = self._rows(rows)
+        n_w = rows.shape[0]
+        out = np.empty(n_w, dtype=np.float64)
+        if n_w == 0:
+            return out
+        skip_p = None
+        if skip is not None:
+            skip = np.ascontiguousarray(np.asarray(skip).astype(bool), dtype=np.uint8)
+            if skip.shape != (n_w,):
+                raise ValueError('skip must be [W]')
+            skip_p = skip.ctypes.data_as(_c_u8_p)
+        self._check(self._lib.psfmc_eval_batch(self._ctx, n_w, _dp(rows), skip_p, _dp(out)))
+        return out
+
+    def loglike_device(self, n_w, d_rows, d_skip, d_out, stream=None):
+        """Enqueue on a HIP stream with raw device pointers (ints); no sync."""
+        self._check(self._lib.psfmc_eval_batch_device(
+            self._ctx, int(n_w), ctypes.c_void_p(d_rows),
+            ctypes.c_void_p(d_skip) if d_skip else None, ctypes.c_void_p(d_out),
+            ctypes.c_void_p(stream) if stream else None))
+
+    def images(self, rows, kinds=None):
+        """dict kind -> [W, ny, nx] for the requested image kinds."""
+        rows = self._rows(rows)
+        kinds = self.IMAGE_KINDS if kinds is None else tuple(kinds)
+        n_w = rows.shape[0]
+        bufs, args = {}, []
+        for k in self.IMAGE_KINDS:
+            if k in kinds:
+                bufs[k] = np.empty((n_w,) + self.shape, dtype=np.float64)
+                args.append(_dp(bufs[k]))
+            else:
+                args.append(None)
+        unknown = set(kinds) - set(self.IMAGE_KINDS)
+        if unknown:
+            raise ValueError('unknown image kinds: {}'.format(sorted(unknown)))
+        if n_w:
+            self._check(self._lib.psfmc_eval_images(self._ctx, n_w, _dp(rows), *args))
+        return bufs
+
+    def spectra(self):
+        """(psf_spec, var_spec) complex128 [n_psf, ny, nx//2+1] as computed on
+        the device (== numpy.fft.rfft2 of the centre-padded images)."""
+        shp = (self.n_psf, self.shape[0], self.shape[1] // 2 + 1, 2)
+        a = np.empty(shp)
+        b = np.empty(shp)
+        self._check(self._lib.psfmc_get_spectra(self._ctx, _dp(a), _dp(b)))
+        return a[..., 0] + 1j * a[..., 1], b[..., 0] + 1j * b[..., 1]
+
+    def set_option(self, key, value):
+        self._check(self._lib.psfmc_set_option(self._ctx, key.encode(), float(value)))
+
+    def get_option(self, key):
+        return self._lib.psfmc_get_option(self._ctx, key.encode())

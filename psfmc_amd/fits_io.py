@@ -1,0 +1,156 @@
+"""
+Minimal FITS image I/O (astropy is not available next to the ROCm stack).
+
+Covers what the hot path's setup needs (psfMC/utils.py:61-63, 87, 111-112 call
+`astropy.io.fits.getdata/getheader`): read the first HDU that holds an image
+(primary or IMAGE extension, BITPIX 8/16/32/64/-32/-64, optional
+BSCALE/BZERO), gzip-compressed files included, and write a single-HDU image.
+Float data keep their on-disk precision (float32 stays float32), which matters
+because the reference's raw-model dtype follows the FITS dtype (models.py:249).
+"""
+import gzip
+from collections import OrderedDict
+
+import numpy as np
+
+BLOCK = 2880
+_BITPIX = {8: 'u1', 16: '>i2', 32: '>i4', 64: '>i8', -32: '>f4', -64: '>f8'}
+
+
+def _open(path):
+    with open(path, 'rb') as f:
+        magic = f.read(2)
+    return gzip.open(path, 'rb') if magic == b'\x1f\x8b' else open(path, 'rb')
+
+
+def _parse_value(text):
+    text = text.strip()
+    if not text:
+        return None
+    if text.startswith("'"):
+        end = text.find("'", 1)
+        while end != -1 and text[end:end + 2] == "''":
+            end = text.find("'", end + 2)
+        return text[1:end if end != -1 else None].replace("''", "'").rstrip()
+    text = text.split('/')[0].strip()
+    if text in ('T', 'F'):
+        return text == 'T'
+    try:
+        return int(text)
+    except ValueError:
+        try:
+            return float(text.replace('D', 'E'))
+        except ValueError:
+            return text
+
+
+def _read_header(f):
+    """Returns (OrderedDict, found_end).  Tolerates a missing END card
+    (`ignore_missing_end=True` in the reference's calls)."""
+    hdr = OrderedDict()
+    while True:
+        block = f.read(BLOCK)
+        if len(block) < BLOCK:
+            return hdr, False
+        for i in range(0, BLOCK, 80):
+            card = block[i:i + 80].decode('ascii', 'replace')
+            key = card[:8].strip()
+            if key == 'END':
+                return hdr, True
+            if card[8:10] == '= ' and key:
+                hdr[key] = _parse_value(card[10:])
+            elif key in ('COMMENT', 'HISTORY'):
+                hdr.setdefault(key, [])
+                hdr[key].append(card[8:].rstrip())
+
+
+def _data_shape(hdr):
+    naxis = int(hdr.get('NAXIS', 0))
+    return tuple(int(hdr['NAXIS%d' % (k + 1)]) for k in reversed(range(naxis)))
+
+
+def read_image(path, with_header=False):
+    """First image found in the file, as a native-endian array."""
+    if not isinstance(path, str):
+        raise IOError('not a file name: %r' % (path,))
+    with _open(path) as f:
+        first = True
+        while True:
+            hdr, _ = _read_header(f)
+            if not hdr:
+                raise IOError('no image data in FITS file %s' % path)
+            if first and hdr.get('SIMPLE') is not True:
+                raise IOError('%s is not a FITS file' % path)
+            first = False
+            shape = _data_shape(hdr)
+            count = int(np.prod(shape)) if shape else 0
+            bitpix = int(hdr.get('BITPIX', 8))
+            nbytes = count * abs(bitpix) // 8
+            nbytes += int(hdr.get('PCOUNT', 0))
+            is_image = hdr.get('XTENSION', 'IMAGE').strip() == 'IMAGE'
+            if count and is_image:
+                raw = f.read(count * abs(bitpix) // 8)
+                data = np.frombuffer(raw, dtype=_BITPIX[bitpix], count=count)
+                data = data.reshape(shape)
+                data = data.astype(data.dtype.newbyteorder('='))
+                bscale = hdr.get('BSCALE', 1)
+                bzero = hdr.get('BZERO', 0)
+                if bscale != 1 or bzero != 0:
+                    if bitpix == 16 and bscale == 1 and bzero == 32768:
+                        data = (data.astype(np.int32) + 32768).astype(np.uint16)
+                    else:
+                        data = data * np.float64(bscale) + np.float64(bzero)
+                return (data, hdr) if with_header else data
+            f.read(-(-nbytes // BLOCK) * BLOCK)      # skip this HDU's data
+
+
+def read_header(path):
+    with _open(path) as f:
+        hdr, _ = _read_header(f)
+    return hdr
+
+
+def _card(key, value, comment=''):
+    if isinstance(value, bool):
+        val = 'T' if value else 'F'
+        text = '%-8s= %20s' % (key, val)
+    elif isinstance(value, (int, np.integer)):
+        text = '%-8s= %20d' % (key, value)
+    elif isinstance(value, (float, np.floating)):
+        text = '%-8s= %20s' % (key, ('%.15G' % value))
+    else:
+        text = "%-8s= '%-8s'" % (key, str(value).replace("'", "''")[:67])
+    if comment:
+        text = (text + ' / ' + comment)
+    return text[:80].ljust(80)
+
+
+def write_image(path, data, header=None):
+    """Single-HDU FITS image.  `header`: mapping of extra cards (values
+    bool/int/float/str)."""
+    data = np.asarray(data)
+    kinds = {'float32': -32, 'float64': -64, 'uint8': 8, 'int16': 16,
+             'int32': 32, 'int64': 64, 'bool': 8}
+    if data.dtype.name not in kinds:
+        data = data.astype(np.float64)
+    bitpix = kinds[data.dtype.name]
+    cards = [_card('SIMPLE', True, 'conforms to FITS standard'),
+             _card('BITPIX', bitpix), _card('NAXIS', data.ndim)]
+    for k, n in enumerate(reversed(data.shape)):
+        cards.append(_card('NAXIS%d' % (k + 1), int(n)))
+    reserved = {'SIMPLE', 'BITPIX', 'NAXIS', 'END', 'EXTEND', 'BSCALE', 'BZERO'}
+    for key, val in (header or {}).items():
+        key = str(key).upper()[:8]
+        if key in reserved or key.startswith('NAXIS') or isinstance(val, list):
+            continue
+        if val is None:
+            continue
+        cards.append(_card(key, val))
+    cards.append('END'.ljust(80))
+    head = ''.join(cards).encode('ascii')
+    head += b' ' * (-len(head) % BLOCK)
+    body = data.astype(_BITPIX[bitpix]).tobytes()
+    body += b'\0' * (-len(body) % BLOCK)
+    with open(path, 'wb') as f:
+        f.write(head)
+        f.write(body)

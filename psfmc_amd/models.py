@@ -1,0 +1,289 @@
+"""
+Composite model + the batched log-posterior -- the drop-in for
+`psfMC.models.MultiComponentModel` (psfMC/models.py).
+
+Host side (this file): model-file parsing, the parameter packing contract,
+vectorised priors with the non-finite early-out, derivation of the per-walker
+scalars the GPU needs (flux, Sersic b_n, surface brightness at r_e, inverse
+ellipse matrix), NaN -> -inf mapping.  Device side (libpsfmc_hip): everything
+from models.py:213 to :236 for all walkers of a batch at once.
+"""
+import numpy as np
+
+from .ModelComponents import Configuration, PointSource, Sersic, Sky
+from .ModelComponents.ComponentBase import ComponentBase
+from .ModelComponents.PointSource import SHIFT_METHODS
+from .ModelComponents.PSFSelector import PSFSelector
+from .model_parser import component_list_from_file
+from .utils import mag_to_flux
+from . import engine
+
+IMAGE_KINDS = engine.Context.IMAGE_KINDS
+
+
+class MultiComponentModel(object):
+    """A 2-D surface-brightness model made of components (Sky, PointSource,
+    Sersic) plus one Configuration, given as a model file or a list
+    (reference: models.py:9-61).
+
+    device / backend / max_walkers configure the GPU context, which is created
+    on first use.
+    """
+
+    def __init__(self, components, device=0, backend='fused', max_walkers=4096):
+        np.seterr(divide='ignore')
+        if isinstance(components, str):
+            try:
+                components = component_list_from_file(components)
+            except IOError as err:
+                raise IOError('Unable to open model file {}. Does it exist? ({})'
+                              .format(components, err))
+        components = list(components)
+        configs = [c for c in components if isinstance(c, Configuration)]
+        if not configs:
+            raise ValueError('Unable to find the Configuration component, '
+                             'required for setting up input images.')
+        config = configs[-1]
+        components.remove(config)
+        components.append(config.psf_selector)      # always last (models.py:37-38)
+        for count, comp in enumerate(components):
+            comp.update_stochastic_names(count=count)
+            if not isinstance(comp, PSFSelector) and comp.device_kind is None:
+                raise NotImplementedError(
+                    'component {} has no GPU rasteriser; supported: Sky, '
+                    'PointSource, Sersic'.format(type(comp).__name__))
+
+        self.config = config
+        self.components = components
+        self.raw_model_components = [c for c in components
+                                     if c.device_kind is not None]
+        self.psf_comps = [c for c in components if isinstance(c, PointSource)]
+        self.obs_header = config.obs_header
+
+        # column ranges of each component in the emcee vector
+        self._spans, pos = [], 0
+        for comp in components:
+            n = comp.num_stochastics()
+            self._spans.append(slice(pos, pos + n))
+            pos += n
+        self._num_params = pos
+        self._param_vector = np.zeros(pos)
+
+        self._sky = [c for c in components if isinstance(c, Sky)]
+        self._ps = self.psf_comps
+        self._sersic = [c for c in components if isinstance(c, Sersic)]
+        self._device, self._backend = device, backend
+        self._max_walkers = int(max_walkers)
+        self._engine = None
+
+        self.blob_images = False      # log_posterior() returns image blobs
+        self.posterior_images = {}
+        self.accumulated_samples = 0
+        self.reset_images()
+
+    # -- engine --------------------------------------------------------------
+    @property
+    def engine(self):
+        if self._engine is None:
+            sel = self.config.psf_selector
+            self._engine = engine.Context(
+                self.config.obs_data, self.config.obs_var, self.config.bad_px,
+                np.stack(sel.psf_data), np.stack(sel.psf_var),
+                n_ps=len(self._ps), n_sersic=len(self._sersic),
+                max_walkers=self._max_walkers, device=self._device,
+                backend=self._backend)
+        return self._engine
+
+    def close(self):
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None
+
+    # -- parameter vector -----------------------------------------------------
+    @property
+    def num_params(self):
+        return self._num_params
+
+    @property
+    def param_names(self):
+        return [n for c in self.components for n in c.stochastic_names()]
+
+    @property
+    def param_fits_abbrs(self):
+        return [n for c in self.components
+                for n in c.stochastic_names(name_attr='fitsname')]
+
+    @property
+    def param_lens(self):
+        return [n for c in self.components for n in c.stochastic_lens()]
+
+    @property
+    def param_values(self):
+        parts = np.split(self._param_vector, np.cumsum(self.param_lens)[:-1])
+        return dict(zip(self.param_names, parts))
+
+    @param_values.setter
+    def param_values(self, vector):
+        vector = np.asarray(vector, dtype=np.float64)
+        self._param_vector = vector
+        for comp, span in zip(self.components, self._spans):
+            comp.set_stochastic_values(vector[span])
+
+    def get_distribution(self, param_name):
+        found = None
+        for comp in self.components:
+            try:
+                found = comp.get_distribution(param_name)
+            except KeyError:
+                pass
+        return found
+
+    def init_params_from_priors(self, nwalkers):
+        """Walker start positions drawn from the priors, re-drawing a component
+        until its joint prior is finite (models.py:108-130)."""
+        out = np.zeros((nwalkers, self.num_params))
+        for w in range(nwalkers):
+            for comp, span in zip(self.components, self._spans):
+                while True:
+                    vals = comp.set_stochastic_values('random')
+                    if np.isfinite(comp.log_priors()):
+                        break
+                out[w, span] = vals
+        return out
+
+    # -- priors ---------------------------------------------------------------
+    def log_priors(self):
+        return np.sum([c.log_priors() for c in self.components])
+
+    def log_priors_batch(self, theta):
+        theta = self._theta(theta)
+        total = np.zeros(theta.shape[0])
+        with np.errstate(all='ignore'):
+            for comp, span in zip(self.components, self._spans):
+                total = total + comp.log_priors_batch(theta[:, span])
+        return total
+
+    # -- host -> device rows ---------------------------------------------------
+    def _theta(self, theta):
+        theta = np.asarray(theta, dtype=np.float64)
+        if theta.ndim == 1:
+            theta = theta[None, :]
+        if theta.ndim != 2 or theta.shape[1] != self.num_params:
+            raise ValueError('expected [W, {}] parameter vectors, got {}'
+                             .format(self.num_params, theta.shape))
+        return theta
+
+    def derived_rows(self, theta):
+        """[W, P] emcee vectors -> [W, row_len] rows of include/psfmc_hip.h."""
+        theta = self._theta(theta)
+        n_w = theta.shape[0]
+        zp = self.config.mag_zeropoint
+        vals = {id(c): c.values_batch(theta[:, s])
+                for c, s in zip(self.components, self._spans)}
+        cols = [sum((vals[id(c)]['adu'] for c in self._sky), np.zeros(n_w))]
+        with np.errstate(all='ignore'):
+            for c in self._ps:
+                v = vals[id(c)]
+                cols += [mag_to_flux(v['mag'], zp), v['xy'][:, 0], v['xy'][:, 1],
+                         np.full(n_w, float(SHIFT_METHODS[c.shift_method]))]
+            for c in self._sersic:
+                v = vals[id(c)]
+                theta_rot = (np.deg2rad(v['angle']) if c.angle_degrees
+                             else v['angle']) + 0.5 * np.pi
+                sin_t, cos_t = np.sin(theta_rot), np.cos(theta_rot)
+                kappa = Sersic.kappa(v['index'])
+                cols += [v['xy'][:, 0], v['xy'][:, 1],
+                         cos_t / v['reff'], sin_t / v['reff'],
+                         -sin_t / v['reff_b'], cos_t / v['reff_b'],
+                         kappa, 0.5 / v['index'],
+                         Sersic.sb_eff(mag_to_flux(v['mag'], zp), v['index'],
+                                       v['reff'], v['reff_b'], kappa)]
+        sel = vals[id(self.config.psf_selector)]
+        psf = sel.get('psf_index', np.zeros(n_w))
+        cols.append(np.clip(psf, 0, len(self.config.psf_selector.psf_data) - 1))
+        return np.ascontiguousarray(np.stack([np.asarray(c, dtype=np.float64)
+                                              for c in cols], axis=1))
+
+    # -- the hot path -----------------------------------------------------------
+    def log_likelihood_batch(self, theta, skip=None):
+        """[W] Gaussian log-likelihoods from the GPU; non-finite -> -inf."""
+        rows = self.derived_rows(theta)
+        ll = self.engine.loglike(rows, skip)
+        return np.where(np.isfinite(ll), ll, -np.inf)
+
+    def log_posterior_batch(self, theta):
+        """log-posterior of W parameter vectors in one GPU batch.  Walkers
+        whose prior is not finite are not evaluated (models.py:208-211)."""
+        theta = self._theta(theta)
+        lnprior = self.log_priors_batch(theta)
+        skip = ~np.isfinite(lnprior)
+        out = np.full(theta.shape[0], -np.inf)
+        if not skip.all():
+            safe = np.where(skip[:, None], theta[np.argmin(skip)], theta)
+            ll = self.log_likelihood_batch(safe, skip)
+            ok = ~skip
+            out[ok] = ll[ok] + lnprior[ok]
+        return out
+
+    @staticmethod
+    def log_posterior(param_values, **kwargs):
+        """Single-vector form with the reference's signature (models.py:193-243):
+        `kwargs` must hold `model`.  Returns (lnprob, blobs)."""
+        model = kwargs.pop('model')
+        model.param_values = param_values
+        lnp = model.log_posterior_batch(param_values)[0]
+        blobs = {}
+        if model.blob_images and np.isfinite(model.log_priors()):
+            blobs = {k: v[0] for k, v in model.sample_images(param_values).items()}
+        return float(lnp), blobs
+
+    # -- images ---------------------------------------------------------------
+    def sample_images(self, theta, kinds=None):
+        """The per-sample images of models.py:222-226 for W vectors:
+        dict kind -> [W, ny, nx]."""
+        return self.engine.images(self.derived_rows(theta), kinds)
+
+    def _one_image(self, kind):
+        return self.sample_images(self._param_vector, (kind,))[kind][0]
+
+    def raw_model(self):
+        return self._one_image('raw_model')
+
+    def convolved_model(self, raw_px=None):
+        return self._one_image('convolved_model')
+
+    def composite_ivm(self, raw_px=None):
+        return self._one_image('composite_ivm')
+
+    def residual(self, convolved_px=None, raw_px=None):
+        return self._one_image('residual')
+
+    def point_source_subtracted(self):
+        return self._one_image('point_source_subtracted')
+
+    def reset_images(self):
+        shape = self.config.obs_data.shape
+        self.accumulated_samples = 0
+        for kind in IMAGE_KINDS:
+            self.posterior_images[kind] = np.ones(shape, dtype=np.float64)
+
+    def accumulate_images(self, sample_images):
+        """Running mean of the per-sample images; the weight map is averaged
+        as a variance (models.py:74-97).  `sample_images`: list of dicts
+        {kind: [ny, nx]} (emcee blobs) or one dict {kind: [W, ny, nx]}."""
+        if isinstance(sample_images, dict):
+            n_w = len(next(iter(sample_images.values())))
+            sample_images = [{k: v[i] for k, v in sample_images.items()}
+                             for i in range(n_w)]
+        post = self.posterior_images
+        with np.errstate(all='ignore'):
+            post['composite_ivm'] = 1 / post['composite_ivm']
+            for imgs in sample_images:
+                if not imgs:
+                    continue
+                self.accumulated_samples += 1
+                n = self.accumulated_samples
+                for kind, img in imgs.items():
+                    step = 1 / img if kind == 'composite_ivm' else img
+                    post[kind] = (post[kind] * (n - 1) + step) / n
+            post['composite_ivm'] = 1 / post['composite_ivm']

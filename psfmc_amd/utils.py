@@ -1,0 +1,96 @@
+"""
+One-time field setup (host glue): FITS -> the shared arrays the GPU context is
+built from.  Restates the setup half of the reference's psfMC/utils.py with the
+minimal FITS reader of this package; the Fourier transform of the PSFs (the
+reference's `pad_and_rfft_image` / `pre_fft_psf`, utils.py:9-22, :126-133) is
+NOT here -- it runs on the device inside `psfmc_ctx_create`.
+"""
+from math import fsum
+from warnings import warn
+
+import numpy as np
+
+from . import fits_io
+
+
+def _as_image(src, with_header=False):
+    """File name or array -> native-endian ndarray (dtype preserved)."""
+    if isinstance(src, str):
+        return fits_io.read_image(src, with_header=with_header)
+    arr = np.asarray(src)
+    arr = arr.astype(arr.dtype.newbyteorder('='))
+    return (arr, {}) if with_header else arr
+
+
+def mag_to_flux(mag, mag_zp):
+    """Total flux for a magnitude (utils.py:160-164)."""
+    return 10 ** (-0.4 * (mag - mag_zp))
+
+
+def norm_psf(psf_data, psf_ivm):
+    """Unit-sum PSF and rescaled weight map; exact summation (utils.py:45-51)."""
+    total = fsum(psf_data.flat)
+    return psf_data / total, psf_ivm * total ** 2
+
+
+def preprocess_obs(obs_data, obs_ivm, mask_file=None):
+    """Observed image, variance map (+inf at bad pixels) and bad-pixel mask
+    (utils.py:54-79).  The mask file only extends `bad_px`; variances are left
+    alone."""
+    obs_data, obs_hdr = _as_image(obs_data, with_header=True)
+    obs_ivm = _as_image(obs_ivm)
+    if obs_data.shape != obs_ivm.shape:
+        raise ValueError('observation and weight map shapes differ: {} vs {}'
+                         .format(obs_data.shape, obs_ivm.shape))
+    bad_px = ~np.isfinite(obs_data) | ~np.isfinite(obs_ivm) | (obs_ivm <= 0)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        obs_var = np.where(bad_px, np.inf, 1 / obs_ivm).astype(obs_ivm.dtype)
+    if mask_file is not None:
+        exclude = mask_from_file(mask_file, obs_hdr, obs_data.shape)
+        if exclude is not None:
+            bad_px = bad_px | exclude
+    return obs_hdr, obs_data, obs_var, bad_px
+
+
+def mask_from_file(mask_file, obs_hdr, shape):
+    """FITS mask (nonzero = exclude) or array (utils.py:82-103).  ds9 region
+    files need pyregion, which is not available: like the reference without
+    pyregion, they are ignored with a warning."""
+    if not isinstance(mask_file, str):
+        return np.asarray(mask_file).astype(bool)
+    try:
+        return fits_io.read_image(mask_file).astype(bool)
+    except (IOError, OSError, KeyError, ValueError):
+        pass
+    warn('{} is not a FITS mask; ds9 region masks are not supported here and '
+         'will be ignored.'.format(mask_file))
+    return None
+
+
+def preprocess_psf(psf_data, psf_ivm):
+    """Normalised PSF and its variance map; zero-weight pixels are zeroed in
+    both (utils.py:106-123)."""
+    psf_data = np.array(_as_image(psf_data))
+    psf_ivm = np.array(_as_image(psf_ivm))
+    bad = ~np.isfinite(psf_data) | ~np.isfinite(psf_ivm) | (psf_ivm <= 0)
+    psf_data[bad] = 0
+    psf_ivm[bad] = 0
+    psf_data, psf_ivm = norm_psf(psf_data, psf_ivm)
+    with np.errstate(divide='ignore'):
+        psf_var = np.where(psf_ivm <= 0, 0, 1 / psf_ivm)
+    return psf_data, psf_var
+
+
+def calculate_psf_variability(psf_data, psf_vars):
+    """Adds the pixel-wise variance between PSFs (breathing / mismatch) to each
+    PSF's variance map when several PSFs are given (utils.py:136-157)."""
+    if len(psf_data) == 1:
+        return list(psf_data), list(psf_vars)
+    mismatch = np.var(psf_data, axis=0)
+    return list(psf_data), [v + mismatch for v in psf_vars]
+
+
+def print_progress(sample, max_samples, stage='Burning'):
+    nxt = 100 * (sample + 1) // max_samples
+    if nxt - 100 * sample // max_samples > 0:
+        print('{}: {:d}%'.format(stage, nxt))

@@ -1,0 +1,121 @@
+"""Shared test helpers: golden-case loading, model construction from the
+golden arrays (through the product's own FITS writer + model-file DSL), and an
+INDEPENDENT theta -> oracle-components translation (it knows each case's
+component layout from the case definition, not from the product's packing
+code)."""
+import os
+
+import numpy as np
+
+import psfmc_oracle as orc
+import synth_field
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+# component layout of each golden case, in model-file order
+LAYOUT = {
+    'example': [('sky',), ('ps', 'lanczos3'), ('sersic', True), ('sersic', True)],
+    'synth256': [('ps', 'lanczos3'), ('sersic', True)],
+    'synth128x2': [('ps', 'lanczos3'), ('sersic', True), ('sersic', True)],
+    'edge': [('sky',), ('ps', 'bilinear'), ('ps', 'lanczos3'), ('sersic', False)],
+}
+HAS_PSF_INDEX = {'edge'}
+# vectors whose result is ill-conditioned (Sersic centre 1e-6 px from a pixel
+# centre: the core pixel amplifies last-bit differences in dx, dy by ~1e8), so
+# even numpy 1.26 vs numpy 2.2 runs of the SAME oracle differ at 1e-8
+ILL_CONDITIONED = {'edge': [27]}
+
+
+def well_conditioned(name, n):
+    keep = np.ones(n, dtype=bool)
+    keep[ILL_CONDITIONED.get(name, [])] = False
+    return keep
+
+
+def load_case(name):
+    return dict(np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False))
+
+
+def synth_layout(n_sersic):
+    return [('ps', 'lanczos3')] + [('sersic', True)] * n_sersic
+
+
+def comps_from_theta(layout, theta, has_psf_index=False):
+    """emcee vector -> (oracle comps, psf_index).  Packing: alphabetical inside
+    a component (PointSource: mag, x, y; Sersic: angle, index, mag, reff,
+    reff_b, x, y), components in file order, psf_index last."""
+    theta = np.asarray(theta, dtype=np.float64)
+    pos, comps = 0, []
+    for item in layout:
+        if item[0] == 'sky':
+            comps.append(dict(type='sky', adu=theta[pos]))
+            pos += 1
+        elif item[0] == 'ps':
+            comps.append(dict(type='ps', mag=theta[pos], xy=theta[pos + 1:pos + 3],
+                              method=item[1]))
+            pos += 3
+        else:
+            a, n, m, re, rb, x, y = theta[pos:pos + 7]
+            comps.append(dict(type='sersic', angle=a, index=n, mag=m, reff=re,
+                              reff_b=rb, xy=np.array([x, y]),
+                              angle_degrees=item[1]))
+            pos += 7
+    psf_index = theta[pos] if has_psf_index else 0
+    return comps, psf_index
+
+
+def oracle_field(case):
+    return orc.make_field(case['sci'], case['ivm'], list(case['psfs']),
+                          list(case['psf_ivms']), mask=case.get('mask'),
+                          mag_zp=float(case['mag_zp']))
+
+
+def oracle_loglike(field, layout, theta, has_psf_index=False, raw_dtype=np.float64):
+    comps, psf = comps_from_theta(layout, theta, has_psf_index)
+    if has_psf_index and not (0 <= np.rint(psf) < len(field.psf_spec)):
+        return -np.inf
+    return orc.log_likelihood(field, comps, psf, raw_dtype=raw_dtype)
+
+
+def write_case_files(name, case, directory):
+    """FITS inputs + model file for a golden case, via the product's writer.
+    Returns the model file path."""
+    from psfmc_amd import fits_io
+    directory = str(directory)
+    if name == 'example':
+        return os.path.join(GOLDEN, 'example', 'model_example.py')
+    fits_io.write_image(os.path.join(directory, 'sci.fits'), case['sci'])
+    fits_io.write_image(os.path.join(directory, 'ivm.fits'), case['ivm'])
+    if name == 'edge':
+        for k in range(len(case['psfs'])):
+            fits_io.write_image(os.path.join(directory, 'psf%d.fits' % k), case['psfs'][k])
+            fits_io.write_image(os.path.join(directory, 'psfivm%d.fits' % k),
+                                case['psf_ivms'][k])
+        fits_io.write_image(os.path.join(directory, 'mask.fits'), case['mask'])
+        with open(os.path.join(GOLDEN, 'edge_model.py')) as f:
+            text = f.read()
+    else:
+        fits_io.write_image(os.path.join(directory, 'psf.fits'), case['psfs'][0])
+        fits_io.write_image(os.path.join(directory, 'psf_ivm.fits'), case['psf_ivms'][0])
+        n_side = case['sci'].shape[0]
+        n_sersic = len(LAYOUT[name]) - 1
+        text = synth_field.model_file_text(n_side, n_sersic)
+    path = os.path.join(directory, 'model.py')
+    with open(path, 'w') as f:
+        f.write(text)
+    return path
+
+
+def build_model(name, case, directory, **kwargs):
+    from psfmc_amd import MultiComponentModel
+    return MultiComponentModel(write_case_files(name, case, directory), **kwargs)
+
+
+def rel_err(got, ref):
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    fin = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(got), fin), 'finite masks differ'
+    assert np.array_equal(got[~fin], ref[~fin]), 'non-finite values differ'
+    if not fin.any():
+        return 0.0
+    return float(np.max(np.abs(got[fin] - ref[fin]) / np.abs(ref[fin])))

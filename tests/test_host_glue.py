@@ -1,0 +1,152 @@
+"""Host-side glue on CPU: FITS I/O, model-file DSL, packing contract, priors,
+derived rows, and the C-ABI library's exported surface (no compute calls)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import helpers
+import psfmc_oracle as orc
+from psfmc_amd import MultiComponentModel, fits_io, engine
+from psfmc_amd.distributions import Normal, Uniform, DiscreteUniform, WeibullMinimum
+from psfmc_amd.ModelComponents import Sersic, PointSource, Sky
+
+CASES = ['example', 'synth256', 'synth128x2', 'edge']
+
+
+def test_fits_roundtrip(tmp_path):
+    rng = np.random.RandomState(0)
+    for dtype in (np.float32, np.float64, np.int16, np.uint8):
+        arr = (rng.normal(size=(6, 10)) * 50).astype(dtype)
+        path = str(tmp_path / 'a.fits')
+        fits_io.write_image(path, arr, header={'MAGZPT': 25.5, 'OBJECT': 'x y'})
+        back, hdr = fits_io.read_image(path, with_header=True)
+        assert back.dtype == arr.dtype and np.array_equal(back, arr)
+        assert hdr['MAGZPT'] == 25.5 and hdr['OBJECT'] == 'x y'
+        assert os.path.getsize(path) % 2880 == 0
+
+
+def test_fits_reads_reference_example_files():
+    ex = os.path.join(helpers.GOLDEN, 'example')
+    case = helpers.load_case('example')
+    assert np.array_equal(fits_io.read_image(os.path.join(ex, 'sci_J0005-0006.fits')), case['sci'])
+    assert np.array_equal(fits_io.read_image(os.path.join(ex, 'ivm_psf.fits')), case['psf_ivms'][0])
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_packing_priors_and_rows_match_reference(name, tmp_path):
+    case = helpers.load_case(name)
+    model = helpers.build_model(name, case, tmp_path)
+    assert model.param_names == [str(s) for s in case['param_names']]
+    assert model.num_params == case['params'].shape[1]
+    lnprior = model.log_priors_batch(case['params'])
+    assert helpers.rel_err(lnprior, case['lnprior']) <= 1e-13
+    fin = np.isfinite(case['lnprior'])
+    rows = model.derived_rows(case['params'][fin])
+    assert np.allclose(rows, case['derived'][fin], rtol=1e-13, atol=0)
+    # setup arrays equal the oracle's restatement of preprocess_obs / preprocess_psf
+    field = helpers.oracle_field(case)
+    assert np.array_equal(model.config.bad_px, field.bad_px)
+    assert np.array_equal(model.config.obs_var, field.obs_var)
+    for a, b in zip(model.config.psf_selector.psf_data, field.psf_list):
+        assert np.array_equal(a, b)
+    for a, b in zip(model.config.psf_selector.psf_var, field.var_list):
+        assert np.array_equal(a, b)
+
+
+def test_scalar_and_batch_priors_agree(tmp_path):
+    case = helpers.load_case('edge')
+    model = helpers.build_model('edge', case, tmp_path)
+    batch = model.log_priors_batch(case['params'])
+    for i in range(0, len(case['params']), 4):
+        model.param_values = case['params'][i]
+        one = model.log_priors()
+        assert (one == batch[i]) or abs(one - batch[i]) <= 1e-13 * abs(one)
+
+
+def test_init_params_from_priors_are_valid(tmp_path):
+    case = helpers.load_case('example')
+    model = helpers.build_model('example', case, tmp_path)
+    np.random.seed(3)
+    p0 = model.init_params_from_priors(12)
+    assert p0.shape == (12, 18)
+    assert np.isfinite(model.log_priors_batch(p0)).all()
+
+
+def test_constants_are_not_packed():
+    ser = Sersic(xy=(3.0, 4.0), mag=Uniform(loc=20, scale=2), reff=5.0, reff_b=Uniform(loc=1, scale=3),
+                 index=WeibullMinimum(c=1.5, scale=4), angle=10.0, angle_degrees=True)
+    assert ser.free_names() == ['index', 'mag', 'reff_b']
+    vals = ser.values_batch(np.array([[2.0, 21.0, 3.0], [1.0, 20.5, 6.0]]))
+    assert vals['xy'].shape == (2, 2) and vals['reff'].tolist() == [5.0, 5.0]
+    lp = ser.log_priors_batch(np.array([[2.0, 21.0, 3.0], [1.0, 20.5, 6.0]]))
+    assert np.isfinite(lp[0]) and lp[1] == -np.inf      # reff_b=6 > reff=5
+
+
+def test_discrete_prior_rounds():
+    d = DiscreteUniform(low=0, high=3)
+    d.value = np.array([1.6])
+    assert d.value == 2 and isinstance(d.value, int)
+    assert np.allclose(d.logp_batch(np.array([[0.2], [2.4], [2.6]])),
+                       [np.log(1 / 3.), np.log(1 / 3.), -np.inf])
+
+
+def test_unknown_component_is_rejected(tmp_path):
+    from psfmc_amd.ModelComponents.ComponentBase import ComponentBase
+    from psfmc_amd.ModelComponents import Configuration
+    case = helpers.load_case('synth128x2')
+
+    class Blob(ComponentBase):
+        pass
+    cfg = Configuration(case['sci'], case['ivm'], case['psfs'][0], case['psf_ivms'][0])
+    with pytest.raises(NotImplementedError):
+        MultiComponentModel([cfg, Blob()])
+    with pytest.raises(ValueError):
+        MultiComponentModel([Sky(adu=0.0)])
+
+
+def test_model_file_redirects_reference_imports(tmp_path):
+    case = helpers.load_case('synth128x2')
+    helpers.write_case_files('synth128x2', case, tmp_path)
+    text = ('import psfMC.distributions\n'
+            'from psfMC.ModelComponents import Configuration, Sky\n'
+            'from psfMC.distributions import Normal\n'
+            "Configuration(obs_file='sci.fits', obsivm_file='ivm.fits', psf_files='psf.fits',\n"
+            "              psfivm_files='psf_ivm.fits', mag_zeropoint=25.0)\n"
+            'for level in (0.0,):\n'
+            '    Sky(adu=Normal(loc=level, scale=0.1))\n')
+    path = tmp_path / 'm.py'
+    path.write_text(text)
+    model = MultiComponentModel(str(path))
+    assert model.param_names == ['0_Sky_adu']
+    assert os.getcwd() != str(tmp_path)
+
+
+def test_library_exports_every_declared_symbol():
+    """include/psfmc_hip.h <-> libpsfmc_hip.so (load only; no GPU calls)."""
+    root = os.path.dirname(helpers.GOLDEN.rstrip('/').rsplit('/tests', 1)[0] + '/x')
+    header = open(os.path.join(root, 'include', 'psfmc_hip.h')).read()
+    declared = set(re.findall(r'\b(psfmc_[a-z_]+)\s*\(', header))
+    assert {'psfmc_ctx_create', 'psfmc_eval_batch', 'psfmc_eval_batch_device',
+            'psfmc_eval_images', 'psfmc_ctx_destroy', 'psfmc_last_error'} <= declared
+    lib = engine.load_library()
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    assert lib.psfmc_abi_version() == 1
+    assert isinstance(lib, ctypes.CDLL)
+
+
+def test_native_argument_errors_without_gpu():
+    """Argument validation happens before any device is touched."""
+    lib = engine.load_library()
+    handle = ctypes.c_void_p()
+    a = np.zeros((4, 4))
+    bad = np.zeros((4, 4), dtype=np.uint8)
+    dp = ctypes.POINTER(ctypes.c_double)
+    rc = lib.psfmc_ctx_create(ctypes.byref(handle), 0, 5, 4, a.ctypes.data_as(dp),
+                              a.ctypes.data_as(dp), bad.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
+                              1, 2, 2, a.ctypes.data_as(dp), a.ctypes.data_as(dp), 1, 1, 8, 1)
+    assert rc == -1 and b'even' in lib.psfmc_last_error()
+    assert handle.value is None
