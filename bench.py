@@ -1,0 +1,186 @@
+#!/usr/bin/env python
+"""
+bench.py -- walker log-posterior evaluations per second (BASELINE.json metric).
+
+A *step* is one pass of the hot path over one batch of synthetic walkers: the
+256x256 field with 1 PointSource + 1 Sersic (BASELINE.json configs[1] shape /
+SURVEY.md section 8(d) headline), W walkers per GPU, derived-parameter rows already
+resident in HBM; the step ends with the all-gather of the log-likelihoods
+across ranks (N > 1).  One process per GPU (`python -m torch.distributed.run`
+for N > 1); weak scaling (per-GPU batch fixed).
+
+Prints ONE JSON line on rank 0 (contract in the task description), including
+  roofline      algorithmic bytes (96 N^2 + 64 N per evaluation)
+                over the live-measured device time of the evaluation pipeline
+  cpu_baseline  the numpy oracle (a port of the reference algorithm) timed on
+                this host, one walker per call like the reference
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'tools')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBPS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md, chip-level table
+
+
+def algorithmic_bytes_per_eval(n):
+    return 96 * n * n + 64 * n
+
+
+def build_problem(args, device):
+    """Synthetic field + walker rows.  Returns (model, theta[W,P])."""
+    import tempfile
+    import synth_field
+    from psfmc_amd import MultiComponentModel, fits_io
+    fld = synth_field.make_field(args.size, args.sersic, seed=0)
+    tmp = tempfile.mkdtemp(prefix='psfmc_bench_')
+    for key, name in (('sci', 'sci.fits'), ('ivm', 'ivm.fits'), ('psf', 'psf.fits'),
+                      ('psf_ivm', 'psf_ivm.fits')):
+        fits_io.write_image(os.path.join(tmp, name), fld[key])
+    path = os.path.join(tmp, 'model.py')
+    with open(path, 'w') as f:
+        f.write(synth_field.model_file_text(args.size, args.sersic))
+    model = MultiComponentModel(path, device=device, backend=args.backend,
+                                max_walkers=args.walkers)
+    half = args.walkers // 2
+    theta = np.vstack([
+        synth_field.draw_walkers(args.size, args.sersic, half, seed=1),
+        synth_field.draw_walkers(args.size, args.sersic, args.walkers - half, seed=2,
+                                 near_truth=fld['truth'])])
+    return model, theta, fld
+
+
+def cpu_baseline(args, fld, theta, budget_s):
+    """The oracle, one walker per call (the reference's execution model,
+    psfMC/fitting.py:55), on a bounded sample of the same walkers."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import psfmc_oracle as orc
+    import helpers
+    field = orc.make_field(fld['sci'], fld['ivm'], [fld['psf']], [fld['psf_ivm']],
+                           mag_zp=fld['mag_zp'])
+    layout = helpers.synth_layout(args.sersic)
+    done, t0 = 0, time.perf_counter()
+    vals = []
+    while True:
+        vals.append(helpers.oracle_loglike(field, layout, theta[done % len(theta)],
+                                           raw_dtype=None))
+        done += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or done >= len(theta):
+            break
+    return {'value': done / el, 'unit': 'evals/s', 'cores': 1, 'kind': 'port',
+            'sample': '%d walkers of the same batch, one per call, %.1f s' % (done, el)}, vals
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--walkers', type=int, default=4096, help='walkers per GPU per step')
+    ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--sersic', type=int, default=1)
+    ap.add_argument('--backend', default=os.environ.get('PSFMC_BACKEND', 'hipfft'))
+    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--no-cpu', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (there is no CPU fallback)')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    model, theta, fld = build_problem(args, local)
+    eng = model.engine
+    rows = torch.from_numpy(model.derived_rows(theta)).to(dev)
+    out = torch.empty(args.walkers, dtype=torch.float64, device=dev)
+    gathered = torch.empty(args.walkers * world, dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        eng.loglike_device(args.walkers, rows.data_ptr(), 0, out.data_ptr(), stream.cuda_stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, out)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # sanity: the batch the timing ran on is numerically right
+    lnlike = out.cpu().numpy()
+    n_finite = int(np.isfinite(lnlike).sum())
+
+    if rank == 0:
+        total_evals = args.walkers * world * args.steps
+        value = total_evals / elapsed
+        b_eval = algorithmic_bytes_per_eval(args.size)
+        launch_s = dev_ms * 1e-3 / args.steps            # device time of one pipeline pass
+        achieved = b_eval * args.walkers / launch_s / 1e9
+        line = {
+            'metric': 'walker log-posterior evals/sec, 256x256 image, 1 PSF+1 Sersic',
+            'value': value, 'unit': 'evals/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'synthetic %dx%d field, 1 PointSource + %d Sersic, %d walkers '
+                                   'per GPU per step, fp64, rows resident in HBM'
+                                   % (args.size, args.size, args.sersic, args.walkers),
+                       'image': args.size, 'walkers_per_gpu': args.walkers,
+                       'backend': args.backend, 'parallelism': 'walkers sharded x%d' % world},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
+                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
+                         'kernel': 'evaluation pipeline (one eval_batch_device pass)',
+                         'bytes_per_eval': b_eval, 'launch_ms': launch_s * 1e3},
+            'finite_loglikes': n_finite,
+        }
+        if not args.no_cpu:
+            base, vals = cpu_baseline(args, fld, theta, args.cpu_seconds)
+            line['cpu_baseline'] = base
+            ref = np.array(vals)
+            got = lnlike[:len(ref)]
+            fin = np.isfinite(ref)
+            line['check_vs_cpu_rel'] = float(np.max(np.abs(got[fin] - ref[fin]) / np.abs(ref[fin])))
+        print(json.dumps(line))
+    model.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
