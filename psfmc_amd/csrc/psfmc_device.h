@@ -14,8 +14,12 @@ constexpr int kRowPs = 4;
 constexpr int kRowSersic = 9;
 
 constexpr int kTaps = 7;        // widest point-source window (lanczos3)
-// prep record (doubles): [0] sky | per PS: ylo, yn, xlo, xn, wy[7], wx[7] (flux
-// folded into wx) | per Sersic: x0 y0 m00 m01 m10 m11 kappa p sb_eff | psf index
+// prep record (doubles):
+//   [0] sky  [1] psf index  [2] mu  [3] 1/lambda   (channel scales of the fused path)
+//   per PS: ylo, yn, xlo, xn, wy[7], wx[7] (flux folded into wx)
+//   per Sersic: x0 y0 m00 m01 m10 m11 kappa p sb_eff
+constexpr int kPrepHead = 4;
+constexpr int kPrepPsfIdx = 1, kPrepMu = 2, kPrepInvLambda = 3;
 constexpr int kPrepPs = 4 + 2 * kTaps;
 constexpr int kPrepSersic = 9;
 
@@ -23,7 +27,7 @@ __host__ __device__ inline int row_len(int n_ps, int n_sersic) {
     return kRowSky + kRowPs * n_ps + kRowSersic * n_sersic + 1;
 }
 __host__ __device__ inline int prep_len(int n_ps, int n_sersic) {
-    return 1 + kPrepPs * n_ps + kPrepSersic * n_sersic + 1;
+    return kPrepHead + kPrepPs * n_ps + kPrepSersic * n_sersic;
 }
 
 // ---------------------------------------------------------------------------
@@ -57,11 +61,21 @@ __device__ inline void ps_window(double c, int n, int method, int* lo, int* cnt)
 }
 
 // Expand one caller row into a prep record.  One thread per walker.
+//
+// mu / lambda: the fused path transforms raw + i*mu*raw^2 as ONE complex signal
+// and gets conv + i*lambda*var back from one inverse transform.  A complex FFT's
+// rounding error in either part is ~eps times the norm of the WHOLE signal, so the
+// two channels are kept at comparable magnitude with exact power-of-two scales:
+// mu ~ 1/peak(raw) (then mu*raw^2 ~ raw) and lambda = mu*rho with rho ~ 1/sum(psf
+// variance map) a per-PSF constant already folded into the kernel spectrum
+// (then lambda*var ~ conv).  `peak` only needs the right order of magnitude.
 __device__ inline void build_prep(const double* __restrict__ row, double* __restrict__ prep,
-                                  int n_ps, int n_sersic, int ny, int nx) {
+                                  int n_ps, int n_sersic, int ny, int nx,
+                                  const double* __restrict__ rho) {
     prep[0] = row[0];
+    double peak = fabs(row[0]);
     const double* r = row + kRowSky;
-    double* p = prep + 1;
+    double* p = prep + kPrepHead;
     for (int k = 0; k < n_ps; ++k, r += kRowPs, p += kPrepPs) {
         const double flux = r[0], x0 = r[1], y0 = r[2];
         const int method = (int)r[3];
@@ -73,9 +87,26 @@ __device__ inline void build_prep(const double* __restrict__ row, double* __rest
             p[4 + t] = t < yn ? ps_weight((double)(ylo + t) - y0, method) : 0.0;
             p[4 + kTaps + t] = t < xn ? ps_weight((double)(xlo + t) - x0, method) * flux : 0.0;
         }
+        peak = fmax(peak, fabs(flux));
     }
-    for (int k = 0; k < n_sersic * kRowSersic; ++k) p[k] = r[k];
-    p[n_sersic * kRowSersic] = r[n_sersic * kRowSersic];     // psf index
+    for (int k = 0; k < n_sersic; ++k, r += kRowSersic, p += kPrepSersic) {
+        for (int j = 0; j < kRowSersic; ++j) p[j] = r[j];
+        // brightness half a pixel from the centre along the minor axis
+        const double rho2 = 0.25 * fmax(r[2] * r[2] + r[4] * r[4], r[3] * r[3] + r[5] * r[5]);
+        const double core = r[8] * exp(-r[6] * expm1(log(rho2) * r[7]));
+        if (core == core) peak = fmax(peak, fabs(core));
+    }
+    const int psf = (int)r[0];
+    prep[kPrepPsfIdx] = (double)psf;
+    double mu = 1.0;
+    if (peak > 0.0 && peak < 1e300) {
+        int e;
+        (void)frexp(peak, &e);                 // peak = m * 2^e, m in [0.5, 1)
+        mu = ldexp(1.0, -e);
+    }
+    const double lambda = mu * (rho ? rho[psf] : 1.0);
+    prep[kPrepMu] = mu;
+    prep[kPrepInvLambda] = 1.0 / lambda;
 }
 
 // ---------------------------------------------------------------------------
@@ -119,7 +150,7 @@ __device__ inline double ps_pixel(const double* __restrict__ p, int ix, int iy) 
 __device__ inline double raster_pixel(const double* __restrict__ prep, int n_ps, int n_sersic,
                                       int ix, int iy, bool ps_only) {
     double val = ps_only ? 0.0 : prep[0];
-    const double* p = prep + 1;
+    const double* p = prep + kPrepHead;
     for (int k = 0; k < n_ps; ++k, p += kPrepPs) val += ps_pixel(p, ix, iy);
     if (!ps_only) {
         const double x = (double)ix, y = (double)iy;

@@ -1,0 +1,164 @@
+// psfmc_fft.h -- register/LDS complex FFT engine for gfx950 (fp64).
+//
+// One length-N transform (N = P*T, power of two) is computed by T adjacent lanes
+// of a wave, each holding P points in registers:
+//     v[a] = x[T*a + t]          on entry  (t = lane within the group, a < P)
+//     v[e] = X[t + T*e]          on exit   (natural order, same striding)
+// so that global loads/stores of consecutive lanes touch consecutive addresses.
+// Decimation in frequency, two stages with ONE exchange through LDS:
+//   stage 1  radix-P DFT over a in registers, then the twiddle W_N^(t*c)
+//   exchange y[t][c] -> LDS rows of P+1 complex (the +1 keeps ds_write_b128 of
+//            the T lanes on distinct banks; reads are contiguous across lanes)
+//   stage 2  P/T radix-T DFTs over the T lanes' values, in registers
+//   X[c + P*d] = sum_b W_N^(b c) W_T^(b d) sum_a x[T a + b] W_P^(a c)
+// The in-register DFTs are fully unrolled radix-2 recursions with compile-time
+// twiddles (trivial factors 1, -i, (1-i)/sqrt2 special-cased).  Direction is a
+// template parameter: SIGN = -1 forward (numpy's convention), +1 inverse
+// (unnormalised).  A 64-lane wave holds 64/T transforms side by side.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace psfmc {
+
+struct cd {
+    double x, y;
+};
+
+__device__ __forceinline__ cd cadd(cd a, cd b) { return cd{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cd csub(cd a, cd b) { return cd{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cd cmul(cd a, cd b) {
+    return cd{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+}
+__device__ __forceinline__ cd cconj(cd a) { return cd{a.x, -a.y}; }
+
+template <int N> struct FftShape;
+template <> struct FftShape<32>   { static constexpr int P = 8,  T = 4;  };
+template <> struct FftShape<64>   { static constexpr int P = 8,  T = 8;  };
+template <> struct FftShape<128>  { static constexpr int P = 16, T = 8;  };
+template <> struct FftShape<256>  { static constexpr int P = 16, T = 16; };
+template <> struct FftShape<512>  { static constexpr int P = 32, T = 16; };
+template <> struct FftShape<1024> { static constexpr int P = 32, T = 32; };
+
+// LDS complex elements one transform needs for its exchange
+template <int N> constexpr int fft_lds_elems() { return FftShape<N>::T * (FftShape<N>::P + 1); }
+
+// cos(2 pi k / 32), k = 0..8
+__device__ constexpr double kCos32[9] = {
+    1.0,
+    0.98078528040323044912618223613423903697393373089333609500291,
+    0.92387953251128675612818318939678828682241662586364248611509,
+    0.83146961230254523707878837761790575673856081198797241619098,
+    0.70710678118654752440084436210484903928483593768847403658834,
+    0.55557023301960222474283081394853287437493719075480404592415,
+    0.38268343236508977172845998403039886676134456248562704143380,
+    0.19509032201612826784828486847702224092769161775195480775450,
+    0.0};
+
+// real / imaginary part of exp(SIGN * 2 pi i * k / R), compile time, R | 32
+template <int R, int K> __device__ constexpr double tw_cos() {
+    constexpr int k = ((K % R) + R) % R * (32 / R);          // in 32nds of a turn
+    return k <= 8 ? kCos32[k] : k <= 16 ? -kCos32[16 - k] : k <= 24 ? -kCos32[k - 16] : kCos32[32 - k];
+}
+template <int R, int K> __device__ constexpr double tw_sin() {   // sin(2 pi K / R)
+    return tw_cos<R, K - R / 4>();
+}
+
+// t = v * exp(SIGN 2 pi i K / R)
+template <int R, int K, int SIGN> __device__ __forceinline__ cd tw_mul(cd v) {
+    constexpr int k = ((K % R) + R) % R;
+    if constexpr (k == 0) {
+        return v;
+    } else if constexpr (4 * k == R) {            // exp(SIGN i pi/2) = SIGN i
+        return SIGN < 0 ? cd{v.y, -v.x} : cd{-v.y, v.x};
+    } else if constexpr (2 * k == R) {
+        return cd{-v.x, -v.y};
+    } else if constexpr (4 * k == 3 * R) {
+        return SIGN < 0 ? cd{-v.y, v.x} : cd{v.y, -v.x};
+    } else {
+        constexpr double c = tw_cos<R, k>();
+        constexpr double s = SIGN * tw_sin<R, k>();
+        return cd{v.x * c - v.y * s, v.x * s + v.y * c};
+    }
+}
+
+// in-register DFT of R points, natural order in and out
+template <int R, int SIGN> struct Dft {
+    static __device__ __forceinline__ void run(cd (&v)[R]) {
+        cd ev[R / 2], od[R / 2];
+#pragma unroll
+        for (int i = 0; i < R / 2; ++i) {
+            ev[i] = v[2 * i];
+            od[i] = v[2 * i + 1];
+        }
+        Dft<R / 2, SIGN>::run(ev);
+        Dft<R / 2, SIGN>::run(od);
+        combine<0>(v, ev, od);
+    }
+    template <int K>
+    static __device__ __forceinline__ void combine(cd (&v)[R], const cd (&ev)[R / 2], const cd (&od)[R / 2]) {
+        if constexpr (K < R / 2) {
+            const cd t = tw_mul<R, K, SIGN>(od[K]);
+            v[K] = cadd(ev[K], t);
+            v[K + R / 2] = csub(ev[K], t);
+            combine<K + 1>(v, ev, od);
+        }
+    }
+};
+template <int SIGN> struct Dft<1, SIGN> {
+    static __device__ __forceinline__ void run(cd (&)[1]) {}
+};
+template <int SIGN> struct Dft<2, SIGN> {
+    static __device__ __forceinline__ void run(cd (&v)[2]) {
+        const cd a = v[0], b = v[1];
+        v[0] = cadd(a, b);
+        v[1] = csub(a, b);
+    }
+};
+
+// Per-lane inter-stage twiddles W_N^(t*c), c < P, from the table tw[k] =
+// exp(-2 pi i k/N).  For P <= 16 they live in registers for the whole kernel;
+// for P = 32 that would cost 128 VGPRs, so they are re-read from the (L1/L2
+// resident) table at each use instead.
+template <int N> constexpr bool fft_tw_in_regs() { return FftShape<N>::P <= 16; }
+template <int N> constexpr int fft_tw_regs() { return fft_tw_in_regs<N>() ? FftShape<N>::P : 1; }
+
+template <int N>
+__device__ __forceinline__ void load_twiddles(cd (&w)[fft_tw_regs<N>()], const cd* __restrict__ table, int t) {
+    if constexpr (fft_tw_in_regs<N>()) {
+#pragma unroll
+        for (int c = 0; c < FftShape<N>::P; ++c) w[c] = table[t * c];
+    } else {
+        w[0] = cd{1.0, 0.0};
+    }
+}
+
+// The cooperative transform.  `xbuf` = this transform's private LDS region of
+// fft_lds_elems<N>() complex; every thread of the block must call (it contains
+// two block barriers), `t` in [0,T).  `w` from load_twiddles (forward table).
+template <int N, int SIGN>
+__device__ __forceinline__ void fft_coop(cd (&v)[FftShape<N>::P], const cd (&w)[fft_tw_regs<N>()],
+                                         const cd* __restrict__ table, int t, cd* __restrict__ xbuf) {
+    constexpr int P = FftShape<N>::P, T = FftShape<N>::T;
+    Dft<P, SIGN>::run(v);
+    cd* row = xbuf + t * (P + 1);
+    row[0] = v[0];
+#pragma unroll
+    for (int c = 1; c < P; ++c) {
+        cd wc;
+        if constexpr (fft_tw_in_regs<N>()) wc = w[c]; else wc = table[t * c];
+        row[c] = cmul(v[c], SIGN < 0 ? wc : cconj(wc));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < P / T; ++h) {
+        cd z[T];
+#pragma unroll
+        for (int b = 0; b < T; ++b) z[b] = xbuf[b * (P + 1) + t + T * h];
+        Dft<T, SIGN>::run(z);
+#pragma unroll
+        for (int d = 0; d < T; ++d) v[h + (P / T) * d] = z[d];
+    }
+    __syncthreads();
+}
+
+}  // namespace psfmc

@@ -16,6 +16,7 @@
 
 #include "psfmc_device.h"
 #include "psfmc_hipfft_path.h"
+#include "psfmc_fused_path.h"
 
 using namespace psfmc;
 
@@ -51,6 +52,24 @@ static int fail(int code, const char* fmt, ...) {
                         (int)r_, __FILE__, __LINE__);                                  \
     } while (0)
 
+#define RC_TRY(expr)                     \
+    do {                                 \
+        int rc_ = (expr);                \
+        if (rc_ != PSFMC_OK) return rc_; \
+    } while (0)
+
+// run BODY with `N_` a compile-time copy of the (power-of-two) length n
+#define DISPATCH_LEN(n, BODY)                                                                   \
+    switch (n) {                                                                                \
+        case 32:   { constexpr int N_ = 32;   BODY; } break;                                    \
+        case 64:   { constexpr int N_ = 64;   BODY; } break;                                    \
+        case 128:  { constexpr int N_ = 128;  BODY; } break;                                    \
+        case 256:  { constexpr int N_ = 256;  BODY; } break;                                    \
+        case 512:  { constexpr int N_ = 512;  BODY; } break;                                    \
+        case 1024: { constexpr int N_ = 1024; BODY; } break;                                    \
+        default: return fail(PSFMC_EINVAL, "fused backend supports sides 32..1024, got %d", n); \
+    }
+
 // ---------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------
@@ -60,28 +79,39 @@ struct psfmc_ctx {
     int n_psf = 0, n_ps = 0, n_sersic = 0;
     int max_walkers = 0, chunk = 0, backend = 0;
     int rlen = 0, plen = 0;
+    int nblk = 0;                 // chi^2 partial sums per walker
     hipStream_t stream = nullptr;
     // shared field arrays (SURVEY row Cfg)
     double *d_sci = nullptr, *d_var = nullptr;
     uint8_t* d_bad = nullptr;
-    double2 *d_pspec = nullptr, *d_vspec = nullptr;   // [n_psf][ny][nxh], = numpy rfft2
     // per-call staging
     double *d_rows = nullptr, *d_prep = nullptr, *d_like = nullptr, *d_partial = nullptr;
     uint8_t* d_skip = nullptr;
-    // hipFFT path work space
-    double* d_real = nullptr;     // [2*chunk][S]
-    double2* d_spec = nullptr;    // [2*chunk][F]
+    // hipFFT path
+    double2 *d_pspec = nullptr, *d_vspec = nullptr;   // [n_psf][ny][nxh] == numpy rfft2
+    double* d_real = nullptr;                         // [2*chunk][S]
+    double2* d_spec = nullptr;                        // [2*chunk][F]
     std::map<int, std::pair<hipfftHandle, hipfftHandle>> plans;   // batch -> (D2Z, Z2D)
     hipfftHandle plan_fwd = 0, plan_inv = 0;                      // the pair in use
-    int chi2_blocks = 0;
+    // fused path
+    cd* d_T = nullptr;        // [chunk][2][nxh][ny] transposed half-spectra
+    cd* d_Kraw = nullptr;     // [n_psf][2][nxh][ny] kernel spectra, unscaled
+    cd* d_Kt = nullptr;       // same * (-1)^(kx+ky) / S
+    cd *d_twx = nullptr, *d_twy = nullptr;            // exp(-2 pi i k/n) tables
+    double* d_rho = nullptr;  // [n_psf] power-of-two scale of the variance channel
+    double *d_img0 = nullptr, *d_img1 = nullptr;      // [chunk][S] staging for eval_images
+    int img_cap = 0;
+    int cols_grid = 0;
 };
 
-// batched 2-D plans for `batch` images, cached per batch size (a half-ensemble
-// call and a full-ensemble call use different sizes)
+// ---------------------------------------------------------------------------
+// hipFFT plans, cached per batch size (a half-ensemble call and a full-ensemble
+// call use different sizes)
+// ---------------------------------------------------------------------------
 static int use_plans(psfmc_ctx* c, int batch) {
     auto it = c->plans.find(batch);
     if (it == c->plans.end()) {
-        if (c->plans.size() >= 8) {            // bound the cache
+        if (c->plans.size() >= 8) {
             for (auto& kv : c->plans) {
                 hipfftDestroy(kv.second.first);
                 hipfftDestroy(kv.second.second);
@@ -99,20 +129,213 @@ static int use_plans(psfmc_ctx* c, int batch) {
     return PSFMC_OK;
 }
 
+static void free_work(psfmc_ctx* c) {
+    void** bufs[] = {(void**)&c->d_real, (void**)&c->d_spec, (void**)&c->d_T};
+    for (void** p : bufs)
+        if (*p) {
+            (void)hipFree(*p);
+            *p = nullptr;
+        }
+}
+
 static int alloc_work(psfmc_ctx* c) {
-    const size_t nimg = (size_t)2 * c->chunk;
-    if (c->d_real) { (void)hipFree(c->d_real); c->d_real = nullptr; }
-    if (c->d_spec) { (void)hipFree(c->d_spec); c->d_spec = nullptr; }
-    HIP_TRY(hipMalloc(&c->d_real, nimg * c->S * sizeof(double)));
-    HIP_TRY(hipMalloc(&c->d_spec, nimg * c->F * sizeof(double2)));
-    return use_plans(c, (int)nimg);
+    free_work(c);
+    if (c->backend == PSFMC_BACKEND_HIPFFT) {
+        const size_t nimg = (size_t)2 * c->chunk;
+        HIP_TRY(hipMalloc(&c->d_real, nimg * c->S * sizeof(double)));
+        HIP_TRY(hipMalloc(&c->d_spec, nimg * c->F * sizeof(double2)));
+        return use_plans(c, (int)nimg);
+    }
+    HIP_TRY(hipMalloc(&c->d_T, (size_t)c->chunk * 2 * c->nxh * c->ny * sizeof(cd)));
+    return PSFMC_OK;
 }
 
 static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
+// ---------------------------------------------------------------------------
+// fused path launchers
+// ---------------------------------------------------------------------------
+static int rows_per_block_for(int nx) {
+    DISPATCH_LEN(nx, return fused_ffts_per_block<N_>());
+    return 0;
+}
+
+template <int NX, bool FROM_IMAGE>
+static int launch_rows_fwd(psfmc_ctx* c, int n, const double* prep, const uint8_t* skip, cd* Tbuf,
+                           int ps_only, const double* img, const double* img_scale, double* raw_out,
+                           hipStream_t st) {
+    constexpr size_t lds = fused_row_lds_bytes<NX>();
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows_fwd<NX, FROM_IMAGE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_rows_fwd<NX, FROM_IMAGE>), dim3(c->ny / fused_ffts_per_block<NX>(), n),
+                       dim3(kFusedThreads), lds, st, prep, skip, c->d_twx, Tbuf, c->n_ps, c->n_sersic,
+                       c->ny, ps_only, img, img_scale, raw_out);
+    return PSFMC_OK;
+}
+
+template <int NY, bool CONVOLVE>
+static int launch_cols(psfmc_ctx* c, cd* Tbuf, int n_cols, const double* prep, const uint8_t* skip,
+                       hipStream_t st) {
+    constexpr size_t lds = fused_col_lds_bytes<NY>();
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cols<NY, CONVOLVE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int groups = (n_cols + fused_ffts_per_block<NY>() - 1) / fused_ffts_per_block<NY>();
+    const int grid = groups < c->cols_grid ? groups : c->cols_grid;
+    hipLaunchKernelGGL((k_cols<NY, CONVOLVE>), dim3(grid), dim3(kFusedThreads), lds, st, Tbuf, c->d_Kt,
+                       prep, skip, c->d_twy, c->plen, c->nxh, n_cols);
+    return PSFMC_OK;
+}
+
+template <int NX>
+static int launch_rows_inv(psfmc_ctx* c, int n, const double* prep, const uint8_t* skip, double* partial,
+                           double* conv_out, double* var_out, hipStream_t st) {
+    constexpr size_t lds = fused_row_lds_bytes<NX>();
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows_inv<NX>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_rows_inv<NX>), dim3(c->ny / fused_ffts_per_block<NX>(), n), dim3(kFusedThreads),
+                       lds, st, c->d_T, skip, c->d_twx, c->d_sci, c->d_var, c->d_bad, partial, c->ny,
+                       prep, c->plen, conv_out, var_out);
+    return PSFMC_OK;
+}
+
+// rasterise + both convolutions of `n` walkers; results stay in d_T (spectral
+// rows after the column pass).  rows_inv is launched by the caller.
+static int fused_forward(psfmc_ctx* c, int n, const double* prep, const uint8_t* skip, int ps_only,
+                         double* raw_out, hipStream_t st) {
+    DISPATCH_LEN(c->nx, RC_TRY((launch_rows_fwd<N_, false>(c, n, prep, skip, c->d_T, ps_only, nullptr,
+                                                           nullptr, raw_out, st))));
+    DISPATCH_LEN(c->ny, RC_TRY((launch_cols<N_, true>(c, c->d_T, n * 2 * c->nxh, prep, skip, st))));
+    return PSFMC_OK;
+}
+
+static int fused_inverse(psfmc_ctx* c, int n, const double* prep, const uint8_t* skip, double* partial,
+                         double* conv_out, double* var_out, hipStream_t st) {
+    DISPATCH_LEN(c->nx, RC_TRY((launch_rows_inv<N_>(c, n, prep, skip, partial, conv_out, var_out, st))));
+    return PSFMC_OK;
+}
+
+static std::vector<cd> twiddle_table(int n) {
+    std::vector<cd> t(n);
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    for (int k = 0; k < n; ++k) {
+        const long double a = two_pi * (long double)k / (long double)n;
+        t[k] = cd{(double)cosl(a), (double)-sinl(a)};
+    }
+    return t;
+}
+
+// ---------------------------------------------------------------------------
+// F0: kernel spectra on the device (replaces utils.py:9-22, :126-133)
+// d_canvas: [2*n_psf][S], image 2p = padded PSF p, image 2p+1 = its variance map
+// ---------------------------------------------------------------------------
+static int spectra_hipfft(psfmc_ctx* c, const double* d_canvas) {
+    HIP_TRY(hipMalloc(&c->d_pspec, (size_t)c->n_psf * c->F * sizeof(double2)));
+    HIP_TRY(hipMalloc(&c->d_vspec, (size_t)c->n_psf * c->F * sizeof(double2)));
+    hipfftHandle plan;
+    int n[2] = {c->ny, c->nx};
+    FFT_TRY(hipfftPlanMany(&plan, 2, n, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_D2Z, 1));
+    int rc = PSFMC_OK;
+    hipfftSetStream(plan, c->stream);
+    for (int p = 0; p < c->n_psf && rc == PSFMC_OK; ++p) {
+        double* a = const_cast<double*>(d_canvas) + (size_t)(2 * p) * c->S;
+        if (hipfftExecD2Z(plan, a, (hipfftDoubleComplex*)(c->d_pspec + (size_t)p * c->F)) != HIPFFT_SUCCESS ||
+            hipfftExecD2Z(plan, a + c->S, (hipfftDoubleComplex*)(c->d_vspec + (size_t)p * c->F)) !=
+                HIPFFT_SUCCESS)
+            rc = fail(PSFMC_EHIP, "hipfftExecD2Z (PSF spectra) failed");
+    }
+    (void)hipStreamSynchronize(c->stream);
+    hipfftDestroy(plan);
+    return rc;
+}
+
+static int spectra_fused(psfmc_ctx* c, const double* d_canvas) {
+    const size_t n_el = (size_t)c->n_psf * 2 * c->nxh * c->ny;
+    HIP_TRY(hipMalloc(&c->d_Kraw, n_el * sizeof(cd)));
+    HIP_TRY(hipMalloc(&c->d_Kt, n_el * sizeof(cd)));
+    DISPATCH_LEN(c->nx, RC_TRY((launch_rows_fwd<N_, true>(c, c->n_psf, nullptr, nullptr, c->d_Kraw, 0,
+                                                          d_canvas, c->d_rho, nullptr, c->stream))));
+    DISPATCH_LEN(c->ny, RC_TRY((launch_cols<N_, false>(c, c->d_Kraw, c->n_psf * 2 * c->nxh, nullptr,
+                                                       nullptr, c->stream))));
+    hipLaunchKernelGGL(k_scale_kernel_spectrum, dim3(256), dim3(256), 0, c->stream, c->d_Kraw, c->d_Kt,
+                       (int)n_el, c->ny, c->nxh, 1.0 / (double)c->S);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PSFMC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// API
+// ---------------------------------------------------------------------------
 extern "C" int psfmc_abi_version(void) { return 1; }
 
 extern "C" const char* psfmc_last_error(void) { return g_err.c_str(); }
+
+static int ctx_init(psfmc_ctx* c, const double* sci, const double* obs_var, const uint8_t* bad_px,
+                    int psf_ny, int psf_nx, const double* psf, const double* psf_var) {
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc(&c->d_sci, c->S * sizeof(double)));
+    HIP_TRY(hipMalloc(&c->d_var, c->S * sizeof(double)));
+    HIP_TRY(hipMalloc(&c->d_bad, c->S));
+    HIP_TRY(hipMemcpy(c->d_sci, sci, c->S * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_var, obs_var, c->S * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_bad, bad_px, c->S, hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&c->d_rows, (size_t)c->max_walkers * c->rlen * sizeof(double)));
+    HIP_TRY(hipMalloc(&c->d_prep, (size_t)c->max_walkers * c->plen * sizeof(double)));
+    HIP_TRY(hipMalloc(&c->d_like, (size_t)c->max_walkers * sizeof(double)));
+    HIP_TRY(hipMalloc(&c->d_skip, (size_t)c->max_walkers));
+    HIP_TRY(hipMalloc(&c->d_partial, (size_t)c->max_walkers * c->nblk * sizeof(double)));
+
+    if (c->backend == PSFMC_BACKEND_FUSED) {
+        const std::vector<cd> tx = twiddle_table(c->nx), ty = twiddle_table(c->ny);
+        HIP_TRY(hipMalloc(&c->d_twx, tx.size() * sizeof(cd)));
+        HIP_TRY(hipMalloc(&c->d_twy, ty.size() * sizeof(cd)));
+        HIP_TRY(hipMemcpy(c->d_twx, tx.data(), tx.size() * sizeof(cd), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_twy, ty.data(), ty.size() * sizeof(cd), hipMemcpyHostToDevice));
+        // rho[p] = 2^-round(log2(sum of the variance map)): brings the variance
+        // channel of the packed complex transforms up to the model channel's scale
+        std::vector<double> rho(c->n_psf, 1.0);
+        const size_t small_n = (size_t)psf_ny * psf_nx;
+        for (int p = 0; p < c->n_psf; ++p) {
+            double tot = 0.0;
+            for (size_t i = 0; i < small_n; ++i) tot += psf_var[(size_t)p * small_n + i];
+            if (tot > 0.0 && std::isfinite(tot)) {
+                int e;
+                (void)frexp(tot, &e);
+                rho[p] = ldexp(1.0, -e);
+            }
+        }
+        HIP_TRY(hipMalloc(&c->d_rho, c->n_psf * sizeof(double)));
+        HIP_TRY(hipMemcpy(c->d_rho, rho.data(), c->n_psf * sizeof(double), hipMemcpyHostToDevice));
+    }
+
+    // centre-padded canvases, interleaved (psf0, var0, psf1, var1, ...)
+    const size_t small = (size_t)psf_ny * psf_nx;
+    std::vector<double> inter((size_t)2 * c->n_psf * small);
+    for (int p = 0; p < c->n_psf; ++p) {
+        memcpy(&inter[(size_t)(2 * p) * small], psf + (size_t)p * small, small * sizeof(double));
+        memcpy(&inter[(size_t)(2 * p + 1) * small], psf_var + (size_t)p * small, small * sizeof(double));
+    }
+    double *d_small = nullptr, *d_canvas = nullptr;
+    HIP_TRY(hipMalloc(&d_small, inter.size() * sizeof(double)));
+    int rc = PSFMC_OK;
+    if (hipMalloc(&d_canvas, (size_t)2 * c->n_psf * c->S * sizeof(double)) != hipSuccess)
+        rc = fail(PSFMC_ENOMEM, "hipMalloc(canvas) failed");
+    if (rc == PSFMC_OK &&
+        hipMemcpy(d_small, inter.data(), inter.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(PSFMC_EHIP, "hipMemcpy(psf) failed");
+    if (rc == PSFMC_OK) {
+        hipLaunchKernelGGL(k_pad, dim3(256), dim3(256), 0, c->stream, d_small, d_canvas, 2 * c->n_psf,
+                           psf_ny, psf_nx, c->ny, c->nx);
+        rc = c->backend == PSFMC_BACKEND_FUSED ? spectra_fused(c, d_canvas) : spectra_hipfft(c, d_canvas);
+    }
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(d_small);
+    if (d_canvas) (void)hipFree(d_canvas);
+    RC_TRY(rc);
+    RC_TRY(alloc_work(c));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PSFMC_OK;
+}
 
 extern "C" int psfmc_ctx_create(psfmc_ctx** out, int device, int ny, int nx, const double* sci,
                                 const double* obs_var, const uint8_t* bad_px, int n_psf,
@@ -131,9 +354,16 @@ extern "C" int psfmc_ctx_create(psfmc_ctx** out, int device, int ny, int nx, con
     if (max_walkers < 1) return fail(PSFMC_EINVAL, "max_walkers must be >= 1");
     if (backend != PSFMC_BACKEND_HIPFFT && backend != PSFMC_BACKEND_FUSED)
         return fail(PSFMC_EINVAL, "unknown backend %d", backend);
-    if (backend == PSFMC_BACKEND_FUSED && !(is_pow2(ny) && is_pow2(nx)))
-        return fail(PSFMC_EINVAL, "fused backend needs power-of-two sides (got %d x %d)", ny, nx);
-    if (backend == PSFMC_BACKEND_FUSED) return fail(PSFMC_EINVAL, "fused backend not built yet");
+    int row_tiles = 0;
+    if (backend == PSFMC_BACKEND_FUSED) {
+        if (!(is_pow2(ny) && is_pow2(nx)) || nx < 32 || ny < 32 || nx > 1024 || ny > 1024)
+            return fail(PSFMC_EINVAL, "fused backend needs power-of-two sides in 32..1024 (got %d x %d)",
+                        ny, nx);
+        const int rpb = rows_per_block_for(nx);
+        if (rpb <= 0 || ny % rpb)
+            return fail(PSFMC_EINVAL, "fused backend: ny=%d must be a multiple of %d for nx=%d", ny, rpb, nx);
+        row_tiles = ny / rpb;
+    }
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(PSFMC_ENODEV, "no HIP device");
@@ -152,70 +382,31 @@ extern "C" int psfmc_ctx_create(psfmc_ctx** out, int device, int ny, int nx, con
     c->max_walkers = max_walkers; c->backend = backend;
     c->rlen = row_len(n_ps, n_sersic);
     c->plen = prep_len(n_ps, n_sersic);
-    c->chi2_blocks = (c->S + 1023) / 1024;
-    if (c->chi2_blocks > 64) c->chi2_blocks = 64;
-    // walkers per internal pass: keep the work space of the hipFFT path <= ~6 GiB
-    const double per_walker = 2.0 * (c->S * 8.0 + c->F * 16.0);
-    int chunk = (int)(6.0 * 1073741824.0 / per_walker);
-    if (chunk < 1) chunk = 1;
-    if (chunk > max_walkers) chunk = max_walkers;
-    c->chunk = chunk;
-
-#define CTX_TRY(expr)                         \
-    do {                                      \
-        int rc_ = (expr);                     \
-        if (rc_ != PSFMC_OK) {                \
-            psfmc_ctx_destroy(c);             \
-            return rc_;                       \
-        }                                     \
-    } while (0)
-#define CTX_HIP(expr) CTX_TRY([&]() -> int { HIP_TRY(expr); return PSFMC_OK; }())
-
-    CTX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    CTX_HIP(hipMalloc(&c->d_sci, c->S * sizeof(double)));
-    CTX_HIP(hipMalloc(&c->d_var, c->S * sizeof(double)));
-    CTX_HIP(hipMalloc(&c->d_bad, c->S));
-    CTX_HIP(hipMemcpy(c->d_sci, sci, c->S * sizeof(double), hipMemcpyHostToDevice));
-    CTX_HIP(hipMemcpy(c->d_var, obs_var, c->S * sizeof(double), hipMemcpyHostToDevice));
-    CTX_HIP(hipMemcpy(c->d_bad, bad_px, c->S, hipMemcpyHostToDevice));
-    CTX_HIP(hipMalloc(&c->d_pspec, (size_t)n_psf * c->F * sizeof(double2)));
-    CTX_HIP(hipMalloc(&c->d_vspec, (size_t)n_psf * c->F * sizeof(double2)));
-    CTX_HIP(hipMalloc(&c->d_rows, (size_t)max_walkers * c->rlen * sizeof(double)));
-    CTX_HIP(hipMalloc(&c->d_prep, (size_t)max_walkers * c->plen * sizeof(double)));
-    CTX_HIP(hipMalloc(&c->d_like, (size_t)max_walkers * sizeof(double)));
-    CTX_HIP(hipMalloc(&c->d_skip, (size_t)max_walkers));
-    CTX_HIP(hipMalloc(&c->d_partial, (size_t)max_walkers * 64 * sizeof(double)));
-
-    // F0 on the device: pad + forward transform of every PSF and variance map
-    {
-        const size_t small = (size_t)n_psf * psf_ny * psf_nx;
-        double *d_small = nullptr, *d_canvas = nullptr;
-        CTX_HIP(hipMalloc(&d_small, 2 * small * sizeof(double)));
-        CTX_HIP(hipMalloc(&d_canvas, (size_t)2 * n_psf * c->S * sizeof(double)));
-        CTX_HIP(hipMemcpy(d_small, psf, small * sizeof(double), hipMemcpyHostToDevice));
-        CTX_HIP(hipMemcpy(d_small + small, psf_var, small * sizeof(double), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_pad, dim3(256), dim3(256), 0, c->stream, d_small, d_canvas, 2 * n_psf,
-                           psf_ny, psf_nx, ny, nx);
-        hipfftHandle plan;
-        int n[2] = {ny, nx};
-        int rc = PSFMC_OK;
-        if (hipfftPlanMany(&plan, 2, n, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_D2Z, n_psf) != HIPFFT_SUCCESS)
-            rc = fail(PSFMC_EHIP, "hipfftPlanMany (PSF spectra) failed");
-        if (rc == PSFMC_OK) {
-            hipfftSetStream(plan, c->stream);
-            if (hipfftExecD2Z(plan, d_canvas, (hipfftDoubleComplex*)c->d_pspec) != HIPFFT_SUCCESS ||
-                hipfftExecD2Z(plan, d_canvas + (size_t)n_psf * c->S, (hipfftDoubleComplex*)c->d_vspec) !=
-                    HIPFFT_SUCCESS)
-                rc = fail(PSFMC_EHIP, "hipfftExecD2Z (PSF spectra) failed");
-            (void)hipStreamSynchronize(c->stream);
-            hipfftDestroy(plan);
-        }
-        (void)hipFree(d_small);
-        (void)hipFree(d_canvas);
-        CTX_TRY(rc);
+    if (backend == PSFMC_BACKEND_FUSED) {
+        c->nblk = row_tiles;
+        c->cols_grid = prop.multiProcessorCount * 2;
+        // walkers per internal pass: the transposed half-spectra of one pass
+        const double per_walker = 2.0 * c->nxh * c->ny * 16.0;
+        int chunk = (int)(4.0 * 1073741824.0 / per_walker);
+        if (chunk > 1024) chunk = 1024;
+        c->chunk = chunk < 1 ? 1 : chunk;
+    } else {
+        c->nblk = (c->S + 1023) / 1024;
+        if (c->nblk > 64) c->nblk = 64;
+        // keep the work space of the hipFFT path <= ~6 GiB
+        const double per_walker = 2.0 * (c->S * 8.0 + c->F * 16.0);
+        int chunk = (int)(6.0 * 1073741824.0 / per_walker);
+        c->chunk = chunk < 1 ? 1 : chunk;
     }
-    CTX_TRY(alloc_work(c));
-    CTX_HIP(hipStreamSynchronize(c->stream));
+    if (c->chunk > max_walkers) c->chunk = max_walkers;
+
+    int rc = ctx_init(c, sci, obs_var, bad_px, psf_ny, psf_nx, psf, psf_var);
+    if (rc != PSFMC_OK) {
+        const std::string keep = g_err;
+        psfmc_ctx_destroy(c);
+        g_err = keep;
+        return rc;
+    }
     *out = c;
     return PSFMC_OK;
 }
@@ -228,8 +419,9 @@ extern "C" int psfmc_ctx_destroy(psfmc_ctx* c) {
         hipfftDestroy(kv.second.first);
         hipfftDestroy(kv.second.second);
     }
-    void* bufs[] = {c->d_sci,  c->d_var,  c->d_bad,  c->d_pspec,   c->d_vspec, c->d_rows,
-                    c->d_prep, c->d_like, c->d_skip, c->d_partial, c->d_real,  c->d_spec};
+    void* bufs[] = {c->d_sci,  c->d_var,  c->d_bad,     c->d_pspec, c->d_vspec, c->d_rows, c->d_prep,
+                    c->d_like, c->d_skip, c->d_partial, c->d_real,  c->d_spec,  c->d_T,    c->d_Kraw,
+                    c->d_Kt,   c->d_twx,  c->d_twy,     c->d_img0,  c->d_img1, c->d_rho};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -245,9 +437,17 @@ extern "C" int psfmc_set_option(psfmc_ctx* c, const char* key, double value) {
         int v = (int)value;
         if (v < 1 || v > c->max_walkers) return fail(PSFMC_EINVAL, "chunk_walkers out of range");
         HIP_TRY(hipSetDevice(c->device));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipDeviceSynchronize());
         c->chunk = v;
+        if (c->d_img0) { (void)hipFree(c->d_img0); c->d_img0 = nullptr; }
+        if (c->d_img1) { (void)hipFree(c->d_img1); c->d_img1 = nullptr; }
+        c->img_cap = 0;
         return alloc_work(c);
+    }
+    if (!strcmp(key, "cols_grid")) {
+        if (value < 1) return fail(PSFMC_EINVAL, "cols_grid must be >= 1");
+        c->cols_grid = (int)value;
+        return PSFMC_OK;
     }
     return fail(PSFMC_EINVAL, "unknown option '%s'", key);
 }
@@ -257,17 +457,17 @@ extern "C" double psfmc_get_option(const psfmc_ctx* c, const char* key) {
     if (!strcmp(key, "chunk_walkers")) return c->chunk;
     if (!strcmp(key, "backend")) return c->backend;
     if (!strcmp(key, "max_walkers")) return c->max_walkers;
+    if (!strcmp(key, "cols_grid")) return c->cols_grid;
     return NAN;
 }
 
 // ---------------------------------------------------------------------------
-// hipFFT path: one chunk of walkers [w0, w0+n)
+// hipFFT path: rasterise + convolve one chunk; results in d_real (conv, var)
 // ---------------------------------------------------------------------------
-static int convolve_chunk(psfmc_ctx* c, int n, const double* d_prep, const uint8_t* d_skip,
-                          hipStream_t st, int ps_only) {
+static int hipfft_convolve(psfmc_ctx* c, int n, const double* d_prep, const uint8_t* d_skip,
+                           hipStream_t st, int ps_only) {
     const size_t lds = (size_t)c->plen * sizeof(double);
-    int prc = use_plans(c, 2 * n);
-    if (prc != PSFMC_OK) return prc;
+    RC_TRY(use_plans(c, 2 * n));
     hipLaunchKernelGGL(k_raster, dim3((c->S + 1023) / 1024, n), dim3(256), lds, st, d_prep, d_skip,
                        c->d_real, c->n_ps, c->n_sersic, c->ny, c->nx, ps_only);
     FFT_TRY(hipfftSetStream(c->plan_fwd, st));
@@ -284,18 +484,23 @@ static int convolve_chunk(psfmc_ctx* c, int n, const double* d_prep, const uint8
 static int eval_device(psfmc_ctx* c, int W, const double* d_rows, const uint8_t* d_skip,
                        double* d_like, hipStream_t st) {
     hipLaunchKernelGGL(k_prep, dim3((W + 127) / 128), dim3(128), 0, st, d_rows, c->d_prep, W, c->n_ps,
-                       c->n_sersic, c->ny, c->nx);
+                       c->n_sersic, c->ny, c->nx, c->d_rho);
     for (int w0 = 0; w0 < W; w0 += c->chunk) {
         const int n = W - w0 < c->chunk ? W - w0 : c->chunk;
         const double* prep = c->d_prep + (size_t)w0 * c->plen;
         const uint8_t* skip = d_skip ? d_skip + w0 : nullptr;
-        int rc = convolve_chunk(c, n, prep, skip, st, 0);
-        if (rc != PSFMC_OK) return rc;
-        hipLaunchKernelGGL(k_chi2, dim3(c->chi2_blocks, n), dim3(256), 0, st, c->d_real, c->d_sci,
-                           c->d_var, c->d_bad, skip, c->d_partial + (size_t)w0 * c->chi2_blocks, c->S);
+        double* partial = c->d_partial + (size_t)w0 * c->nblk;
+        if (c->backend == PSFMC_BACKEND_FUSED) {
+            RC_TRY(fused_forward(c, n, prep, skip, 0, nullptr, st));
+            RC_TRY(fused_inverse(c, n, prep, skip, partial, nullptr, nullptr, st));
+        } else {
+            RC_TRY(hipfft_convolve(c, n, prep, skip, st, 0));
+            hipLaunchKernelGGL(k_chi2, dim3(c->nblk, n), dim3(256), 0, st, c->d_real, c->d_sci, c->d_var,
+                               c->d_bad, skip, partial, c->S);
+        }
     }
     hipLaunchKernelGGL(k_finish, dim3((W + 127) / 128), dim3(128), 0, st, c->d_partial, d_skip, d_like,
-                       W, c->chi2_blocks);
+                       W, c->nblk);
     HIP_TRY(hipGetLastError());
     return PSFMC_OK;
 }
@@ -331,46 +536,79 @@ extern "C" int psfmc_eval_batch(psfmc_ctx* c, int W, const double* rows, const u
     return PSFMC_OK;
 }
 
+// ---------------------------------------------------------------------------
+// images (models.py:222-226)
+// ---------------------------------------------------------------------------
+static int ensure_image_staging(psfmc_ctx* c) {
+    if (c->img_cap >= c->chunk) return PSFMC_OK;
+    if (c->d_img0) { (void)hipFree(c->d_img0); c->d_img0 = nullptr; }
+    if (c->d_img1) { (void)hipFree(c->d_img1); c->d_img1 = nullptr; }
+    c->img_cap = 0;
+    HIP_TRY(hipMalloc(&c->d_img0, (size_t)c->chunk * c->S * sizeof(double)));
+    HIP_TRY(hipMalloc(&c->d_img1, (size_t)c->chunk * c->S * sizeof(double)));
+    c->img_cap = c->chunk;
+    return PSFMC_OK;
+}
+
 extern "C" int psfmc_eval_images(psfmc_ctx* c, int W, const double* rows, double* raw, double* conv,
                                  double* resid, double* ivm, double* ps_sub) {
     int rc = check_call(c, W, rows, rows);
     if (rc != PSFMC_OK || W == 0) return rc;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->stream;
+    const bool fused = c->backend == PSFMC_BACKEND_FUSED;
     const size_t img = (size_t)c->S * sizeof(double);
     HIP_TRY(hipMemcpyAsync(c->d_rows, rows, (size_t)W * c->rlen * sizeof(double), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_prep, dim3((W + 127) / 128), dim3(128), 0, st, c->d_rows, c->d_prep, W, c->n_ps,
-                       c->n_sersic, c->ny, c->nx);
+                       c->n_sersic, c->ny, c->nx, c->d_rho);
+    RC_TRY(ensure_image_staging(c));
     double* d_out = nullptr;     // [chunk][S] staging for derived images
     HIP_TRY(hipMalloc(&d_out, (size_t)c->chunk * img));
+    // where the convolved model / model variance of walker w live after a pass
+    const double* conv_src = fused ? c->d_img0 : c->d_real;
+    const double* var_src = fused ? c->d_img1 : c->d_real;
+    const int stride = fused ? 1 : 2, var_c = fused ? 0 : 1;
     for (int w0 = 0; w0 < W && rc == PSFMC_OK; w0 += c->chunk) {
         const int n = W - w0 < c->chunk ? W - w0 : c->chunk;
         const double* prep = c->d_prep + (size_t)w0 * c->plen;
-        auto emit = [&](double* host, int comp, int op) -> int {
+        auto emit = [&](double* host, const double* src, int strd, int comp, int op) -> int {
             if (!host) return PSFMC_OK;
-            hipLaunchKernelGGL(k_image_out, dim3(64, n), dim3(256), 0, st, c->d_real, c->d_sci, c->d_var,
-                               d_out, c->S, comp, op);
+            hipLaunchKernelGGL(k_image_out, dim3(64, n), dim3(256), 0, st, src, c->d_sci, c->d_var, d_out,
+                               c->S, strd, comp, op);
             HIP_TRY(hipMemcpyAsync(host + (size_t)w0 * c->S, d_out, (size_t)n * img,
                                    hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             return PSFMC_OK;
         };
-        if (raw) {   // raw model before it is overwritten by the inverse transform
+        auto pass = [&](int ps_only, double* raw_dev) -> int {
+            if (fused) {
+                RC_TRY(fused_forward(c, n, prep, nullptr, ps_only, raw_dev, st));
+                return fused_inverse(c, n, prep, nullptr, c->d_partial, c->d_img0, c->d_img1, st);
+            }
+            return hipfft_convolve(c, n, prep, nullptr, st, ps_only);
+        };
+        auto fetch = [&](double* host, const double* dev) -> int {
+            HIP_TRY(hipMemcpyAsync(host + (size_t)w0 * c->S, dev, (size_t)n * img, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            return PSFMC_OK;
+        };
+        if (raw && !fused) {   // raw model before the inverse transform overwrites it
             hipLaunchKernelGGL(k_raster, dim3((c->S + 1023) / 1024, n), dim3(256),
                                (size_t)c->plen * sizeof(double), st, prep, (const uint8_t*)nullptr,
                                c->d_real, c->n_ps, c->n_sersic, c->ny, c->nx, 0);
-            rc = emit(raw, 0, IMG_COPY);
+            rc = emit(raw, c->d_real, 2, 0, IMG_COPY);
             if (rc != PSFMC_OK) break;
         }
-        if (conv || resid || ivm) {
-            rc = convolve_chunk(c, n, prep, nullptr, st, 0);
-            if (rc == PSFMC_OK) rc = emit(conv, 0, IMG_COPY);
-            if (rc == PSFMC_OK) rc = emit(resid, 0, IMG_RESID);
-            if (rc == PSFMC_OK) rc = emit(ivm, 1, IMG_IVM);
+        if (conv || resid || ivm || (raw && fused)) {
+            rc = pass(0, (raw && fused) ? d_out : nullptr);
+            if (rc == PSFMC_OK && raw && fused) rc = fetch(raw, d_out);
+            if (rc == PSFMC_OK) rc = emit(conv, conv_src, stride, 0, IMG_COPY);
+            if (rc == PSFMC_OK) rc = emit(resid, conv_src, stride, 0, IMG_RESID);
+            if (rc == PSFMC_OK) rc = emit(ivm, var_src, stride, var_c, IMG_IVM);
         }
         if (rc == PSFMC_OK && ps_sub) {
-            rc = convolve_chunk(c, n, prep, nullptr, st, 1);
-            if (rc == PSFMC_OK) rc = emit(ps_sub, 0, IMG_RESID);
+            rc = pass(1, nullptr);
+            if (rc == PSFMC_OK) rc = emit(ps_sub, conv_src, stride, 0, IMG_RESID);
         }
     }
     (void)hipStreamSynchronize(st);
@@ -383,7 +621,21 @@ extern "C" int psfmc_get_spectra(psfmc_ctx* c, double* psf_spec, double* var_spe
     if (!c || !psf_spec || !var_spec) return fail(PSFMC_EINVAL, "NULL argument");
     HIP_TRY(hipSetDevice(c->device));
     const size_t bytes = (size_t)c->n_psf * c->F * sizeof(double2);
-    HIP_TRY(hipMemcpy(psf_spec, c->d_pspec, bytes, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(var_spec, c->d_vspec, bytes, hipMemcpyDeviceToHost));
-    return PSFMC_OK;
+    if (c->backend == PSFMC_BACKEND_HIPFFT) {
+        HIP_TRY(hipMemcpy(psf_spec, c->d_pspec, bytes, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(var_spec, c->d_vspec, bytes, hipMemcpyDeviceToHost));
+        return PSFMC_OK;
+    }
+    cd* tmp = nullptr;
+    HIP_TRY(hipMalloc(&tmp, bytes));
+    int rc = PSFMC_OK;
+    for (int comp = 0; comp < 2 && rc == PSFMC_OK; ++comp) {
+        hipLaunchKernelGGL(k_untranspose_spectrum, dim3(256), dim3(256), 0, c->stream, c->d_Kraw, tmp,
+                           c->n_psf, comp, c->ny, c->nxh, c->d_rho);
+        if (hipStreamSynchronize(c->stream) != hipSuccess ||
+            hipMemcpy(comp ? var_spec : psf_spec, tmp, bytes, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(PSFMC_EHIP, "spectrum copy failed");
+    }
+    (void)hipFree(tmp);
+    return rc;
 }

@@ -10,11 +10,11 @@ namespace psfmc {
 
 // rows [W][row_len] -> prep [W][prep_len]
 __global__ void k_prep(const double* __restrict__ rows, double* __restrict__ prep, int W,
-                       int n_ps, int n_sersic, int ny, int nx) {
+                       int n_ps, int n_sersic, int ny, int nx, const double* __restrict__ rho) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= W) return;
     build_prep(rows + (size_t)w * row_len(n_ps, n_sersic),
-               prep + (size_t)w * prep_len(n_ps, n_sersic), n_ps, n_sersic, ny, nx);
+               prep + (size_t)w * prep_len(n_ps, n_sersic), n_ps, n_sersic, ny, nx, rho);
 }
 
 // raw model and its square: real[(2w)][S] = raw, real[(2w+1)][S] = raw^2
@@ -54,7 +54,7 @@ k_spec_mul(double2* __restrict__ spec, const double2* __restrict__ pspec,
     const int w = blockIdx.y;
     if (skip && skip[w]) return;
     const int F = ny * nxh;
-    const int psf = (int)prep[(size_t)w * plen + plen - 1];
+    const int psf = (int)prep[(size_t)w * plen + kPrepPsfIdx];
     const double2* kp = pspec + (size_t)psf * F;
     const double2* kv = vspec + (size_t)psf * F;
     double2* a = spec + (size_t)(2 * w) * F;
@@ -112,9 +112,9 @@ __global__ void k_pad(const double* __restrict__ src, double* __restrict__ dst, 
 enum ImgOp { IMG_COPY = 0, IMG_RESID = 1, IMG_IVM = 2 };
 __global__ void k_image_out(const double* __restrict__ real, const double* __restrict__ sci,
                             const double* __restrict__ obs_var, double* __restrict__ out,
-                            int S, int c, int op) {
+                            int S, int stride, int c, int op) {
     const int w = blockIdx.y;
-    const double* src = real + (size_t)(2 * w + c) * S;
+    const double* src = real + (size_t)(stride * w + c) * S;
     double* dst = out + (size_t)w * S;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < S; i += gridDim.x * blockDim.x) {
         const double v = src[i];

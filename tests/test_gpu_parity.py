@@ -17,7 +17,7 @@ import psfmc_oracle as orc
 pytestmark = pytest.mark.gpu
 
 CASES = ['example', 'synth256', 'synth128x2', 'edge']
-BACKENDS = ['hipfft']
+BACKENDS = ['hipfft', 'fused']
 REF_TOL = 1e-6
 ORACLE_TOL = 1e-9
 
