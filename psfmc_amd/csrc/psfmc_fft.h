@@ -8,7 +8,8 @@
 // Decimation in frequency, two stages with ONE exchange through LDS:
 //   stage 1  radix-P DFT over a in registers, then the twiddle W_N^(t*c)
 //   exchange y[t][c] -> LDS rows of P+1 complex (the +1 keeps ds_write_b128 of
-//            the T lanes on distinct banks; reads are contiguous across lanes)
+//            the T lanes on distinct banks; reads are contiguous across lanes);
+//            wave-local, so there is no workgroup barrier anywhere in a transform
 //   stage 2  P/T radix-T DFTs over the T lanes' values, in registers
 //   X[c + P*d] = sum_b W_N^(b c) W_T^(b d) sum_a x[T a + b] W_P^(a c)
 // The in-register DFTs are fully unrolled radix-2 recursions with compile-time
@@ -32,7 +33,6 @@ __device__ __forceinline__ cd cmul(cd a, cd b) {
 __device__ __forceinline__ cd cconj(cd a) { return cd{a.x, -a.y}; }
 
 template <int N> struct FftShape;
-template <> struct FftShape<32>   { static constexpr int P = 8,  T = 4;  };
 template <> struct FftShape<64>   { static constexpr int P = 8,  T = 8;  };
 template <> struct FftShape<128>  { static constexpr int P = 16, T = 8;  };
 template <> struct FftShape<256>  { static constexpr int P = 16, T = 16; };
@@ -132,11 +132,21 @@ __device__ __forceinline__ void load_twiddles(cd (&w)[fft_tw_regs<N>()], const c
     }
 }
 
+// LDS hand-off between lanes of ONE wave.  A wave's DS instructions execute in
+// program order, so a ds_read issued after a ds_write of the same wave observes
+// it; all that is needed is that the compiler keeps that order (the fences) and
+// that the wave is converged here.  No s_barrier: waves never wait for each other.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // The cooperative transform.  `xbuf` = this transform's private LDS region of
-// fft_lds_elems<N>() complex; every thread of the block must call (it contains
-// two block barriers), `t` in [0,T).  `w` from load_twiddles (forward table).
+// fft_lds_elems<N>() complex; the T lanes of a transform sit in one wave (T <= 32),
+// `t` in [0,T).  `w` from load_twiddles (forward table).  Converged call only.
 template <int N, int SIGN>
-__device__ __forceinline__ void fft_coop(cd (&v)[FftShape<N>::P], const cd (&w)[fft_tw_regs<N>()],
+__device__ __forceinline__ void fft_wave(cd (&v)[FftShape<N>::P], const cd (&w)[fft_tw_regs<N>()],
                                          const cd* __restrict__ table, int t, cd* __restrict__ xbuf) {
     constexpr int P = FftShape<N>::P, T = FftShape<N>::T;
     Dft<P, SIGN>::run(v);
@@ -148,7 +158,7 @@ __device__ __forceinline__ void fft_coop(cd (&v)[FftShape<N>::P], const cd (&w)[
         if constexpr (fft_tw_in_regs<N>()) wc = w[c]; else wc = table[t * c];
         row[c] = cmul(v[c], SIGN < 0 ? wc : cconj(wc));
     }
-    __syncthreads();
+    wave_lds_sync();
 #pragma unroll
     for (int h = 0; h < P / T; ++h) {
         cd z[T];
@@ -158,7 +168,7 @@ __device__ __forceinline__ void fft_coop(cd (&v)[FftShape<N>::P], const cd (&w)[
 #pragma unroll
         for (int d = 0; d < T; ++d) v[h + (P / T) * d] = z[d];
     }
-    __syncthreads();
+    wave_lds_sync();
 }
 
 }  // namespace psfmc

@@ -1,21 +1,28 @@
 // psfmc_fused_path.h -- the PSFMC_BACKEND_FUSED kernels: three launches per
-// batch of walkers, no stand-alone FFT passes.
+// batch of walkers, no stand-alone FFT passes, no workgroup barriers.
 //
-//   rows_fwd   rasterise a tile of image rows straight into registers as
-//              z = raw + i raw^2 (two real images in one complex signal), FFT
-//              along x, untangle the two Hermitian spectra and store them
-//              transposed:   T[w][c][kx][y]   c = 0 (raw), 1 (raw^2), kx <= nx/2
-//   cols       per (w, c, kx) column, contiguous in y: FFT along y, multiply by
-//              the pre-scaled, pre-shifted kernel spectrum Kt[psf][c][kx][ky],
-//              inverse FFT along y, store in place
-//   rows_inv   reload a tile of rows (all kx), rebuild the full complex spectrum
-//              Y = G + i H (G, H Hermitian in kx), inverse FFT along x: real part
-//              = PSF-convolved model, imaginary part = model variance; fused
-//              chi^2 + log term + masked reduction -> one partial per tile.
+//   rows_fwd   each WAVE rasterises its group of RG image rows straight into
+//              registers as z = raw + i mu raw^2 (two real images in one complex
+//              signal), transforms along x, untangles the two Hermitian spectra
+//              and stores the kx <= nx/2 half
+//   cols       per (walker, kx): the two columns (c = 0 model, c = 1 variance),
+//              transform along y, multiply by the pre-scaled, pre-shifted kernel
+//              spectrum Kt[psf][kx][c][ky], inverse transform along y, in place
+//   rows_inv   each wave reloads its RG rows (all kx), rebuilds the full complex
+//              spectrum Y = G + i H (G, H Hermitian in kx), inverse transform
+//              along x: real part = PSF-convolved model, imaginary part =
+//              lambda * model variance; fused chi^2 + log term + masked reduction
+//              -> one partial sum per wave.
+//
+// Intermediate layout ("T"): [walker][kx][yg][c][r], y = yg*RG + r, RG = 64/T(nx)
+// rows per wave.  The RG rows x {model, variance} of one kx are contiguous
+// (128 B at nx = 256), so a row wave touches whole 64-B halves of cache lines
+// with the lanes already in transform order (no LDS transposition), and a column
+// pair (kx) is one contiguous run of 2*ny complex for the column kernel.
 //
 // HBM traffic per walker: one write + one read/write + one read of T
-// (2*(nx/2+1)*ny complex128), i.e. 4 x 1.03 MB at 256^2, against 6.3 MB of
-// "algorithmic" bytes for the unfused arrangement.
+// (2*(nx/2+1)*ny complex128 = 1.03 MB at 256^2) against 6.3 MB of "algorithmic"
+// bytes for the unfused arrangement.
 //
 // Reference: psfMC/models.py:213-216, 233-236; utils.py:25-32 (convolve: the
 // ifftshift is the (-1)^(kx+ky) sign folded into Kt, as is 1/(nx*ny)).
@@ -25,40 +32,60 @@
 
 namespace psfmc {
 
-constexpr int kFusedThreads = 256;
+constexpr int kRowThreads = 64;      // row kernels: one autonomous wave per workgroup
+constexpr int kColThreads = 256;     // column kernel: 4 waves, persistent
 
-template <int N> constexpr int fused_ffts_per_block() { return kFusedThreads / FftShape<N>::T; }
-// waves per SIMD the register allocator must leave room for: 32-point lanes
-// (N >= 512) need the whole register file
+template <int NX> constexpr int row_group() { return 64 / FftShape<NX>::T; }      // rows per wave
+template <int NX> constexpr size_t fused_row_lds_bytes() {
+    return (size_t)row_group<NX>() * fft_lds_elems<NX>() * sizeof(cd);
+}
+template <int NY> constexpr int col_ffts_per_block() { return kColThreads / FftShape<NY>::T; }
+template <int NY> constexpr size_t fused_col_lds_bytes() {
+    return (size_t)col_ffts_per_block<NY>() * fft_lds_elems<NY>() * sizeof(cd);
+}
+// waves per SIMD the register allocator must leave room for
 template <int N> constexpr int fused_min_waves() { return FftShape<N>::P > 16 ? 1 : 2; }
 
-// LDS bytes of a row kernel working on transforms of length NX
-template <int NX> constexpr size_t fused_row_lds_bytes() {
-    constexpr size_t fpb = fused_ffts_per_block<NX>();
-    constexpr size_t xch = fpb * fft_lds_elems<NX>();
-    constexpr size_t tile = fpb * (NX + 1);                 // Z tile (rows_fwd)
-    constexpr size_t gh = 2 * fpb * (NX / 2 + 1);            // G,H tile (rows_inv)
-    constexpr size_t m = xch > tile ? (xch > gh ? xch : gh) : (tile > gh ? tile : gh);
-    return m * sizeof(cd);
+// element offset of (y, c) inside one (walker, kx) run of 2*ny complex.
+// Sides are >= 64, so RG <= 8 <= T(ny): for y = T a + t the offset is affine in a,
+// t_elem(T a + t) = t_elem(t) + 2 T a  (used by the column kernel).
+__device__ __forceinline__ int t_elem(int y, int c, int rg_log2) {
+    const int rg = 1 << rg_log2;
+    return (((y >> rg_log2) * 2 + c) << rg_log2) + (y & (rg - 1));
 }
-template <int NY> constexpr size_t fused_col_lds_bytes() {
-    return (size_t)fused_ffts_per_block<NY>() * fft_lds_elems<NY>() * sizeof(cd);
+
+// packed, pre-permuted field arrays for rows_inv: pix[(yg*P + e)*64 + lane] =
+// {sci or NaN at excluded pixels, obs_var} of pixel (y = yg*RG + lane/T, x = lane%T + T*e)
+struct FieldPx {
+    double sci, var;
+};
+
+template <int NX>
+__global__ void k_pack_field(const double* __restrict__ sci, const double* __restrict__ obs_var,
+                             const uint8_t* __restrict__ bad, FieldPx* __restrict__ out, int ny) {
+    constexpr int P = FftShape<NX>::P, T = FftShape<NX>::T, RG = row_group<NX>();
+    const int n = ny * NX;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int lane = i & 63, e = (i >> 6) % P, yg = i / (64 * P);
+        const int y = yg * RG + lane / T, x = lane % T + T * e;
+        const size_t src = (size_t)y * NX + x;
+        out[i] = FieldPx{bad[src] ? __builtin_nan("") : sci[src], obs_var[src]};
+    }
 }
 
 // ---------------------------------------------------------------------------
-// rows_fwd.  grid (ny / FPB, n_walkers); block 256.
+// rows_fwd.  grid (ny / RG, n_walkers); one wave per workgroup.
 //   FROM_IMAGE = false: rasterise from prep (the hot path)
-//   FROM_IMAGE = true : z = img0 + i img_scale[w] img1 read from memory (PSF spectra at setup)
+//   FROM_IMAGE = true : z = img0 + i img_scale[w] img1 from memory (PSF spectra at setup)
 // raw_out (optional): [n][ny][nx] copy of the raw model (psfmc_eval_images)
 // ---------------------------------------------------------------------------
 template <int NX, bool FROM_IMAGE>
-__global__ void __launch_bounds__(kFusedThreads, fused_min_waves<NX>())
+__global__ void __launch_bounds__(kRowThreads, fused_min_waves<NX>())
 k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
            const cd* __restrict__ twx, cd* __restrict__ Tbuf, int n_ps, int n_sersic, int ny,
            int ps_only, const double* __restrict__ img, const double* __restrict__ img_scale,
            double* __restrict__ raw_out) {
-    constexpr int P = FftShape<NX>::P, T = FftShape<NX>::T;
-    constexpr int FPB = fused_ffts_per_block<NX>();
+    constexpr int P = FftShape<NX>::P, T = FftShape<NX>::T, RG = row_group<NX>();
     constexpr int NXH = NX / 2 + 1;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     cd* smem = reinterpret_cast<cd*>(smem_raw);
@@ -67,24 +94,26 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
     const int w = blockIdx.y;
     if (skip && skip[w]) return;
     const int f = threadIdx.x / T, t = threadIdx.x % T;
-    const int y0 = blockIdx.x * FPB;
-    const int iy = y0 + f;
+    const int yg = blockIdx.x;
+    const int iy = yg * RG + f;
     const size_t S = (size_t)ny * NX;
 
     cd v[P];
     if constexpr (FROM_IMAGE) {
         const double* a = img + (size_t)(2 * w) * S + (size_t)iy * NX;
         const double* b = a + S;
+        const double sc = img_scale[w];
 #pragma unroll
-        for (int k = 0; k < P; ++k) v[k] = cd{a[T * k + t], b[T * k + t] * img_scale[w]};
+        for (int k = 0; k < P; ++k) v[k] = cd{a[T * k + t], b[T * k + t] * sc};
     } else {
         const int plen = prep_len(n_ps, n_sersic);
-        for (int i = threadIdx.x; i < plen; i += kFusedThreads) s_prep[i] = prep[(size_t)w * plen + i];
-        __syncthreads();
+        for (int i = threadIdx.x; i < plen; i += kRowThreads) s_prep[i] = prep[(size_t)w * plen + i];
+        wave_lds_sync();
+        const double mu = s_prep[kPrepMu];
 #pragma unroll
         for (int k = 0; k < P; ++k) {
             const double r = raster_pixel(s_prep, n_ps, n_sersic, T * k + t, iy, ps_only != 0);
-            v[k] = cd{r, s_prep[kPrepMu] * r * r};
+            v[k] = cd{r, mu * r * r};
         }
         if (raw_out) {
             double* o = raw_out + (size_t)w * S + (size_t)iy * NX;
@@ -94,36 +123,49 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
     }
     cd tw[fft_tw_regs<NX>()];
     load_twiddles<NX>(tw, twx, t);
-    fft_coop<NX, -1>(v, tw, twx, t, smem + (size_t)f * fft_lds_elems<NX>());
+    cd* xbuf = smem + (size_t)f * fft_lds_elems<NX>();
+    fft_wave<NX, -1>(v, tw, twx, t, xbuf);
 
-    // Z tile in LDS: Zl[f][k], row stride NX+1 (conflict-free column reads)
-    cd* Zl = smem;
+    // Untangle.  Lane t holds Z[k], k = t + T e.  Z[NX - k] is held by lane
+    // (T - t) % T at e' = P-1-e (t != 0) or P-e (t == 0), i.e. in the upper half of
+    // its registers: pass the upper halves through LDS (wave-local).
 #pragma unroll
-    for (int e = 0; e < P; ++e) Zl[f * (NX + 1) + t + T * e] = v[e];
-    __syncthreads();
-    // untangle + transposed store: lanes run over the tile's rows (contiguous y)
-    const int fr = threadIdx.x % FPB, g = threadIdx.x / FPB;
-    cd* T0 = Tbuf + (size_t)w * 2 * NXH * ny + y0 + fr;
-    cd* T1 = T0 + (size_t)NXH * ny;
-    for (int kx = g; kx < NXH; kx += kFusedThreads / FPB) {
-        const cd zk = Zl[fr * (NX + 1) + kx];
-        const cd zm = Zl[fr * (NX + 1) + ((NX - kx) & (NX - 1))];
-        T0[(size_t)kx * ny] = cd{0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y)};
-        T1[(size_t)kx * ny] = cd{0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x)};
+    for (int e = P / 2; e < P; ++e) xbuf[(e - P / 2) * T + t] = v[e];
+    wave_lds_sync();
+    const int tm = (T - t) % T;
+    const int shift = t ? P - 1 : P;
+    cd* dst = Tbuf + (size_t)w * 2 * NXH * ny + t_elem(iy, 0, __builtin_ctz(RG));
+    const size_t kstride = (size_t)2 * ny;
+#pragma unroll
+    for (int e = 0; e < P / 2; ++e) {
+        const cd zk = v[e];
+        cd zm = (e == 0 && t == 0) ? zk                       // k = 0 is its own mirror
+                                   : xbuf[(shift - e - P / 2) * T + tm];
+        cd* o = dst + (size_t)(t + T * e) * kstride;
+        o[0] = cd{0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y)};        // spectrum of raw
+        o[RG] = cd{0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x)};      // spectrum of mu raw^2
+    }
+    if (t == 0) {                                           // Nyquist column, its own mirror
+        const cd z = v[P / 2];
+        cd* o = dst + (size_t)(NX / 2) * kstride;
+        o[0] = cd{z.x, 0.0};
+        o[RG] = cd{z.y, 0.0};
     }
 }
 
 // ---------------------------------------------------------------------------
-// cols.  persistent grid; one column = ny contiguous complex.
-//   CONVOLVE = true : FFT_y, * Kt[psf][c][kx][.], IFFT_y (the hot path)
+// cols.  persistent grid of 256-thread workgroups; slot s of a workgroup works
+// on column col = (walker*nxh + kx)*2 + c.
+//   CONVOLVE = true : FFT_y, * Kt[psf][kx][c][.], IFFT_y (the hot path)
 //   CONVOLVE = false: FFT_y only (PSF spectra at setup)
 // ---------------------------------------------------------------------------
 template <int NY, bool CONVOLVE>
-__global__ void __launch_bounds__(kFusedThreads, fused_min_waves<NY>())
+__global__ void __launch_bounds__(kColThreads, fused_min_waves<NY>())
 k_cols(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restrict__ prep,
-       const uint8_t* __restrict__ skip, const cd* __restrict__ twy, int plen, int nxh, int n_cols) {
+       const uint8_t* __restrict__ skip, const cd* __restrict__ twy, int plen, int nxh, int n_cols,
+       int rg_log2) {
     constexpr int P = FftShape<NY>::P, T = FftShape<NY>::T;
-    constexpr int FPB = fused_ffts_per_block<NY>();
+    constexpr int FPB = col_ffts_per_block<NY>();
     extern __shared__ __align__(16) unsigned char smem_raw[];
     cd* smem = reinterpret_cast<cd*>(smem_raw);
     const int s = threadIdx.x / T, t = threadIdx.x % T;
@@ -134,134 +176,122 @@ k_cols(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restric
     for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const int col = grp * FPB + s;
         bool active = col < n_cols;
-        int w = 0, q = 0;
+        const int pr = col >> 1, c = col & 1;     // (walker, kx) pair, component
+        int w = 0, kx = 0;
         if (active) {
-            w = col / (2 * nxh);
-            q = col - w * 2 * nxh;
+            w = pr / nxh;
+            kx = pr - w * nxh;
             if (skip && skip[w]) active = false;
         }
-        cd* base = Tbuf + (size_t)col * NY;
+        cd* base = Tbuf + (size_t)pr * 2 * NY + (c << rg_log2) + t_elem(t, 0, rg_log2);
         cd v[P];
 #pragma unroll
-        for (int a = 0; a < P; ++a) v[a] = active ? base[T * a + t] : cd{0.0, 0.0};
-        fft_coop<NY, -1>(v, tw, twy, t, xbuf);
+        for (int a = 0; a < P; ++a) v[a] = active ? base[2 * T * a] : cd{0.0, 0.0};
+        fft_wave<NY, -1>(v, tw, twy, t, xbuf);
         if constexpr (CONVOLVE) {
             const int psf = active ? (int)prep[(size_t)w * plen + kPrepPsfIdx] : 0;
-            const cd* k = Kt + ((size_t)psf * 2 * nxh + q) * NY;
+            const cd* k = Kt + (((size_t)psf * nxh + kx) * 2 + c) * NY;
 #pragma unroll
             for (int e = 0; e < P; ++e) v[e] = cmul(v[e], k[t + T * e]);
-            fft_coop<NY, +1>(v, tw, twy, t, xbuf);
+            fft_wave<NY, +1>(v, tw, twy, t, xbuf);
         }
         if (active) {
 #pragma unroll
-            for (int e = 0; e < P; ++e) base[T * e + t] = v[e];
+            for (int e = 0; e < P; ++e) base[2 * T * e] = v[e];
         }
     }
 }
 
 // ---------------------------------------------------------------------------
-// rows_inv.  grid (ny / FPB, n_walkers); block 256.
-// partial[w][blockIdx.x] = sum over the tile's good pixels of the chi^2 term.
+// rows_inv.  grid (ny / RG, n_walkers); one wave per workgroup.
+// partial[w][yg] = sum over the wave's good pixels of the chi^2 term.
 // conv_out / var_out (optional): [n][ny][nx] images (psfmc_eval_images)
 // ---------------------------------------------------------------------------
 template <int NX>
-__global__ void __launch_bounds__(kFusedThreads, fused_min_waves<NX>())
+__global__ void __launch_bounds__(kRowThreads, fused_min_waves<NX>())
 k_rows_inv(const cd* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const cd* __restrict__ twx,
-           const double* __restrict__ sci, const double* __restrict__ obs_var,
-           const uint8_t* __restrict__ bad, double* __restrict__ partial, int ny,
+           const FieldPx* __restrict__ field, double* __restrict__ partial, int ny,
            const double* __restrict__ prep, int plen,
            double* __restrict__ conv_out, double* __restrict__ var_out) {
-    constexpr int P = FftShape<NX>::P, T = FftShape<NX>::T;
-    constexpr int FPB = fused_ffts_per_block<NX>();
+    constexpr int P = FftShape<NX>::P, T = FftShape<NX>::T, RG = row_group<NX>();
     constexpr int NXH = NX / 2 + 1;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     cd* smem = reinterpret_cast<cd*>(smem_raw);
-    __shared__ double s_red[kFusedThreads / 64];
 
     const int w = blockIdx.y;
     if (skip && skip[w]) return;
-    const int y0 = blockIdx.x * FPB;
-    // transposed load: lanes run over the tile's rows
-    {
-        const int fr = threadIdx.x % FPB, g = threadIdx.x / FPB;
-        const cd* src = Tbuf + (size_t)w * 2 * NXH * ny + y0 + fr;
-        for (int q = g; q < 2 * NXH; q += kFusedThreads / FPB) {
-            const int c = q >= NXH ? 1 : 0;
-            const int kx = q - c * NXH;
-            smem[((size_t)c * FPB + fr) * NXH + kx] = src[(size_t)q * ny];
-        }
-    }
-    __syncthreads();
     const int f = threadIdx.x / T, t = threadIdx.x % T;
+    const int yg = blockIdx.x;
+    const int iy = yg * RG + f;
+    const cd* src = Tbuf + (size_t)w * 2 * NXH * ny + t_elem(iy, 0, __builtin_ctz(RG));
+    const size_t kstride = (size_t)2 * ny;
+
+    // Y[k], k = T a + t:  k <= NX/2: G[k] + i H[k];  else conj(G[NX-k]) + i conj(H[NX-k])
     cd v[P];
-    {
-        const cd* G = smem + (size_t)f * NXH;
-        const cd* H = smem + ((size_t)FPB + f) * NXH;
 #pragma unroll
-        for (int a = 0; a < P; ++a) {
-            const int k = T * a + t;
-            if (k <= NX / 2) {
-                const cd gk = G[k], hk = H[k];
-                v[a] = cd{gk.x - hk.y, gk.y + hk.x};
-            } else {
-                const cd gk = G[NX - k], hk = H[NX - k];
-                v[a] = cd{gk.x + hk.y, hk.x - gk.y};
-            }
-        }
+    for (int a = 0; a < P; ++a) {
+        const int k = T * a + t;
+        const bool direct = a < P / 2 || (a == P / 2 && t == 0);
+        const cd* p = src + (size_t)(direct ? k : NX - k) * kstride;
+        const cd g = p[0], h = p[RG];
+        v[a] = direct ? cd{g.x - h.y, g.y + h.x} : cd{g.x + h.y, h.x - g.y};
     }
     cd tw[fft_tw_regs<NX>()];
     load_twiddles<NX>(tw, twx, t);
-    __syncthreads();                       // G/H tile is dead; its LDS becomes the exchange buffer
-    fft_coop<NX, +1>(v, tw, twx, t, smem + (size_t)f * fft_lds_elems<NX>());
+    fft_wave<NX, +1>(v, tw, twx, t, smem + (size_t)f * fft_lds_elems<NX>());
     // imaginary part is lambda * model variance (see build_prep)
     const double inv_lambda = prep[(size_t)w * plen + kPrepInvLambda];
 #pragma unroll
     for (int e = 0; e < P; ++e) v[e].y *= inv_lambda;
 
-    const int iy = y0 + f;
-    const size_t rowoff = (size_t)iy * NX;
     if (conv_out) {
-        double* oc = conv_out + (size_t)w * ny * NX + rowoff;
-        double* ov = var_out + (size_t)w * ny * NX + rowoff;
+        const size_t rowoff = (size_t)w * ny * NX + (size_t)iy * NX;
 #pragma unroll
         for (int e = 0; e < P; ++e) {
-            oc[T * e + t] = v[e].x;
-            ov[T * e + t] = v[e].y;
+            conv_out[rowoff + T * e + t] = v[e].x;
+            var_out[rowoff + T * e + t] = v[e].y;
         }
     }
+    const FieldPx* fp = field + (size_t)yg * P * 64 + threadIdx.x;
     double acc = 0.0;
 #pragma unroll
     for (int e = 0; e < P; ++e) {
-        const size_t i = rowoff + T * e + t;
-        if (!bad[i]) acc += chi2_term(sci[i], obs_var[i], v[e].x, v[e].y);
+        const FieldPx px = fp[e * 64];
+        const double term = chi2_term(px.sci, px.var, v[e].x, v[e].y);
+        acc += (px.sci == px.sci) ? term : 0.0;             // NaN sci marks an excluded pixel
     }
-    const double tot = block_sum(acc, s_red);
-    if (threadIdx.x == 0) partial[(size_t)w * gridDim.x + blockIdx.x] = tot;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if (threadIdx.x == 0) partial[(size_t)w * gridDim.x + yg] = acc;
 }
 
-// Kt[psf][c][kx][ky] = spec_c[psf][ky][kx] * (-1)^(kx+ky) / S, from the raw
-// column-transformed PSF buffer (same [c][kx][ky] layout; its c = 1 half already
-// carries the channel scale rho[psf], which stays in Kt)
+// Kt[psf][kx][c][ky] = spec_c[psf][ky][kx] * (-1)^(kx+ky) / S from the
+// column-transformed PSF buffer (T layout with ky in place of y; its c = 1 half
+// already carries the channel scale rho[psf], which stays in Kt)
 __global__ void k_scale_kernel_spectrum(const cd* __restrict__ raw, cd* __restrict__ Kt, int n_total,
-                                        int ny, int nxh, double inv_s) {
+                                        int ny, int nxh, int rg_log2, double inv_s) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_total; i += gridDim.x * blockDim.x) {
         const int ky = i % ny;
-        const int kx = (i / ny) % nxh;
+        const int c = (i / ny) & 1;
+        const int pk = i / (2 * ny);                    // psf*nxh + kx
+        const int kx = pk % nxh;
         const double sc = ((kx + ky) & 1) ? -inv_s : inv_s;
-        Kt[i] = cd{raw[i].x * sc, raw[i].y * sc};
+        const cd v = raw[(size_t)pk * 2 * ny + t_elem(ky, c, rg_log2)];
+        Kt[i] = cd{v.x * sc, v.y * sc};
     }
 }
 
 // natural-layout copy for psfmc_get_spectra: out[psf][ky][kx] of component c
 __global__ void k_untranspose_spectrum(const cd* __restrict__ raw, cd* __restrict__ out, int n_psf,
-                                       int c, int ny, int nxh, const double* __restrict__ rho) {
+                                       int c, int ny, int nxh, int rg_log2,
+                                       const double* __restrict__ rho) {
     const int n = n_psf * ny * nxh;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int kx = i % nxh;
         const int ky = (i / nxh) % ny;
         const int p = i / (nxh * ny);
         const double sc = c ? 1.0 / rho[p] : 1.0;
-        const cd v = raw[(((size_t)p * 2 + c) * nxh + kx) * ny + ky];
+        const cd v = raw[((size_t)p * nxh + kx) * 2 * ny + t_elem(ky, c, rg_log2)];
         out[i] = cd{v.x * sc, v.y * sc};
     }
 }

@@ -61,13 +61,12 @@ static int fail(int code, const char* fmt, ...) {
 // run BODY with `N_` a compile-time copy of the (power-of-two) length n
 #define DISPATCH_LEN(n, BODY)                                                                   \
     switch (n) {                                                                                \
-        case 32:   { constexpr int N_ = 32;   BODY; } break;                                    \
         case 64:   { constexpr int N_ = 64;   BODY; } break;                                    \
         case 128:  { constexpr int N_ = 128;  BODY; } break;                                    \
         case 256:  { constexpr int N_ = 256;  BODY; } break;                                    \
         case 512:  { constexpr int N_ = 512;  BODY; } break;                                    \
         case 1024: { constexpr int N_ = 1024; BODY; } break;                                    \
-        default: return fail(PSFMC_EINVAL, "fused backend supports sides 32..1024, got %d", n); \
+        default: return fail(PSFMC_EINVAL, "fused backend supports sides 64..1024, got %d", n); \
     }
 
 // ---------------------------------------------------------------------------
@@ -99,6 +98,8 @@ struct psfmc_ctx {
     cd* d_Kt = nullptr;       // same * (-1)^(kx+ky) / S
     cd *d_twx = nullptr, *d_twy = nullptr;            // exp(-2 pi i k/n) tables
     double* d_rho = nullptr;  // [n_psf] power-of-two scale of the variance channel
+    FieldPx* d_field = nullptr;   // [S] {sci|NaN, obs_var} in rows_inv lane order
+    int rg_log2 = 0;          // log2(rows per wave of the row kernels)
     double *d_img0 = nullptr, *d_img1 = nullptr;      // [chunk][S] staging for eval_images
     int img_cap = 0;
     int cols_grid = 0;
@@ -155,8 +156,8 @@ static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 // ---------------------------------------------------------------------------
 // fused path launchers
 // ---------------------------------------------------------------------------
-static int rows_per_block_for(int nx) {
-    DISPATCH_LEN(nx, return fused_ffts_per_block<N_>());
+static int row_group_for(int nx) {
+    DISPATCH_LEN(nx, return row_group<N_>());
     return 0;
 }
 
@@ -165,10 +166,8 @@ static int launch_rows_fwd(psfmc_ctx* c, int n, const double* prep, const uint8_
                            int ps_only, const double* img, const double* img_scale, double* raw_out,
                            hipStream_t st) {
     constexpr size_t lds = fused_row_lds_bytes<NX>();
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows_fwd<NX, FROM_IMAGE>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_rows_fwd<NX, FROM_IMAGE>), dim3(c->ny / fused_ffts_per_block<NX>(), n),
-                       dim3(kFusedThreads), lds, st, prep, skip, c->d_twx, Tbuf, c->n_ps, c->n_sersic,
+    hipLaunchKernelGGL((k_rows_fwd<NX, FROM_IMAGE>), dim3(c->ny / row_group<NX>(), n),
+                       dim3(kRowThreads), lds, st, prep, skip, c->d_twx, Tbuf, c->n_ps, c->n_sersic,
                        c->ny, ps_only, img, img_scale, raw_out);
     return PSFMC_OK;
 }
@@ -179,10 +178,10 @@ static int launch_cols(psfmc_ctx* c, cd* Tbuf, int n_cols, const double* prep, c
     constexpr size_t lds = fused_col_lds_bytes<NY>();
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cols<NY, CONVOLVE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int groups = (n_cols + fused_ffts_per_block<NY>() - 1) / fused_ffts_per_block<NY>();
+    const int groups = (n_cols + col_ffts_per_block<NY>() - 1) / col_ffts_per_block<NY>();
     const int grid = groups < c->cols_grid ? groups : c->cols_grid;
-    hipLaunchKernelGGL((k_cols<NY, CONVOLVE>), dim3(grid), dim3(kFusedThreads), lds, st, Tbuf, c->d_Kt,
-                       prep, skip, c->d_twy, c->plen, c->nxh, n_cols);
+    hipLaunchKernelGGL((k_cols<NY, CONVOLVE>), dim3(grid), dim3(kColThreads), lds, st, Tbuf, c->d_Kt,
+                       prep, skip, c->d_twy, c->plen, c->nxh, n_cols, c->rg_log2);
     return PSFMC_OK;
 }
 
@@ -190,11 +189,15 @@ template <int NX>
 static int launch_rows_inv(psfmc_ctx* c, int n, const double* prep, const uint8_t* skip, double* partial,
                            double* conv_out, double* var_out, hipStream_t st) {
     constexpr size_t lds = fused_row_lds_bytes<NX>();
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows_inv<NX>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_rows_inv<NX>), dim3(c->ny / fused_ffts_per_block<NX>(), n), dim3(kFusedThreads),
-                       lds, st, c->d_T, skip, c->d_twx, c->d_sci, c->d_var, c->d_bad, partial, c->ny,
-                       prep, c->plen, conv_out, var_out);
+    hipLaunchKernelGGL((k_rows_inv<NX>), dim3(c->ny / row_group<NX>(), n), dim3(kRowThreads), lds, st,
+                       c->d_T, skip, c->d_twx, c->d_field, partial, c->ny, prep, c->plen, conv_out,
+                       var_out);
+    return PSFMC_OK;
+}
+
+template <int NX> static int pack_field(psfmc_ctx* c) {
+    hipLaunchKernelGGL((k_pack_field<NX>), dim3(256), dim3(256), 0, c->stream, c->d_sci, c->d_var,
+                       c->d_bad, c->d_field, c->ny);
     return PSFMC_OK;
 }
 
@@ -257,7 +260,7 @@ static int spectra_fused(psfmc_ctx* c, const double* d_canvas) {
     DISPATCH_LEN(c->ny, RC_TRY((launch_cols<N_, false>(c, c->d_Kraw, c->n_psf * 2 * c->nxh, nullptr,
                                                        nullptr, c->stream))));
     hipLaunchKernelGGL(k_scale_kernel_spectrum, dim3(256), dim3(256), 0, c->stream, c->d_Kraw, c->d_Kt,
-                       (int)n_el, c->ny, c->nxh, 1.0 / (double)c->S);
+                       (int)n_el, c->ny, c->nxh, c->rg_log2, 1.0 / (double)c->S);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     return PSFMC_OK;
@@ -306,6 +309,8 @@ static int ctx_init(psfmc_ctx* c, const double* sci, const double* obs_var, cons
         }
         HIP_TRY(hipMalloc(&c->d_rho, c->n_psf * sizeof(double)));
         HIP_TRY(hipMemcpy(c->d_rho, rho.data(), c->n_psf * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(&c->d_field, (size_t)c->S * sizeof(FieldPx)));
+        DISPATCH_LEN(c->nx, RC_TRY(pack_field<N_>(c)));
     }
 
     // centre-padded canvases, interleaved (psf0, var0, psf1, var1, ...)
@@ -356,13 +361,13 @@ extern "C" int psfmc_ctx_create(psfmc_ctx** out, int device, int ny, int nx, con
         return fail(PSFMC_EINVAL, "unknown backend %d", backend);
     int row_tiles = 0;
     if (backend == PSFMC_BACKEND_FUSED) {
-        if (!(is_pow2(ny) && is_pow2(nx)) || nx < 32 || ny < 32 || nx > 1024 || ny > 1024)
-            return fail(PSFMC_EINVAL, "fused backend needs power-of-two sides in 32..1024 (got %d x %d)",
+        if (!(is_pow2(ny) && is_pow2(nx)) || nx < 64 || ny < 64 || nx > 1024 || ny > 1024)
+            return fail(PSFMC_EINVAL, "fused backend needs power-of-two sides in 64..1024 (got %d x %d)",
                         ny, nx);
-        const int rpb = rows_per_block_for(nx);
-        if (rpb <= 0 || ny % rpb)
-            return fail(PSFMC_EINVAL, "fused backend: ny=%d must be a multiple of %d for nx=%d", ny, rpb, nx);
-        row_tiles = ny / rpb;
+        const int rg = row_group_for(nx);
+        if (rg <= 0 || ny % rg)
+            return fail(PSFMC_EINVAL, "fused backend: ny=%d must be a multiple of %d for nx=%d", ny, rg, nx);
+        row_tiles = ny / rg;
     }
 
     int ndev = 0;
@@ -384,6 +389,7 @@ extern "C" int psfmc_ctx_create(psfmc_ctx** out, int device, int ny, int nx, con
     c->plen = prep_len(n_ps, n_sersic);
     if (backend == PSFMC_BACKEND_FUSED) {
         c->nblk = row_tiles;
+        c->rg_log2 = __builtin_ctz(ny / row_tiles);
         c->cols_grid = prop.multiProcessorCount * 2;
         // walkers per internal pass: the transposed half-spectra of one pass
         const double per_walker = 2.0 * c->nxh * c->ny * 16.0;
@@ -421,7 +427,7 @@ extern "C" int psfmc_ctx_destroy(psfmc_ctx* c) {
     }
     void* bufs[] = {c->d_sci,  c->d_var,  c->d_bad,     c->d_pspec, c->d_vspec, c->d_rows, c->d_prep,
                     c->d_like, c->d_skip, c->d_partial, c->d_real,  c->d_spec,  c->d_T,    c->d_Kraw,
-                    c->d_Kt,   c->d_twx,  c->d_twy,     c->d_img0,  c->d_img1, c->d_rho};
+                    c->d_Kt,   c->d_twx,  c->d_twy,     c->d_img0,  c->d_img1, c->d_rho,   c->d_field};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -631,7 +637,7 @@ extern "C" int psfmc_get_spectra(psfmc_ctx* c, double* psf_spec, double* var_spe
     int rc = PSFMC_OK;
     for (int comp = 0; comp < 2 && rc == PSFMC_OK; ++comp) {
         hipLaunchKernelGGL(k_untranspose_spectrum, dim3(256), dim3(256), 0, c->stream, c->d_Kraw, tmp,
-                           c->n_psf, comp, c->ny, c->nxh, c->d_rho);
+                           c->n_psf, comp, c->ny, c->nxh, c->rg_log2, c->d_rho);
         if (hipStreamSynchronize(c->stream) != hipSuccess ||
             hipMemcpy(comp ? var_spec : psf_spec, tmp, bytes, hipMemcpyDeviceToHost) != hipSuccess)
             rc = fail(PSFMC_EHIP, "spectrum copy failed");
