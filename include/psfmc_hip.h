@@ -128,6 +128,13 @@ int psfmc_get_spectra(psfmc_ctx* ctx, double* psf_spec, double* var_spec);
 int psfmc_set_option(psfmc_ctx* ctx, const char* key, double value);
 double psfmc_get_option(const psfmc_ctx* ctx, const char* key);
 
+/*
+ * Diagnostic hook: evaluate one of the library's fp64 device functions on n host
+ * values (op 0 log2, 1 exp2, 2 reciprocal, 3 reciprocal square root) so tests can
+ * check the hand-written elementary functions of the rasteriser against numpy.
+ */
+int psfmc_debug_math(int device, int op, int n, const double* in, double* out);
+
 /* message of the last failing call on this thread ("" if none) */
 const char* psfmc_last_error(void);
 

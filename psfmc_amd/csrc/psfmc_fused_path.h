@@ -89,8 +89,6 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
     constexpr int NXH = NX / 2 + 1;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     cd* smem = reinterpret_cast<cd*>(smem_raw);
-    __shared__ double s_prep[kPrepHead + kPrepPs * 16 + kPrepSersic * 16];
-
     const int w = blockIdx.y;
     if (skip && skip[w]) return;
     const int f = threadIdx.x / T, t = threadIdx.x % T;
@@ -106,15 +104,12 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
 #pragma unroll
         for (int k = 0; k < P; ++k) v[k] = cd{a[T * k + t], b[T * k + t] * sc};
     } else {
-        const int plen = prep_len(n_ps, n_sersic);
-        for (int i = threadIdx.x; i < plen; i += kRowThreads) s_prep[i] = prep[(size_t)w * plen + i];
-        wave_lds_sync();
-        const double mu = s_prep[kPrepMu];
+        const double* wprep = prep + (size_t)w * prep_len(n_ps, n_sersic);   // wave-uniform
+        const double mu = wprep[kPrepMu];
+        double r[P];
+        raster_row<P, T>(wprep, n_ps, n_sersic, t, iy, ps_only != 0, r);
 #pragma unroll
-        for (int k = 0; k < P; ++k) {
-            const double r = raster_pixel(s_prep, n_ps, n_sersic, T * k + t, iy, ps_only != 0);
-            v[k] = cd{r, mu * r * r};
-        }
+        for (int k = 0; k < P; ++k) v[k] = cd{r[k], mu * r[k] * r[k]};
         if (raw_out) {
             double* o = raw_out + (size_t)w * S + (size_t)iy * NX;
 #pragma unroll

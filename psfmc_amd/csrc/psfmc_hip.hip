@@ -645,3 +645,32 @@ extern "C" int psfmc_get_spectra(psfmc_ctx* c, double* psf_spec, double* var_spe
     (void)hipFree(tmp);
     return rc;
 }
+
+// ---------------------------------------------------------------------------
+// diagnostic: device elementary functions on host arrays
+// ---------------------------------------------------------------------------
+__global__ void k_debug_math(int op, int n, const double* __restrict__ in, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = in[i];
+    out[i] = op == 0 ? fast_log2(x) : op == 1 ? fast_exp2(x) : op == 2 ? fast_rcp(x) : fast_rsqrt(x);
+}
+
+extern "C" int psfmc_debug_math(int device, int op, int n, const double* in, double* out) {
+    if (n < 0 || op < 0 || op > 3 || (n > 0 && (!in || !out))) return fail(PSFMC_EINVAL, "bad argument");
+    if (n == 0) return PSFMC_OK;
+    HIP_TRY(hipSetDevice(device));
+    double *d_in = nullptr, *d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_in, (size_t)n * sizeof(double)));
+    int rc = PSFMC_OK;
+    if (hipMalloc(&d_out, (size_t)n * sizeof(double)) != hipSuccess) rc = fail(PSFMC_ENOMEM, "hipMalloc");
+    if (rc == PSFMC_OK) {
+        (void)hipMemcpy(d_in, in, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(k_debug_math, dim3((n + 255) / 256), dim3(256), 0, 0, op, n, d_in, d_out);
+        if (hipMemcpy(out, d_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(PSFMC_EHIP, "debug_math copy failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    return rc;
+}

@@ -77,6 +77,8 @@ def load_library():
     lib.psfmc_set_option.argtypes = [vp, ctypes.c_char_p, cd]
     lib.psfmc_get_option.restype = cd
     lib.psfmc_get_option.argtypes = [vp, ctypes.c_char_p]
+    lib.psfmc_debug_math.restype = ci
+    lib.psfmc_debug_math.argtypes = [ci, ci, ci, _c_double_p, _c_double_p]
     if lib.psfmc_abi_version() != 1:
         raise ImportError('libpsfmc_hip ABI version mismatch')
     _lib = lib
@@ -89,6 +91,19 @@ def _dp(arr):
 
 def _f64(arr):
     return np.ascontiguousarray(arr, dtype=np.float64)
+
+
+def debug_math(op, values, device=0):
+    """Evaluate a device elementary function ('log2', 'exp2', 'rcp', 'rsqrt') on
+    an array (test hook for the rasteriser's hand-written fp64 math)."""
+    lib = load_library()
+    code = {'log2': 0, 'exp2': 1, 'rcp': 2, 'rsqrt': 3}[op]
+    x = _f64(np.ravel(values))
+    out = np.empty_like(x)
+    rc = lib.psfmc_debug_math(int(device), code, x.size, _dp(x), _dp(out))
+    if rc != 0:
+        raise NativeError(rc, lib.psfmc_last_error().decode('utf-8', 'replace'))
+    return out.reshape(np.shape(values))
 
 
 class Context(object):

@@ -153,3 +153,33 @@ def test_native_errors_are_reported(models):
         model.engine.loglike(np.zeros((1000, model.engine.row_len)))
     with pytest.raises(engine.NativeError):
         model.engine.set_option('no_such_option', 1)
+
+
+def test_device_math():
+    """The rasteriser's hand-written fp64 log2 / exp2 / reciprocal / rsqrt vs numpy."""
+    from psfmc_amd import engine
+    rng = np.random.RandomState(4)
+    x = np.concatenate([10.0 ** rng.uniform(-12, 8, 20000), 1.0 + rng.normal(size=4000) * 1e-3,
+                        [1.0, 2.0, 0.5, 0.70710678118654746, 0.70710678118654757, 1e-300, 1e300]])
+    got = engine.debug_math('log2', x)
+    ref = np.log2(x)
+    assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)) <= 4e-16
+    close = np.abs(x - 1.0) < 0.2                 # relative accuracy near the zero of log
+    nz = close & (ref != 0)
+    assert np.max(np.abs(got[nz] - ref[nz]) / np.abs(ref[nz])) <= 1e-15
+    assert engine.debug_math('log2', np.array([1.0]))[0] == 0.0
+
+    y = np.concatenate([rng.uniform(-60, 60, 20000), rng.uniform(-1075, -1000, 200),
+                        [0.0, 1.0, -1.0, 0.5, -0.5, 1023.0, -1074.0, -1100.0, -5000.0, -np.inf]])
+    got = engine.debug_math('exp2', y)
+    ref = np.exp2(y)
+    normal = ref > 1e-300
+    assert np.max(np.abs(got[normal] - ref[normal]) / ref[normal]) <= 6e-16
+    assert np.all(np.abs(got[~normal] - ref[~normal]) <= 5e-324 + 1e-15 * ref[~normal])
+    assert np.isnan(engine.debug_math('exp2', np.array([np.nan]))[0])
+    assert engine.debug_math('exp2', np.array([2000.0, np.inf])).tolist() == [np.inf, np.inf]
+
+    z = 10.0 ** rng.uniform(-200, 200, 20000)
+    assert np.max(np.abs(engine.debug_math('rcp', z) * z - 1.0)) <= 4e-16
+    assert np.max(np.abs(engine.debug_math('rsqrt', z) * np.sqrt(z) - 1.0)) <= 6e-16
+    assert np.isnan(engine.debug_math('rcp', np.array([0.0]))[0] * 0.0)
