@@ -89,6 +89,8 @@ def main():
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--sersic', type=int, default=1)
     ap.add_argument('--backend', default=os.environ.get('PSFMC_BACKEND', 'fused'))
+    ap.add_argument('--chunk', type=int, default=0, help='walkers per internal pass (0 = library default)')
+    ap.add_argument('--opt', action='append', default=[], help='library option key=value (tuning)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-cpu', action='store_true')
     args = ap.parse_args()
@@ -109,6 +111,11 @@ def main():
 
     model, theta, fld = build_problem(args, local)
     eng = model.engine
+    if args.chunk:
+        eng.set_option('chunk_walkers', args.chunk)
+    for kv in args.opt:
+        key, val = kv.split('=')
+        eng.set_option(key, float(val))
     rows = torch.from_numpy(model.derived_rows(theta)).to(dev)
     out = torch.empty(args.walkers, dtype=torch.float64, device=dev)
     gathered = torch.empty(args.walkers * world, dtype=torch.float64, device=dev)

@@ -306,6 +306,17 @@ __device__ inline double chi2_term(double sci, double obs_var, double conv, doub
     return r * r * ivm - log(0.5 / M_PI * ivm);
 }
 
+// The same term with the rasteriser's elementary functions (fused path):
+//   r^2 / d + ln(2 pi d),  d = model_var + obs_var  (= r^2 ivm - ln(ivm / 2 pi)).
+// d <= 0 gives NaN like the reference's log of a negative weight.
+__device__ __forceinline__ double chi2_term_fast(double sci, double obs_var, double conv, double mvar) {
+    const double d = mvar + obs_var;
+    const double r = sci - conv;
+    const double lg = 0.69314718055994530942 * fast_log2(6.28318530717958647693 * d);
+    const double term = __builtin_fma(r * r, fast_rcp(d), lg);
+    return d > 0.0 ? term : __builtin_nan("");
+}
+
 // wave64 + LDS block sum; result valid in thread 0.  blockDim.x multiple of 64.
 __device__ inline double block_sum(double v, double* lds /* >= blockDim/64 doubles */) {
 #pragma unroll

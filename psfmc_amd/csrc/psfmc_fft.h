@@ -39,7 +39,7 @@ template <> struct FftShape<256>  { static constexpr int P = 16, T = 16; };
 template <> struct FftShape<512>  { static constexpr int P = 32, T = 16; };
 template <> struct FftShape<1024> { static constexpr int P = 32, T = 32; };
 
-// LDS complex elements one transform needs for its exchange
+// LDS doubles one transform needs for its exchange (one component at a time)
 template <int N> constexpr int fft_lds_elems() { return FftShape<N>::T * (FftShape<N>::P + 1); }
 
 // cos(2 pi k / 32), k = 0..8
@@ -143,32 +143,46 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 // The cooperative transform.  `xbuf` = this transform's private LDS region of
-// fft_lds_elems<N>() complex; the T lanes of a transform sit in one wave (T <= 32),
+// fft_lds_elems<N>() DOUBLES; the T lanes of a transform sit in one wave (T <= 32),
 // `t` in [0,T).  `w` from load_twiddles (forward table).  Converged call only.
+// The exchange goes through LDS one component at a time (real parts, then
+// imaginary parts): half the LDS footprint per wave, which is what bounds how many
+// waves a CU can hold, for the same number of LDS bytes moved.
 template <int N, int SIGN>
 __device__ __forceinline__ void fft_wave(cd (&v)[FftShape<N>::P], const cd (&w)[fft_tw_regs<N>()],
-                                         const cd* __restrict__ table, int t, cd* __restrict__ xbuf) {
+                                         const cd* __restrict__ table, int t, double* __restrict__ xbuf) {
     constexpr int P = FftShape<N>::P, T = FftShape<N>::T;
     Dft<P, SIGN>::run(v);
-    cd* row = xbuf + t * (P + 1);
-    row[0] = v[0];
 #pragma unroll
     for (int c = 1; c < P; ++c) {
         cd wc;
         if constexpr (fft_tw_in_regs<N>()) wc = w[c]; else wc = table[t * c];
-        row[c] = cmul(v[c], SIGN < 0 ? wc : cconj(wc));
+        v[c] = cmul(v[c], SIGN < 0 ? wc : cconj(wc));
     }
+    double* row = xbuf + t * (P + 1);
+    cd z[P / T][T];
+#pragma unroll
+    for (int c = 0; c < P; ++c) row[c] = v[c].x;
+    wave_lds_sync();
+#pragma unroll
+    for (int h = 0; h < P / T; ++h)
+#pragma unroll
+        for (int b = 0; b < T; ++b) z[h][b].x = xbuf[b * (P + 1) + t + T * h];
+    wave_lds_sync();
+#pragma unroll
+    for (int c = 0; c < P; ++c) row[c] = v[c].y;
+    wave_lds_sync();
+#pragma unroll
+    for (int h = 0; h < P / T; ++h)
+#pragma unroll
+        for (int b = 0; b < T; ++b) z[h][b].y = xbuf[b * (P + 1) + t + T * h];
     wave_lds_sync();
 #pragma unroll
     for (int h = 0; h < P / T; ++h) {
-        cd z[T];
+        Dft<T, SIGN>::run(z[h]);
 #pragma unroll
-        for (int b = 0; b < T; ++b) z[b] = xbuf[b * (P + 1) + t + T * h];
-        Dft<T, SIGN>::run(z);
-#pragma unroll
-        for (int d = 0; d < T; ++d) v[h + (P / T) * d] = z[d];
+        for (int d = 0; d < T; ++d) v[h + (P / T) * d] = z[h][d];
     }
-    wave_lds_sync();
 }
 
 }  // namespace psfmc

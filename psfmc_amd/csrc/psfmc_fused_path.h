@@ -37,11 +37,11 @@ constexpr int kColThreads = 256;     // column kernel: 4 waves, persistent
 
 template <int NX> constexpr int row_group() { return 64 / FftShape<NX>::T; }      // rows per wave
 template <int NX> constexpr size_t fused_row_lds_bytes() {
-    return (size_t)row_group<NX>() * fft_lds_elems<NX>() * sizeof(cd);
+    return (size_t)row_group<NX>() * fft_lds_elems<NX>() * sizeof(double);
 }
 template <int NY> constexpr int col_ffts_per_block() { return kColThreads / FftShape<NY>::T; }
 template <int NY> constexpr size_t fused_col_lds_bytes() {
-    return (size_t)col_ffts_per_block<NY>() * fft_lds_elems<NY>() * sizeof(cd);
+    return (size_t)col_ffts_per_block<NY>() * fft_lds_elems<NY>() * sizeof(double);
 }
 // waves per SIMD the register allocator must leave room for
 template <int N> constexpr int fused_min_waves() { return FftShape<N>::P > 16 ? 1 : 2; }
@@ -87,8 +87,7 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
            double* __restrict__ raw_out) {
     constexpr int P = FftShape<NX>::P, T = FftShape<NX>::T, RG = row_group<NX>();
     constexpr int NXH = NX / 2 + 1;
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    cd* smem = reinterpret_cast<cd*>(smem_raw);
+    extern __shared__ __align__(16) double smem[];
     const int w = blockIdx.y;
     if (skip && skip[w]) return;
     const int f = threadIdx.x / T, t = threadIdx.x % T;
@@ -118,14 +117,16 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
     }
     cd tw[fft_tw_regs<NX>()];
     load_twiddles<NX>(tw, twx, t);
-    cd* xbuf = smem + (size_t)f * fft_lds_elems<NX>();
+    double* xbuf = smem + (size_t)f * fft_lds_elems<NX>();
     fft_wave<NX, -1>(v, tw, twx, t, xbuf);
 
     // Untangle.  Lane t holds Z[k], k = t + T e.  Z[NX - k] is held by lane
     // (T - t) % T at e' = P-1-e (t != 0) or P-e (t == 0), i.e. in the upper half of
-    // its registers: pass the upper halves through LDS (wave-local).
+    // its registers: pass the upper halves through LDS (wave-local; the N/2 complex
+    // fit the transform's exchange region of T (P+1) doubles).
+    cd* ubuf = reinterpret_cast<cd*>(xbuf);
 #pragma unroll
-    for (int e = P / 2; e < P; ++e) xbuf[(e - P / 2) * T + t] = v[e];
+    for (int e = P / 2; e < P; ++e) ubuf[(e - P / 2) * T + t] = v[e];
     wave_lds_sync();
     const int tm = (T - t) % T;
     const int shift = t ? P - 1 : P;
@@ -135,7 +136,7 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
     for (int e = 0; e < P / 2; ++e) {
         const cd zk = v[e];
         cd zm = (e == 0 && t == 0) ? zk                       // k = 0 is its own mirror
-                                   : xbuf[(shift - e - P / 2) * T + tm];
+                                   : ubuf[(shift - e - P / 2) * T + tm];
         cd* o = dst + (size_t)(t + T * e) * kstride;
         o[0] = cd{0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y)};        // spectrum of raw
         o[RG] = cd{0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x)};      // spectrum of mu raw^2
@@ -161,10 +162,9 @@ k_cols(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restric
        int rg_log2) {
     constexpr int P = FftShape<NY>::P, T = FftShape<NY>::T;
     constexpr int FPB = col_ffts_per_block<NY>();
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    cd* smem = reinterpret_cast<cd*>(smem_raw);
+    extern __shared__ __align__(16) double smem[];
     const int s = threadIdx.x / T, t = threadIdx.x % T;
-    cd* xbuf = smem + (size_t)s * fft_lds_elems<NY>();
+    double* xbuf = smem + (size_t)s * fft_lds_elems<NY>();
     cd tw[fft_tw_regs<NY>()];
     load_twiddles<NY>(tw, twy, t);
     const int n_groups = (n_cols + FPB - 1) / FPB;
@@ -210,8 +210,7 @@ k_rows_inv(const cd* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
            double* __restrict__ conv_out, double* __restrict__ var_out) {
     constexpr int P = FftShape<NX>::P, T = FftShape<NX>::T, RG = row_group<NX>();
     constexpr int NXH = NX / 2 + 1;
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    cd* smem = reinterpret_cast<cd*>(smem_raw);
+    extern __shared__ __align__(16) double smem[];
 
     const int w = blockIdx.y;
     if (skip && skip[w]) return;
@@ -252,7 +251,7 @@ k_rows_inv(const cd* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
 #pragma unroll
     for (int e = 0; e < P; ++e) {
         const FieldPx px = fp[e * 64];
-        const double term = chi2_term(px.sci, px.var, v[e].x, v[e].y);
+        const double term = chi2_term_fast(px.sci, px.var, v[e].x, v[e].y);
         acc += (px.sci == px.sci) ? term : 0.0;             // NaN sci marks an excluded pixel
     }
 #pragma unroll
