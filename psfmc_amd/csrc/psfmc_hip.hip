@@ -93,7 +93,14 @@ struct psfmc_ctx {
     std::map<int, std::pair<hipfftHandle, hipfftHandle>> plans;   // batch -> (D2Z, Z2D)
     hipfftHandle plan_fwd = 0, plan_inv = 0;                      // the pair in use
     // fused path
-    cd* d_T = nullptr;        // [chunk][2][nxh][ny] transposed half-spectra
+    // [chunk][nxh][ny/RG][2][RG] half-spectra of one pass; pass i uses buffer and
+    // side stream i % n_streams so neighbouring passes overlap
+    static constexpr int kMaxStreams = 4;
+    cd* d_Ts[kMaxStreams] = {nullptr, nullptr, nullptr, nullptr};
+    cd* d_T = nullptr;        // = d_Ts[0]
+    hipStream_t side[kMaxStreams] = {nullptr, nullptr, nullptr, nullptr};   // side[0] unused
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxStreams] = {nullptr, nullptr, nullptr, nullptr};
+    int n_streams = 2;
     cd* d_Kraw = nullptr;     // [n_psf][2][nxh][ny] kernel spectra, unscaled
     cd* d_Kt = nullptr;       // same * (-1)^(kx+ky) / S
     cd *d_twx = nullptr, *d_twy = nullptr;            // exp(-2 pi i k/n) tables
@@ -131,12 +138,14 @@ static int use_plans(psfmc_ctx* c, int batch) {
 }
 
 static void free_work(psfmc_ctx* c) {
-    void** bufs[] = {(void**)&c->d_real, (void**)&c->d_spec, (void**)&c->d_T};
+    void** bufs[] = {(void**)&c->d_real, (void**)&c->d_spec, (void**)&c->d_Ts[0], (void**)&c->d_Ts[1],
+                     (void**)&c->d_Ts[2], (void**)&c->d_Ts[3]};
     for (void** p : bufs)
         if (*p) {
             (void)hipFree(*p);
             *p = nullptr;
         }
+    c->d_T = nullptr;
 }
 
 static int alloc_work(psfmc_ctx* c) {
@@ -147,7 +156,9 @@ static int alloc_work(psfmc_ctx* c) {
         HIP_TRY(hipMalloc(&c->d_spec, nimg * c->F * sizeof(double2)));
         return use_plans(c, (int)nimg);
     }
-    HIP_TRY(hipMalloc(&c->d_T, (size_t)c->chunk * 2 * c->nxh * c->ny * sizeof(cd)));
+    for (int i = 0; i < c->n_streams; ++i)
+        HIP_TRY(hipMalloc(&c->d_Ts[i], (size_t)c->chunk * 2 * c->nxh * c->ny * sizeof(cd)));
+    c->d_T = c->d_Ts[0];
     return PSFMC_OK;
 }
 
@@ -186,11 +197,11 @@ static int launch_cols(psfmc_ctx* c, cd* Tbuf, int n_cols, const double* prep, c
 }
 
 template <int NX>
-static int launch_rows_inv(psfmc_ctx* c, int n, const double* prep, const uint8_t* skip, double* partial,
-                           double* conv_out, double* var_out, hipStream_t st) {
+static int launch_rows_inv(psfmc_ctx* c, int n, const cd* Tbuf, const double* prep, const uint8_t* skip,
+                           double* partial, double* conv_out, double* var_out, hipStream_t st) {
     constexpr size_t lds = fused_row_lds_bytes<NX>();
     hipLaunchKernelGGL((k_rows_inv<NX>), dim3(c->ny / row_group<NX>(), n), dim3(kRowThreads), lds, st,
-                       c->d_T, skip, c->d_twx, c->d_field, partial, c->ny, prep, c->plen, conv_out,
+                       Tbuf, skip, c->d_twx, c->d_field, partial, c->ny, prep, c->plen, conv_out,
                        var_out);
     return PSFMC_OK;
 }
@@ -203,17 +214,17 @@ template <int NX> static int pack_field(psfmc_ctx* c) {
 
 // rasterise + both convolutions of `n` walkers; results stay in d_T (spectral
 // rows after the column pass).  rows_inv is launched by the caller.
-static int fused_forward(psfmc_ctx* c, int n, const double* prep, const uint8_t* skip, int ps_only,
-                         double* raw_out, hipStream_t st) {
-    DISPATCH_LEN(c->nx, RC_TRY((launch_rows_fwd<N_, false>(c, n, prep, skip, c->d_T, ps_only, nullptr,
+static int fused_forward(psfmc_ctx* c, int n, cd* Tbuf, const double* prep, const uint8_t* skip,
+                         int ps_only, double* raw_out, hipStream_t st) {
+    DISPATCH_LEN(c->nx, RC_TRY((launch_rows_fwd<N_, false>(c, n, prep, skip, Tbuf, ps_only, nullptr,
                                                            nullptr, raw_out, st))));
-    DISPATCH_LEN(c->ny, RC_TRY((launch_cols<N_, true>(c, c->d_T, n * 2 * c->nxh, prep, skip, st))));
+    DISPATCH_LEN(c->ny, RC_TRY((launch_cols<N_, true>(c, Tbuf, n * 2 * c->nxh, prep, skip, st))));
     return PSFMC_OK;
 }
 
-static int fused_inverse(psfmc_ctx* c, int n, const double* prep, const uint8_t* skip, double* partial,
-                         double* conv_out, double* var_out, hipStream_t st) {
-    DISPATCH_LEN(c->nx, RC_TRY((launch_rows_inv<N_>(c, n, prep, skip, partial, conv_out, var_out, st))));
+static int fused_inverse(psfmc_ctx* c, int n, const cd* Tbuf, const double* prep, const uint8_t* skip,
+                         double* partial, double* conv_out, double* var_out, hipStream_t st) {
+    DISPATCH_LEN(c->nx, RC_TRY((launch_rows_inv<N_>(c, n, Tbuf, prep, skip, partial, conv_out, var_out, st))));
     return PSFMC_OK;
 }
 
@@ -276,6 +287,11 @@ extern "C" const char* psfmc_last_error(void) { return g_err.c_str(); }
 static int ctx_init(psfmc_ctx* c, const double* sci, const double* obs_var, const uint8_t* bad_px,
                     int psf_ny, int psf_nx, const double* psf, const double* psf_var) {
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    for (int i = 1; i < psfmc_ctx::kMaxStreams; ++i) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+    }
     HIP_TRY(hipMalloc(&c->d_sci, c->S * sizeof(double)));
     HIP_TRY(hipMalloc(&c->d_var, c->S * sizeof(double)));
     HIP_TRY(hipMalloc(&c->d_bad, c->S));
@@ -392,10 +408,12 @@ extern "C" int psfmc_ctx_create(psfmc_ctx** out, int device, int ny, int nx, con
         c->rg_log2 = __builtin_ctz(ny / row_tiles);
         c->cols_grid = prop.multiProcessorCount * 2;
         // walkers per internal pass: the transposed half-spectra of one pass
+        // (two passes in flight, together about the 256 MiB Infinity Cache: measured
+        // best at 256^2)
         const double per_walker = 2.0 * c->nxh * c->ny * 16.0;
-        int chunk = (int)(4.0 * 1073741824.0 / per_walker);
-        if (chunk > 1024) chunk = 1024;
-        c->chunk = chunk < 1 ? 1 : chunk;
+        int chunk = (int)(128.0 * 1048576.0 / per_walker) & ~15;
+        if (chunk < 16) chunk = 16;
+        c->chunk = chunk;
     } else {
         c->nblk = (c->S + 1023) / 1024;
         if (c->nblk > 64) c->nblk = 64;
@@ -426,11 +444,20 @@ extern "C" int psfmc_ctx_destroy(psfmc_ctx* c) {
         hipfftDestroy(kv.second.second);
     }
     void* bufs[] = {c->d_sci,  c->d_var,  c->d_bad,     c->d_pspec, c->d_vspec, c->d_rows, c->d_prep,
-                    c->d_like, c->d_skip, c->d_partial, c->d_real,  c->d_spec,  c->d_T,    c->d_Kraw,
-                    c->d_Kt,   c->d_twx,  c->d_twy,     c->d_img0,  c->d_img1, c->d_rho,   c->d_field};
+                    c->d_like, c->d_skip, c->d_partial, c->d_real,  c->d_spec,  c->d_Ts[0], c->d_Kraw,
+                    c->d_Kt,   c->d_twx,  c->d_twy,     c->d_img0,  c->d_img1, c->d_rho,   c->d_field, c->d_Ts[1],
+                    c->d_Ts[2], c->d_Ts[3]};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    for (int i = 1; i < psfmc_ctx::kMaxStreams; ++i) {
+        if (c->side[i]) {
+            (void)hipStreamSynchronize(c->side[i]);
+            (void)hipStreamDestroy(c->side[i]);
+        }
+        if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+    }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     delete c;
     return PSFMC_OK;
 }
@@ -455,6 +482,13 @@ extern "C" int psfmc_set_option(psfmc_ctx* c, const char* key, double value) {
         c->cols_grid = (int)value;
         return PSFMC_OK;
     }
+    if (!strcmp(key, "streams")) {
+        if (value < 1 || value > psfmc_ctx::kMaxStreams) return fail(PSFMC_EINVAL, "streams must be 1..4");
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipDeviceSynchronize());
+        c->n_streams = (int)value;
+        return alloc_work(c);
+    }
     return fail(PSFMC_EINVAL, "unknown option '%s'", key);
 }
 
@@ -464,6 +498,7 @@ extern "C" double psfmc_get_option(const psfmc_ctx* c, const char* key) {
     if (!strcmp(key, "backend")) return c->backend;
     if (!strcmp(key, "max_walkers")) return c->max_walkers;
     if (!strcmp(key, "cols_grid")) return c->cols_grid;
+    if (!strcmp(key, "streams")) return c->n_streams;
     return NAN;
 }
 
@@ -491,19 +526,37 @@ static int eval_device(psfmc_ctx* c, int W, const double* d_rows, const uint8_t*
                        double* d_like, hipStream_t st) {
     hipLaunchKernelGGL(k_prep, dim3((W + 127) / 128), dim3(128), 0, st, d_rows, c->d_prep, W, c->n_ps,
                        c->n_sersic, c->ny, c->nx, c->d_rho);
-    for (int w0 = 0; w0 < W; w0 += c->chunk) {
+    const bool fused = c->backend == PSFMC_BACKEND_FUSED;
+    // Fused path: pass i runs on stream i % n_streams with its own T buffer, so the
+    // VALU-bound row kernels of one pass overlap the HBM-bound column kernel of its
+    // neighbours.  Fork/join on events keeps the caller's stream semantics.
+    const int npass = (W + c->chunk - 1) / c->chunk;
+    const int lanes = !fused ? 1 : (npass < c->n_streams ? npass : c->n_streams);
+    if (lanes > 1) {
+        HIP_TRY(hipEventRecord(c->ev_fork, st));
+        for (int i = 1; i < lanes; ++i) HIP_TRY(hipStreamWaitEvent(c->side[i], c->ev_fork, 0));
+    }
+    int pass = 0;
+    for (int w0 = 0; w0 < W; w0 += c->chunk, ++pass) {
         const int n = W - w0 < c->chunk ? W - w0 : c->chunk;
         const double* prep = c->d_prep + (size_t)w0 * c->plen;
         const uint8_t* skip = d_skip ? d_skip + w0 : nullptr;
         double* partial = c->d_partial + (size_t)w0 * c->nblk;
-        if (c->backend == PSFMC_BACKEND_FUSED) {
-            RC_TRY(fused_forward(c, n, prep, skip, 0, nullptr, st));
-            RC_TRY(fused_inverse(c, n, prep, skip, partial, nullptr, nullptr, st));
+        if (fused) {
+            const int lane = pass % lanes;
+            hipStream_t s = lane ? c->side[lane] : st;
+            cd* Tbuf = c->d_Ts[lane];
+            RC_TRY(fused_forward(c, n, Tbuf, prep, skip, 0, nullptr, s));
+            RC_TRY(fused_inverse(c, n, Tbuf, prep, skip, partial, nullptr, nullptr, s));
         } else {
             RC_TRY(hipfft_convolve(c, n, prep, skip, st, 0));
             hipLaunchKernelGGL(k_chi2, dim3(c->nblk, n), dim3(256), 0, st, c->d_real, c->d_sci, c->d_var,
                                c->d_bad, skip, partial, c->S);
         }
+    }
+    for (int i = 1; i < lanes; ++i) {
+        HIP_TRY(hipEventRecord(c->ev_join[i], c->side[i]));
+        HIP_TRY(hipStreamWaitEvent(st, c->ev_join[i], 0));
     }
     hipLaunchKernelGGL(k_finish, dim3((W + 127) / 128), dim3(128), 0, st, c->d_partial, d_skip, d_like,
                        W, c->nblk);
@@ -588,8 +641,8 @@ extern "C" int psfmc_eval_images(psfmc_ctx* c, int W, const double* rows, double
         };
         auto pass = [&](int ps_only, double* raw_dev) -> int {
             if (fused) {
-                RC_TRY(fused_forward(c, n, prep, nullptr, ps_only, raw_dev, st));
-                return fused_inverse(c, n, prep, nullptr, c->d_partial, c->d_img0, c->d_img1, st);
+                RC_TRY(fused_forward(c, n, c->d_T, prep, nullptr, ps_only, raw_dev, st));
+                return fused_inverse(c, n, c->d_T, prep, nullptr, c->d_partial, c->d_img0, c->d_img1, st);
             }
             return hipfft_convolve(c, n, prep, nullptr, st, ps_only);
         };
