@@ -35,6 +35,19 @@ def algorithmic_bytes_per_eval(n):
     return 96 * n * n + 64 * n
 
 
+def pmc_traffic(args, kernel):
+    """HBM bytes per walker of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json; FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM,
+    plus WRITE_SIZE), or None when that shape was not profiled."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    try:
+        with open(path) as f:
+            table = json.load(f)
+        return table['%dx%d' % (args.size, args.size)][kernel]['hbm_bytes_per_walker']
+    except (IOError, OSError, KeyError, ValueError):
+        return None
+
+
 def build_problem(args, device):
     """Synthetic field + walker rows.  Returns (model, theta[W,P])."""
     import tempfile
@@ -56,6 +69,42 @@ def build_problem(args, device):
         synth_field.draw_walkers(args.size, args.sersic, args.walkers - half, seed=2,
                                  near_truth=fld['truth'])])
     return model, theta, fld
+
+
+def kernel_profile(eng, args, step, torch, dev, steps):
+    """Per-kernel device time from HIP events recorded inside the library around
+    every launch (set_option 'profile').  Run with ONE pass in flight so that a
+    kernel's events bracket that kernel alone -- the same quantity rocprofv3
+    --kernel-trace reports.  Returns a list of dicts, longest total first."""
+    n = args.size
+    nxh = n // 2 + 1
+    t_bytes = 2 * nxh * n * 16                  # transposed half-spectra of one walker
+    designed = {'rows_fwd': t_bytes, 'cols': 2 * t_bytes, 'rows_inv': t_bytes}
+    names = {'rows_fwd': 'k_rows_fwd<%d, false>' % n, 'cols': 'k_cols<%d, true>' % n,
+             'rows_inv': 'k_rows_inv<%d>' % n}
+    streams = eng.get_option('streams')
+    eng.set_option('streams', 1)
+    eng.set_option('profile', 1)
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(dev)
+    chunk = int(eng.get_option('chunk_walkers'))
+    out = []
+    for key in ('rows_fwd', 'cols', 'rows_inv'):
+        ms = eng.get_option('prof_ms_' + key)
+        cnt = eng.get_option('prof_n_' + key)
+        if not cnt:
+            continue
+        avg_s = ms * 1e-3 / cnt
+        walkers = args.walkers * steps / cnt          # walkers one launch processes (avg)
+        out.append({'kernel': names[key], 'launches': int(cnt), 'avg_ms': avg_s * 1e3,
+                    'total_ms': ms, 'walkers_per_launch': walkers,
+                    'bytes_per_walker': designed[key],
+                    'GBps': designed[key] * walkers / avg_s / 1e9})
+    eng.set_option('profile', 0)
+    eng.set_option('streams', streams)
+    out.sort(key=lambda d: -d['total_ms'])
+    return out, chunk
 
 
 def cpu_baseline(args, fld, theta, budget_s):
@@ -155,6 +204,13 @@ def main():
     lnlike = out.cpu().numpy()
     n_finite = int(np.isfinite(lnlike).sum())
 
+    kernels, chunk = ([], 0)
+    if rank == 0 and args.backend == 'fused':
+        kernels, chunk = kernel_profile(eng, args, step if world == 1 else
+                                        (lambda: eng.loglike_device(args.walkers, rows.data_ptr(), 0,
+                                                                    out.data_ptr(), stream.cuda_stream)),
+                                        torch, dev, max(2, min(args.steps, 5)))
+
     if rank == 0:
         total_evals = args.walkers * world * args.steps
         value = total_evals / elapsed
@@ -172,12 +228,37 @@ def main():
                                    % (args.size, args.size, args.sersic, args.walkers),
                        'image': args.size, 'walkers_per_gpu': args.walkers,
                        'backend': args.backend, 'parallelism': 'walkers sharded x%d' % world},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
-                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
-                         'kernel': 'evaluation pipeline (one eval_batch_device pass)',
-                         'bytes_per_eval': b_eval, 'launch_ms': launch_s * 1e3},
             'finite_loglikes': n_finite,
         }
+        # whole pipeline against SURVEY.md section 8(d)'s algorithmic bytes per evaluation
+        pipe = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
+                'kernel': 'evaluation pipeline (k_rows_fwd + k_cols + k_rows_inv, one '
+                          'eval_batch_device call of %d walkers)' % args.walkers,
+                'bytes_per_eval': b_eval, 'launch_ms': launch_s * 1e3}
+        if kernels:
+            # dominant kernel: its own algorithmic bytes (= the HBM bytes the design
+            # moves: it reads and writes the transposed half-spectra once) over its
+            # event-timed average launch duration
+            k = kernels[0]
+            traffic = pmc_traffic(args, k['kernel'])
+            line['roofline'] = {
+                'bound': 'hbm', 'achieved': k['GBps'], 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                'frac': k['GBps'] / HBM_PEAK_GBPS,
+                'traffic': traffic * k['walkers_per_launch'] if traffic else None,
+                'kernel': k['kernel'], 'launch_ms': k['avg_ms'], 'launches': k['launches'],
+                'bytes_per_launch': k['bytes_per_walker'] * k['walkers_per_launch'],
+                'walkers_per_launch': k['walkers_per_launch']}
+            line['roofline_pipeline'] = pipe
+            line['kernels'] = kernels
+        else:
+            line['roofline'] = pipe
+        # host-inclusive rate: the Python batch call (scipy priors, kappa, rows, H2D, D2H)
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            model.log_posterior_batch(theta)
+        line['host_path_evals_per_s'] = args.walkers * reps / (time.perf_counter() - t0)
         if not args.no_cpu:
             base, vals = cpu_baseline(args, fld, theta, args.cpu_seconds)
             line['cpu_baseline'] = base

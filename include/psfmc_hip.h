@@ -124,7 +124,9 @@ int psfmc_eval_images(psfmc_ctx* ctx, int W, const double* rows,
  */
 int psfmc_get_spectra(psfmc_ctx* ctx, double* psf_spec, double* var_spec);
 
-/* tuning knobs: "chunk_walkers" (walkers per internal pass) */
+/* tuning knobs: "chunk_walkers" (walkers per internal pass), "streams" (passes in
+ * flight, 1..4), "cols_grid", "profile" (1: time every kernel with HIP events; read
+ * back with get_option "prof_ms_rows_fwd" / "prof_n_rows_fwd", ..._cols, ..._rows_inv) */
 int psfmc_set_option(psfmc_ctx* ctx, const char* key, double value);
 double psfmc_get_option(const psfmc_ctx* ctx, const char* key);
 

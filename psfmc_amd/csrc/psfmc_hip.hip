@@ -101,6 +101,12 @@ struct psfmc_ctx {
     hipStream_t side[kMaxStreams] = {nullptr, nullptr, nullptr, nullptr};   // side[0] unused
     hipEvent_t ev_fork = nullptr, ev_join[kMaxStreams] = {nullptr, nullptr, nullptr, nullptr};
     int n_streams = 2;
+    // optional per-kernel timing with HIP events (set_option "profile")
+    bool profile = false;
+    struct ProfRec { int kind; hipEvent_t a, b; };
+    std::vector<ProfRec> prof_pending;
+    double prof_ms[3] = {0, 0, 0};
+    long prof_n[3] = {0, 0, 0};
     cd* d_Kraw = nullptr;     // [n_psf][2][nxh][ny] kernel spectra, unscaled
     cd* d_Kt = nullptr;       // same * (-1)^(kx+ky) / S
     cd *d_twx = nullptr, *d_twy = nullptr;            // exp(-2 pi i k/n) tables
@@ -212,18 +218,52 @@ template <int NX> static int pack_field(psfmc_ctx* c) {
     return PSFMC_OK;
 }
 
+// per-kernel timing: bracket a launch with events on its own stream
+enum { PROF_ROWS_FWD = 0, PROF_COLS = 1, PROF_ROWS_INV = 2 };
+struct ProfScope {
+    psfmc_ctx* c; int kind; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(psfmc_ctx* c_, int kind_, hipStream_t st_) : c(c_), kind(kind_), st(st_) {
+        if (c->profile && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess)
+            (void)hipEventRecord(a, st);
+    }
+    ~ProfScope() {
+        if (c->profile && a && b) {
+            (void)hipEventRecord(b, st);
+            c->prof_pending.push_back({kind, a, b});
+        }
+    }
+};
+
+static void prof_collect(psfmc_ctx* c) {
+    for (auto& r : c->prof_pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            c->prof_ms[r.kind] += ms;
+            c->prof_n[r.kind] += 1;
+        }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    c->prof_pending.clear();
+}
+
 // rasterise + both convolutions of `n` walkers; results stay in d_T (spectral
 // rows after the column pass).  rows_inv is launched by the caller.
 static int fused_forward(psfmc_ctx* c, int n, cd* Tbuf, const double* prep, const uint8_t* skip,
                          int ps_only, double* raw_out, hipStream_t st) {
-    DISPATCH_LEN(c->nx, RC_TRY((launch_rows_fwd<N_, false>(c, n, prep, skip, Tbuf, ps_only, nullptr,
-                                                           nullptr, raw_out, st))));
+    {
+        ProfScope ps(c, PROF_ROWS_FWD, st);
+        DISPATCH_LEN(c->nx, RC_TRY((launch_rows_fwd<N_, false>(c, n, prep, skip, Tbuf, ps_only, nullptr,
+                                                               nullptr, raw_out, st))));
+    }
+    ProfScope ps(c, PROF_COLS, st);
     DISPATCH_LEN(c->ny, RC_TRY((launch_cols<N_, true>(c, Tbuf, n * 2 * c->nxh, prep, skip, st))));
     return PSFMC_OK;
 }
 
 static int fused_inverse(psfmc_ctx* c, int n, const cd* Tbuf, const double* prep, const uint8_t* skip,
                          double* partial, double* conv_out, double* var_out, hipStream_t st) {
+    ProfScope ps(c, PROF_ROWS_INV, st);
     DISPATCH_LEN(c->nx, RC_TRY((launch_rows_inv<N_>(c, n, Tbuf, prep, skip, partial, conv_out, var_out, st))));
     return PSFMC_OK;
 }
@@ -411,7 +451,7 @@ extern "C" int psfmc_ctx_create(psfmc_ctx** out, int device, int ny, int nx, con
         // (two passes in flight, together about the 256 MiB Infinity Cache: measured
         // best at 256^2)
         const double per_walker = 2.0 * c->nxh * c->ny * 16.0;
-        int chunk = (int)(128.0 * 1048576.0 / per_walker) & ~15;
+        int chunk = ((int)(128.0 * 1048576.0 / per_walker) + 8) & ~15;
         if (chunk < 16) chunk = 16;
         c->chunk = chunk;
     } else {
@@ -439,6 +479,7 @@ extern "C" int psfmc_ctx_destroy(psfmc_ctx* c) {
     if (!c) return PSFMC_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    prof_collect(c);
     for (auto& kv : c->plans) {
         hipfftDestroy(kv.second.first);
         hipfftDestroy(kv.second.second);
@@ -482,6 +523,14 @@ extern "C" int psfmc_set_option(psfmc_ctx* c, const char* key, double value) {
         c->cols_grid = (int)value;
         return PSFMC_OK;
     }
+    if (!strcmp(key, "profile")) {
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipDeviceSynchronize());
+        prof_collect(c);
+        c->profile = value != 0;
+        for (int i = 0; i < 3; ++i) { c->prof_ms[i] = 0; c->prof_n[i] = 0; }
+        return PSFMC_OK;
+    }
     if (!strcmp(key, "streams")) {
         if (value < 1 || value > psfmc_ctx::kMaxStreams) return fail(PSFMC_EINVAL, "streams must be 1..4");
         HIP_TRY(hipSetDevice(c->device));
@@ -492,8 +541,18 @@ extern "C" int psfmc_set_option(psfmc_ctx* c, const char* key, double value) {
     return fail(PSFMC_EINVAL, "unknown option '%s'", key);
 }
 
-extern "C" double psfmc_get_option(const psfmc_ctx* c, const char* key) {
-    if (!c || !key) return NAN;
+extern "C" double psfmc_get_option(const psfmc_ctx* cc, const char* key) {
+    if (!cc || !key) return NAN;
+    psfmc_ctx* c = const_cast<psfmc_ctx*>(cc);
+    static const char* kinds[3] = {"rows_fwd", "cols", "rows_inv"};
+    for (int i = 0; i < 3; ++i) {
+        char name[64];
+        snprintf(name, sizeof name, "prof_ms_%s", kinds[i]);
+        if (!strcmp(key, name)) { prof_collect(c); return c->prof_ms[i]; }
+        snprintf(name, sizeof name, "prof_n_%s", kinds[i]);
+        if (!strcmp(key, name)) { prof_collect(c); return (double)c->prof_n[i]; }
+    }
+    if (!strcmp(key, "row_group")) return 1 << c->rg_log2;
     if (!strcmp(key, "chunk_walkers")) return c->chunk;
     if (!strcmp(key, "backend")) return c->backend;
     if (!strcmp(key, "max_walkers")) return c->max_walkers;

@@ -1,31 +1,32 @@
 #!/bin/bash
-# PMC passes for the fused kernels (run on the GPU box via gpurun).
+# rocprofv3 PMC passes over bench.py (run on the GPU box via gpurun).  Counters are
+# collected in their own runs (no trace domains), FETCH_SIZE and WRITE_SIZE apart
+# (they do not fit one pass: MI355X_MICROARCH.md, rocprofv3 PMC slots).
 # usage: tools/prof_pmc.sh <outdir-under-gpurun_out> [bench args...]
 set -o pipefail
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
+BENCH_ARGS="$*"
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() {  # name counters...
   local name=$1; shift
   rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu $BENCH_ARGS > $OUT/$name.log 2>&1 || echo "pass $name failed"
 }
-BENCH_ARGS="$*"
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVES
-run sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS
+run sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS
 run fetch FETCH_SIZE
 run write WRITE_SIZE
-run tcc TCC_HIT_sum TCC_MISS_sum
 python3 - <<PY
 import csv, glob, collections
-for name in ['sq1','sq2','fetch','write','tcc']:
+for name in ['sq1','sq2','fetch','write']:
     files = glob.glob('$OUT/%s/*/*counter_collection.csv' % name)
     if not files: print(name, 'no output'); continue
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
     for r in csv.DictReader(open(files[0])):
-        k = r['Kernel_Name'].split('(')[0][-30:]
+        k = r['Kernel_Name'].split('(')[0].replace('void psfmc::','')
         agg[k][r['Counter_Name']] += float(r['Counter_Value'])
         cnt[(k, r['Counter_Name'])] += 1
-    for k in agg:
-        if 'k_rows' in k or 'k_cols' in k:
+    for k in sorted(agg):
+        if ('k_rows' in k or 'k_cols' in k) and 'true>' not in k.replace('k_cols','') and ', false>' not in k.replace('k_rows_fwd',''):
             print(name, k, {c: '%.4g' % (v / cnt[(k, c)]) for c, v in agg[k].items()})
 PY
