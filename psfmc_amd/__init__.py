@@ -4,6 +4,10 @@ brightness modelling.  Public names mirror the reference package `psfMC`.
 """
 from .models import MultiComponentModel
 from .batch import BatchLogPosterior
+from .sampler import EnsembleSampler
+from .fitting import model_galaxy_mcmc
+from .database import load_database
 
 __version__ = '0.1.0'
-__all__ = ['MultiComponentModel', 'BatchLogPosterior']
+__all__ = ['MultiComponentModel', 'BatchLogPosterior', 'EnsembleSampler', 'model_galaxy_mcmc',
+           'load_database']

@@ -154,3 +154,89 @@ def write_image(path, data, header=None):
     with open(path, 'wb') as f:
         f.write(head)
         f.write(body)
+
+
+# --------------------------------------------------------------------------
+# binary tables (trace database, psfMC/database.py:6-56 uses astropy.table)
+# --------------------------------------------------------------------------
+_TFORM = {'f8': ('D', '>f8'), 'i8': ('K', '>i8'), 'f4': ('E', '>f4'), 'i4': ('J', '>i4'),
+          'b1': ('L', 'u1')}
+_TFORM_READ = {'D': '>f8', 'K': '>i8', 'E': '>f4', 'J': '>i4', 'I': '>i2', 'B': 'u1', 'L': 'u1'}
+
+
+def write_table(path, columns, meta=None):
+    """One BINTABLE extension.  `columns`: ordered mapping name -> array [nrows] or
+    [nrows, k]; `meta`: mapping key -> value or (value, comment)."""
+    names = list(columns)
+    arrays = [np.asarray(columns[n]) for n in names]
+    nrows = len(arrays[0]) if arrays else 0
+    fields, tforms = [], []
+    for n, a in zip(names, arrays):
+        if len(a) != nrows:
+            raise ValueError('column {} has {} rows, expected {}'.format(n, len(a), nrows))
+        kind = a.dtype.kind + str(a.dtype.itemsize)
+        if kind not in _TFORM:
+            a = a.astype(np.float64)
+            kind = 'f8'
+        width = int(np.prod(a.shape[1:])) if a.ndim > 1 else 1
+        code, be = _TFORM[kind]
+        fields.append((a.reshape(nrows, width), be, width))
+        tforms.append(('%d%s' % (width, code)) if width > 1 else code)
+    rec = np.dtype([('c%d' % i, be, (w,)) for i, (_, be, w) in enumerate(fields)])
+    table = np.zeros(nrows, dtype=rec)
+    for i, (a, be, w) in enumerate(fields):
+        table['c%d' % i] = a
+    primary = [_card('SIMPLE', True, 'conforms to FITS standard'), _card('BITPIX', 8),
+               _card('NAXIS', 0), _card('EXTEND', True), 'END'.ljust(80)]
+    head0 = ''.join(primary).encode('ascii')
+    head0 += b' ' * (-len(head0) % BLOCK)
+    cards = [_card('XTENSION', 'BINTABLE', 'binary table extension'), _card('BITPIX', 8),
+             _card('NAXIS', 2), _card('NAXIS1', rec.itemsize), _card('NAXIS2', nrows),
+             _card('PCOUNT', 0), _card('GCOUNT', 1), _card('TFIELDS', len(names))]
+    for i, (n, tf) in enumerate(zip(names, tforms)):
+        cards.append(_card('TTYPE%d' % (i + 1), n))
+        cards.append(_card('TFORM%d' % (i + 1), tf))
+    for key, val in (meta or {}).items():
+        comment = ''
+        if isinstance(val, tuple):
+            val, comment = val
+        if isinstance(val, (np.bool_,)):
+            val = bool(val)
+        cards.append(_card(str(key).upper()[:8], val, comment))
+    cards.append('END'.ljust(80))
+    head1 = ''.join(cards).encode('ascii')
+    head1 += b' ' * (-len(head1) % BLOCK)
+    body = table.tobytes()
+    body += b'\0' * (-len(body) % BLOCK)
+    with open(path, 'wb') as f:
+        f.write(head0 + head1 + body)
+
+
+def read_table(path):
+    """First BINTABLE extension -> (OrderedDict name -> native array, header)."""
+    with _open(path) as f:
+        hdr, _ = _read_header(f)
+        shape = _data_shape(hdr)
+        skip = (int(np.prod(shape)) if shape else 0) * abs(int(hdr.get('BITPIX', 8))) // 8
+        f.read(-(-skip // BLOCK) * BLOCK)
+        while True:
+            hdr, _ = _read_header(f)
+            if not hdr:
+                raise IOError('no binary table in {}'.format(path))
+            n1, n2 = int(hdr.get('NAXIS1', 0)), int(hdr.get('NAXIS2', 0))
+            if str(hdr.get('XTENSION', '')).strip() == 'BINTABLE':
+                break
+            f.read(-(-(n1 * n2 + int(hdr.get('PCOUNT', 0))) // BLOCK) * BLOCK)
+        fields = []
+        for i in range(int(hdr['TFIELDS'])):
+            tform = str(hdr['TFORM%d' % (i + 1)]).strip()
+            width = int(tform[:-1]) if tform[:-1] else 1
+            fields.append((str(hdr['TTYPE%d' % (i + 1)]).strip(), _TFORM_READ[tform[-1]], width))
+        rec = np.dtype([('c%d' % i, be, (w,)) for i, (_, be, w) in enumerate(fields)])
+        raw = np.frombuffer(f.read(n1 * n2), dtype=rec, count=n2)
+    cols = OrderedDict()
+    for i, (name, be, w) in enumerate(fields):
+        a = raw['c%d' % i]
+        a = a.astype(a.dtype.newbyteorder('='))
+        cols[name] = a[:, 0] if w == 1 else a
+    return cols, hdr

@@ -1,0 +1,95 @@
+"""
+`model_galaxy_mcmc`: the reference's entry point (psfMC/fitting.py:13-113) on the
+batched GPU log-posterior.  Same arguments and outputs (trace database
+`<output_name>_db.fits`, posterior images `<output_name>_<type>.fits`); every
+half-ensemble proposal is one GPU batch, and the per-iteration image accumulation
+(`fitting.py:83`) evaluates the walkers' current positions in one batch instead of
+carrying five images back from every proposal.
+"""
+import os
+from collections import OrderedDict
+from warnings import warn
+
+import numpy as np
+
+from .analysis import check_convergence_autocorr, save_posterior_images, default_filetypes
+from .database import save_database, load_database
+from .models import MultiComponentModel
+from .sampler import EnsembleSampler
+from .utils import print_progress
+
+
+def model_galaxy_mcmc(model_file, output_name=None, write_fits=default_filetypes, iterations=0,
+                      burn=0, chains=None, max_iterations=1,
+                      convergence_check=check_convergence_autocorr, sampler_class=None,
+                      device=0, backend='fused', random_state=None, accumulate=True, quiet=False):
+    """Model a galaxy's surface brightness with MCMC.
+
+    model_file, output_name, write_fits, iterations, burn, chains, max_iterations,
+    convergence_check: as in the reference.  Extra keywords: `sampler_class` (an
+    emcee-compatible EnsembleSampler; default the built-in one), `device`,
+    `backend`, `random_state` (RandomState state tuple or seed for reproducible
+    runs), `accumulate` (posterior images during sampling)."""
+    if output_name is None:
+        output_name = 'out_' + model_file.replace('.py', '')
+    output_name += '_{}'
+
+    mc_model = model_file if isinstance(model_file, MultiComponentModel) else None
+    if mc_model is None:
+        n_hint = max(chains or 0, 64)
+        mc_model = MultiComponentModel(model_file, device=device, backend=backend,
+                                       max_walkers=n_hint)
+    if chains is None:
+        chains = 2 * mc_model.num_params + 2
+    if chains > mc_model._max_walkers:
+        raise ValueError('model was built for at most {} walkers'.format(mc_model._max_walkers))
+
+    cls = sampler_class or EnsembleSampler
+    if cls is EnsembleSampler:
+        sampler = cls(chains, mc_model.num_params, batch_lnpostfn=mc_model.log_posterior_batch)
+    else:                      # a real emcee: batch through its pool hook
+        from .batch import BatchLogPosterior
+        sampler = cls(chains, mc_model.num_params, mc_model.log_posterior,
+                      kwargs={'model': mc_model}, pool=BatchLogPosterior(mc_model).as_pool())
+    if random_state is not None:
+        if isinstance(random_state, (int, np.integer)):
+            random_state = np.random.RandomState(int(random_state)).get_state()
+        sampler.random_state = random_state
+
+    db_name = output_name.format('db') + '.fits'
+    if not os.path.exists(db_name):
+        param_vec = mc_model.init_params_from_priors(chains)
+        lnprob = None
+        for step, result in enumerate(sampler.sample(param_vec, iterations=burn)):
+            param_vec, lnprob = result[0], result[1]
+            sampler.clear_blobs()
+            if not quiet:
+                print_progress(step, burn, 'Burning')
+        sampler.reset()
+
+        converged = False
+        for sampling_iter in range(max_iterations):
+            for step, result in enumerate(sampler.sample(param_vec, lnprob0=lnprob,
+                                                         iterations=iterations)):
+                param_vec, lnprob = result[0], result[1]
+                if accumulate:      # images of the walkers' current positions, one batch
+                    mc_model.accumulate_images(mc_model.sample_images(param_vec))
+                sampler.clear_blobs()
+                if not quiet:
+                    print_progress(step, iterations, 'Sampling')
+            if convergence_check(sampler):
+                converged = True
+                break
+            warn('Not yet converged after {:d} iterations:'.format((sampling_iter + 1) * iterations))
+            convergence_check(sampler, verbose=0 if quiet else 1)
+
+        meta = OrderedDict([('MCITER', sampler.chain.shape[1]), ('MCBURN', burn),
+                            ('MCCHAINS', chains), ('MCCONVRG', bool(converged)),
+                            ('MCACCEPT', float(sampler.acceptance_fraction.mean()))])
+        database = save_database(sampler, mc_model, db_name, meta_dict=meta)
+    else:
+        print('Database already contains sampled chains, skipping sampling')
+        database = load_database(db_name)
+
+    save_posterior_images(mc_model, database, output_name=output_name, filetypes=write_fits)
+    return mc_model, database

@@ -208,7 +208,10 @@ class MultiComponentModel(object):
     def log_likelihood_batch(self, theta, skip=None):
         """[W] Gaussian log-likelihoods from the GPU; non-finite -> -inf."""
         rows = self.derived_rows(theta)
-        ll = self.engine.loglike(rows, skip)
+        cap = self._max_walkers                  # larger batches go through in slices
+        parts = [self.engine.loglike(rows[lo:lo + cap], None if skip is None else skip[lo:lo + cap])
+                 for lo in range(0, len(rows), cap)]
+        ll = np.concatenate(parts) if parts else np.zeros(0)
         return np.where(np.isfinite(ll), ll, -np.inf)
 
     def log_posterior_batch(self, theta):
@@ -241,7 +244,10 @@ class MultiComponentModel(object):
     def sample_images(self, theta, kinds=None):
         """The per-sample images of models.py:222-226 for W vectors:
         dict kind -> [W, ny, nx]."""
-        return self.engine.images(self.derived_rows(theta), kinds)
+        rows = self.derived_rows(theta)
+        cap = self._max_walkers
+        parts = [self.engine.images(rows[lo:lo + cap], kinds) for lo in range(0, max(len(rows), 1), cap)]
+        return {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
 
     def _one_image(self, kind):
         return self.sample_images(self._param_vector, (kind,))[kind][0]

@@ -1,0 +1,239 @@
+"""
+Affine-invariant ensemble sampler (Goodman & Weare 2010 stretch move) with the
+interface of emcee 2.2.1's `EnsembleSampler`, which the reference drives
+(psfMC/fitting.py:56-86, psfMC/database.py:18-19, analysis/statistics.py:145).
+
+emcee is not installable here (no network) and is not vendored by the
+reference, so this is written from the published algorithm and emcee's
+documented API; SURVEY.md Appendix A lists the behaviour it reproduces:
+two half-ensemble proposals per iteration, `z ~ g(z) ∝ 1/sqrt(z)` on [1/a, a],
+acceptance `ln q = (dim-1) ln z + lnp(new) - lnp(old) > ln U`, a
+`numpy.random.RandomState` owned by the sampler, `(lnprob, blob)` results,
+`ValueError` on NaN log-probabilities or non-finite parameters, the `pool.map`
+hook, `chain [nwalkers, iterations, dim]`, `lnprobability`, `acceptance_fraction`,
+`reset`, `clear_blobs`, `get_autocorr_time`.  PARITY UNPINNED against emcee
+itself (no copy available); its statistical behaviour is tested on Gaussian
+targets (tests/test_sampler.py).
+
+What is new: every half-step evaluates its walkers in ONE call --
+`batch_lnpostfn([n, dim]) -> [n]` (e.g. `model.log_posterior_batch`, one GPU
+batch) or `pool.map` (e.g. `BatchLogPosterior.as_pool()`), instead of one Python
+call per walker.
+"""
+import numpy as np
+
+__all__ = ['EnsembleSampler', 'AutocorrError', 'integrated_time']
+
+
+class AutocorrError(Exception):
+    """The chain is too short to estimate the autocorrelation time."""
+
+
+def autocorr_function(x, axis=0):
+    """Normalised autocorrelation function along `axis` (FFT based)."""
+    x = np.atleast_1d(x)
+    n = x.shape[axis]
+    idx = [slice(None)] * x.ndim
+    f = np.fft.fft(x - np.mean(x, axis=axis, keepdims=True), n=2 * n, axis=axis)
+    idx[axis] = slice(0, n)
+    acf = np.fft.ifft(f * np.conjugate(f), axis=axis)[tuple(idx)].real
+    idx[axis] = slice(0, 1)
+    return acf / acf[tuple(idx)]
+
+
+def integrated_time(x, low=10, high=None, step=1, c=10, axis=0):
+    """Integrated autocorrelation time with the self-consistent window of
+    emcee 2.x: the smallest window M in [low, high) with M > c * tau(M)."""
+    size = 0.5 * x.shape[axis]
+    if int(c * low) >= size:
+        raise AutocorrError('The chain is too short')
+    f = autocorr_function(x, axis=axis)
+    if high is None:
+        high = int(size / c)
+    idx = [slice(None)] * f.ndim
+    for m in np.arange(low, high, step).astype(int):
+        idx[axis] = slice(1, m)
+        tau = 1 + 2 * np.sum(f[tuple(idx)], axis=axis)
+        if np.all(tau > 1.0) and m > c * tau.max():
+            return tau
+    raise AutocorrError('The chain is too short to reliably estimate the '
+                        'autocorrelation time')
+
+
+class _Wrapped(object):
+    """lnpostfn with its extra arguments bound (a fresh kwargs dict per call:
+    the reference's log_posterior pops 'model' from it, models.py:205)."""
+
+    def __init__(self, f, args, kwargs):
+        self.f, self.args, self.kwargs = f, list(args or []), dict(kwargs or {})
+
+    def __call__(self, x):
+        return self.f(x, *self.args, **self.kwargs)
+
+
+class EnsembleSampler(object):
+    def __init__(self, nwalkers, dim, lnpostfn=None, a=2.0, args=None, kwargs=None,
+                 threads=1, pool=None, live_dangerously=False, batch_lnpostfn=None):
+        if nwalkers % 2:
+            raise ValueError('The number of walkers must be even.')
+        if nwalkers < 2 * dim and not live_dangerously:
+            raise ValueError('The number of walkers needs to be more than twice the '
+                             'dimension of your parameter space.')
+        if lnpostfn is None and batch_lnpostfn is None:
+            raise ValueError('need lnpostfn or batch_lnpostfn')
+        self.k, self.dim, self.a = int(nwalkers), int(dim), float(a)
+        self.lnprobfn = _Wrapped(lnpostfn, args, kwargs) if lnpostfn is not None else None
+        self.batch_lnpostfn = batch_lnpostfn
+        self.pool = pool
+        self.threads = threads
+        self._random = np.random.mtrand.RandomState()
+        self._last_run_mcmc_result = None
+        self.reset()
+
+    # -- state ----------------------------------------------------------------
+    def reset(self):
+        self.iterations = 0
+        self.naccepted = np.zeros(self.k)
+        self._chain = np.empty((self.k, 0, self.dim))
+        self._lnprob = np.empty((self.k, 0))
+        self._blobs = []
+        self._last_run_mcmc_result = None
+
+    clear_chain = reset
+
+    def clear_blobs(self):
+        self._blobs = []
+
+    @property
+    def random_state(self):
+        return self._random.get_state()
+
+    @random_state.setter
+    def random_state(self, state):
+        try:
+            self._random.set_state(state)
+        except (TypeError, ValueError):
+            pass
+
+    @property
+    def chain(self):
+        return self._chain
+
+    @property
+    def flatchain(self):
+        s = self._chain.shape
+        return self._chain.reshape(s[0] * s[1], s[2])
+
+    @property
+    def lnprobability(self):
+        return self._lnprob
+
+    @property
+    def flatlnprobability(self):
+        return self._lnprob.flatten()
+
+    @property
+    def blobs(self):
+        return self._blobs
+
+    @property
+    def acceptance_fraction(self):
+        return self.naccepted / max(self.iterations, 1)
+
+    @property
+    def acor(self):
+        return self.get_autocorr_time()
+
+    def get_autocorr_time(self, low=10, high=None, step=1, c=10):
+        return integrated_time(np.mean(self._chain, axis=0), axis=0, low=low, high=high,
+                               step=step, c=c)
+
+    # -- evaluation -------------------------------------------------------------
+    def _get_lnprob(self, pos):
+        p = np.asarray(pos, dtype=np.float64)
+        if np.any(np.isinf(p)):
+            raise ValueError('At least one parameter value was infinite.')
+        if np.any(np.isnan(p)):
+            raise ValueError('At least one parameter value was NaN.')
+        if self.batch_lnpostfn is not None:
+            lnprob, blob = np.asarray(self.batch_lnpostfn(p), dtype=np.float64), None
+        else:
+            mapper = self.pool.map if self.pool is not None else map
+            results = list(mapper(self.lnprobfn, [p[i] for i in range(len(p))]))
+            try:
+                lnprob = np.array([float(r[0]) for r in results])
+                blob = [r[1] for r in results]
+            except (IndexError, TypeError):
+                lnprob = np.array([float(r) for r in results])
+                blob = None
+        if np.any(np.isnan(lnprob)):
+            raise ValueError('lnprob returned NaN.')
+        return lnprob, blob
+
+    def _propose_stretch(self, p0, p1, lnprob0):
+        s, c = np.atleast_2d(p0), np.atleast_2d(p1)
+        ns, nc = len(s), len(c)
+        zz = ((self.a - 1.0) * self._random.rand(ns) + 1) ** 2.0 / self.a
+        rint = self._random.randint(nc, size=(ns,))
+        q = c[rint] - zz[:, np.newaxis] * (c[rint] - s)
+        newlnprob, blob = self._get_lnprob(q)
+        lnpdiff = (self.dim - 1.0) * np.log(zz) + newlnprob - lnprob0
+        accept = lnpdiff > np.log(self._random.rand(len(lnpdiff)))
+        return q, newlnprob, accept, blob
+
+    # -- sampling ----------------------------------------------------------------
+    def sample(self, p0, lnprob0=None, rstate0=None, blobs0=None, iterations=1, thin=1,
+               storechain=True):
+        """Generator advancing the ensemble; yields (pos, lnprob, rstate[, blobs])
+        after every iteration."""
+        if rstate0 is not None:
+            self.random_state = rstate0
+        p = np.array(p0, dtype=np.float64)
+        if p.shape != (self.k, self.dim):
+            raise ValueError('p0 must have shape ({}, {})'.format(self.k, self.dim))
+        halfk = self.k // 2
+        lnprob, blobs = lnprob0, blobs0
+        if lnprob is None:
+            lnprob, blobs = self._get_lnprob(p)
+        lnprob = np.array(lnprob, dtype=np.float64)
+        if np.any(np.isnan(lnprob)):
+            raise ValueError('The initial lnprob was NaN.')
+        i0 = self._chain.shape[1]
+        if storechain:
+            n_keep = int(iterations // thin)
+            self._chain = np.concatenate((self._chain, np.zeros((self.k, n_keep, self.dim))), axis=1)
+            self._lnprob = np.concatenate((self._lnprob, np.zeros((self.k, n_keep))), axis=1)
+        first, second = slice(halfk), slice(halfk, self.k)
+        for i in range(int(iterations)):
+            self.iterations += 1
+            for s0, s1 in ((first, second), (second, first)):
+                q, newlnp, acc, blob = self._propose_stretch(p[s0], p[s1], lnprob[s0])
+                if np.any(acc):
+                    lnprob[s0][acc] = newlnp[acc]
+                    p[s0][acc] = q[acc]
+                    self.naccepted[s0][acc] += 1
+                    if blob is not None and blobs is not None:
+                        full = np.arange(self.k)[s0][acc]
+                        for j, src in zip(full, np.arange(len(acc))[acc]):
+                            blobs[j] = blob[src]
+            if storechain and i % thin == 0:
+                ind = i0 + int(i // thin)
+                self._chain[:, ind, :] = p
+                self._lnprob[:, ind] = lnprob
+                if blobs is not None:
+                    self._blobs.append(list(blobs))
+            if blobs is not None:
+                yield p, lnprob, self.random_state, blobs
+            else:
+                yield p, lnprob, self.random_state
+
+    def run_mcmc(self, pos0, N, rstate0=None, lnprob0=None, **kwargs):
+        if pos0 is None:
+            if self._last_run_mcmc_result is None:
+                raise ValueError('Cannot have pos0=None if run_mcmc has never been called.')
+            pos0, lnprob0, rstate0 = self._last_run_mcmc_result[:3]
+        results = None
+        for results in self.sample(pos0, lnprob0, rstate0, iterations=N, **kwargs):
+            pass
+        self._last_run_mcmc_result = results[:3] if results is not None else None
+        return results

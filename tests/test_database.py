@@ -1,0 +1,36 @@
+"""Trace database round trip and walker filtering (CPU)."""
+import numpy as np
+
+import helpers
+from psfmc_amd.database import save_database, load_database, filter_lowp_walkers, get_sampler_state
+
+
+class FakeSampler(object):
+    def __init__(self, n_w, n_it, dim, seed=0):
+        rng = np.random.RandomState(seed)
+        self.chain = rng.normal(size=(n_w, n_it, dim))
+        self.lnprobability = -np.sum(self.chain ** 2, axis=2)
+
+
+def test_save_load_roundtrip(tmp_path):
+    case = helpers.load_case('synth128x2')
+    model = helpers.build_model('synth128x2', case, tmp_path)
+    sampler = FakeSampler(6, 7, model.num_params)
+    sampler.lnprobability[4] -= 1e3                      # a lost walker
+    path = str(tmp_path / 'run_db.fits')
+    db = save_database(sampler, model, path, meta_dict={'MCITER': 7, 'MCBURN': 3, 'MCCHAINS': 6,
+                                                        'MCCONVRG': False, 'MCACCEPT': 0.31})
+    assert db.colnames == model.param_names + ['lnprobability', 'walker', 'sample']
+    assert len(db) == 42 and db['1_Sersic_xy'].shape == (42, 2)
+    again = load_database(path)
+    theta = again.param_matrix(model.param_names)
+    assert np.array_equal(theta, sampler.chain.reshape(42, -1))
+    assert np.array_equal(again['lnprobability'], sampler.lnprobability.ravel())
+    assert again['walker'].tolist()[:8] == [0] * 7 + [1] and again['sample'].tolist()[:8] == list(range(7)) + [0]
+    best = np.argmax(sampler.lnprobability)
+    assert again.meta['MAPWLKR'] == best // 7 and again.meta['MAPSAMP'] == best % 7
+    assert again.meta['MCBURN'] == 3 and again.meta['MCCONVRG'] is False and again.meta['MCACCEPT'] == 0.31
+    kept = filter_lowp_walkers(again, percentile=20)
+    assert sorted(set(kept['walker'].tolist())) == [0, 1, 2, 3, 5]
+    pos, lnp = get_sampler_state(again)
+    assert np.array_equal(pos, sampler.chain[:, -1]) and np.array_equal(lnp, sampler.lnprobability[:, -1])
