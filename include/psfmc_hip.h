@@ -118,6 +118,19 @@ int psfmc_eval_images(psfmc_ctx* ctx, int W, const double* rows,
                       double* ps_sub);
 
 /*
+ * Posterior-image accumulation on the device (replaces the per-sample blob
+ * hand-over and the running mean of MultiComponentModel.accumulate_images,
+ * models.py:74-97, fed from fitting.py:83).  psfmc_accumulate_images adds the images
+ * of W walkers (rows as above) to device-resident sums; composite_ivm is averaged as
+ * a variance (models.py:81-97).  psfmc_get_accumulated returns the means ([ny][nx]
+ * each, any pointer may be NULL; ivm = 1 / mean variance) and the sample count.
+ */
+int psfmc_accumulate_images(psfmc_ctx* ctx, int W, const double* rows);
+int psfmc_get_accumulated(psfmc_ctx* ctx, double* raw, double* conv, double* resid, double* ivm,
+                          double* ps_sub, long long* count);
+int psfmc_reset_accumulated(psfmc_ctx* ctx);
+
+/*
  * Device-computed PSF spectra, for checking the on-device replacement of
  * pre_fft_psf (utils.py:126-133): out arrays [n_psf][ny][nx/2+1][2] (re, im),
  * equal to numpy.fft.rfft2 of the centre-padded images.

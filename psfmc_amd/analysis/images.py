@@ -60,8 +60,9 @@ def save_posterior_images(model, database, output_name='out_{}', mode='weighted'
             theta = database.param_matrix(names)
             for lo in range(0, total, batch):
                 print_progress(lo, total, 'Creating posterior images')
-                model.accumulate_images(model.sample_images(theta[lo:lo + batch]))
-        out = {k: np.array(model.posterior_images[k]) for k in filetypes}
+                model.accumulate_samples(theta[lo:lo + batch])
+        post = model.collect_posterior_images()
+        out = {k: np.array(post[k]) for k in filetypes}
     else:
         warn('Unknown posterior output mode ({}).'.format(mode))
         return

@@ -115,6 +115,8 @@ struct psfmc_ctx {
     int rg_log2 = 0;          // log2(rows per wave of the row kernels)
     double *d_img0 = nullptr, *d_img1 = nullptr;      // [chunk][S] staging for eval_images
     int img_cap = 0;
+    double* d_acc = nullptr;  // [4][S] sums: raw, conv, model variance, PS-only conv
+    long long acc_count = 0;
     int cols_grid = 0;
 };
 
@@ -486,7 +488,7 @@ extern "C" int psfmc_ctx_destroy(psfmc_ctx* c) {
     }
     void* bufs[] = {c->d_sci,  c->d_var,  c->d_bad,     c->d_pspec, c->d_vspec, c->d_rows, c->d_prep,
                     c->d_like, c->d_skip, c->d_partial, c->d_real,  c->d_spec,  c->d_Ts[0], c->d_Kraw,
-                    c->d_Kt,   c->d_twx,  c->d_twy,     c->d_img0,  c->d_img1, c->d_rho,   c->d_field, c->d_Ts[1],
+                    c->d_Kt,   c->d_twx,  c->d_twy,     c->d_img0,  c->d_img1, c->d_rho,   c->d_field, c->d_Ts[1], c->d_acc,
                     c->d_Ts[2], c->d_Ts[3]};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
@@ -732,6 +734,101 @@ extern "C" int psfmc_eval_images(psfmc_ctx* c, int W, const double* rows, double
     (void)hipStreamSynchronize(st);
     (void)hipFree(d_out);
     if (rc == PSFMC_OK) HIP_TRY(hipGetLastError());
+    return rc;
+}
+
+// ---------------------------------------------------------------------------
+// posterior-image accumulation (models.py:74-97)
+// ---------------------------------------------------------------------------
+extern "C" int psfmc_reset_accumulated(psfmc_ctx* c) {
+    if (!c) return fail(PSFMC_EINVAL, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->d_acc) HIP_TRY(hipMalloc(&c->d_acc, (size_t)4 * c->S * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(c->d_acc, 0, (size_t)4 * c->S * sizeof(double), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->acc_count = 0;
+    return PSFMC_OK;
+}
+
+extern "C" int psfmc_accumulate_images(psfmc_ctx* c, int W, const double* rows) {
+    int rc = check_call(c, W, rows, rows);
+    if (rc != PSFMC_OK || W == 0) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->d_acc) RC_TRY(psfmc_reset_accumulated(c));
+    hipStream_t st = c->stream;
+    const bool fused = c->backend == PSFMC_BACKEND_FUSED;
+    HIP_TRY(hipMemcpyAsync(c->d_rows, rows, (size_t)W * c->rlen * sizeof(double), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_prep, dim3((W + 127) / 128), dim3(128), 0, st, c->d_rows, c->d_prep, W, c->n_ps,
+                       c->n_sersic, c->ny, c->nx, c->d_rho);
+    RC_TRY(ensure_image_staging(c));
+    double* d_raw = nullptr;
+    if (fused) HIP_TRY(hipMalloc(&d_raw, (size_t)c->chunk * c->S * sizeof(double)));
+    const double* conv_src = fused ? c->d_img0 : c->d_real;
+    const double* var_src = fused ? c->d_img1 : c->d_real;
+    const int stride = fused ? 1 : 2, var_c = fused ? 0 : 1;
+    auto acc = [&](const double* src, int strd, int comp, int slot, int n) {
+        hipLaunchKernelGGL(k_accumulate, dim3(256), dim3(256), 0, st, src, c->d_acc + (size_t)slot * c->S,
+                           c->S, n, strd, comp);
+    };
+    for (int w0 = 0; w0 < W && rc == PSFMC_OK; w0 += c->chunk) {
+        const int n = W - w0 < c->chunk ? W - w0 : c->chunk;
+        const double* prep = c->d_prep + (size_t)w0 * c->plen;
+        if (fused) {
+            rc = fused_forward(c, n, c->d_T, prep, nullptr, 0, d_raw, st);
+            if (rc == PSFMC_OK) rc = fused_inverse(c, n, c->d_T, prep, nullptr, c->d_partial, c->d_img0, c->d_img1, st);
+            if (rc != PSFMC_OK) break;
+            acc(d_raw, 1, 0, 0, n);
+        } else {
+            hipLaunchKernelGGL(k_raster, dim3((c->S + 1023) / 1024, n), dim3(256),
+                               (size_t)c->plen * sizeof(double), st, prep, (const uint8_t*)nullptr,
+                               c->d_real, c->n_ps, c->n_sersic, c->ny, c->nx, 0);
+            acc(c->d_real, 2, 0, 0, n);
+            rc = hipfft_convolve(c, n, prep, nullptr, st, 0);
+            if (rc != PSFMC_OK) break;
+        }
+        acc(conv_src, stride, 0, 1, n);
+        acc(var_src, stride, var_c, 2, n);
+        if (fused) {
+            rc = fused_forward(c, n, c->d_T, prep, nullptr, 1, nullptr, st);
+            if (rc == PSFMC_OK) rc = fused_inverse(c, n, c->d_T, prep, nullptr, c->d_partial, c->d_img0, c->d_img1, st);
+        } else {
+            rc = hipfft_convolve(c, n, prep, nullptr, st, 1);
+        }
+        if (rc != PSFMC_OK) break;
+        acc(conv_src, stride, 0, 3, n);
+    }
+    (void)hipStreamSynchronize(st);
+    if (d_raw) (void)hipFree(d_raw);
+    if (rc == PSFMC_OK) {
+        HIP_TRY(hipGetLastError());
+        c->acc_count += W;
+    }
+    return rc;
+}
+
+extern "C" int psfmc_get_accumulated(psfmc_ctx* c, double* raw, double* conv, double* resid, double* ivm,
+                                     double* ps_sub, long long* count) {
+    if (!c) return fail(PSFMC_EINVAL, "ctx is NULL");
+    if (count) *count = c->acc_count;
+    if (c->acc_count == 0 || !c->d_acc) return PSFMC_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    double* d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_out, (size_t)c->S * sizeof(double)));
+    const double inv_n = 1.0 / (double)c->acc_count;
+    struct { double* host; int slot, op; } outs[] = {{raw, 0, 0}, {conv, 1, 0}, {resid, 1, 1},
+                                                     {ivm, 2, 2}, {ps_sub, 3, 1}};
+    int rc = PSFMC_OK;
+    for (auto& o : outs) {
+        if (!o.host) continue;
+        hipLaunchKernelGGL(k_accumulated_out, dim3(256), dim3(256), 0, c->stream,
+                           c->d_acc + (size_t)o.slot * c->S, c->d_sci, c->d_var, d_out, c->S, inv_n, o.op);
+        if (hipMemcpyAsync(o.host, d_out, (size_t)c->S * sizeof(double), hipMemcpyDeviceToHost, c->stream) !=
+                hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+            rc = fail(PSFMC_EHIP, "accumulated image copy failed");
+            break;
+        }
+    }
+    (void)hipFree(d_out);
     return rc;
 }
 

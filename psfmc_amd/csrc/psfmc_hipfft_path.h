@@ -122,4 +122,24 @@ __global__ void k_image_out(const double* __restrict__ real, const double* __res
     }
 }
 
+// acc[i] += sum_w src[(stride*w + c)][i]   (posterior-image sums)
+__global__ void k_accumulate(const double* __restrict__ src, double* __restrict__ acc, int S, int n,
+                             int stride, int c) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < S; i += gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int w = 0; w < n; ++w) s += src[(size_t)(stride * w + c) * S + i];
+        acc[i] += s;
+    }
+}
+
+// means from the sums: op 0 mean, 1 sci - mean, 2 1 / (mean + obs_var)
+__global__ void k_accumulated_out(const double* __restrict__ acc, const double* __restrict__ sci,
+                                  const double* __restrict__ obs_var, double* __restrict__ out, int S,
+                                  double inv_n, int op) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < S; i += gridDim.x * blockDim.x) {
+        const double m = acc[i] * inv_n;
+        out[i] = op == 0 ? m : op == 1 ? sci[i] - m : 1.0 / (m + obs_var[i]);
+    }
+}
+
 }  // namespace psfmc

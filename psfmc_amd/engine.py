@@ -77,6 +77,12 @@ def load_library():
     lib.psfmc_set_option.argtypes = [vp, ctypes.c_char_p, cd]
     lib.psfmc_get_option.restype = cd
     lib.psfmc_get_option.argtypes = [vp, ctypes.c_char_p]
+    lib.psfmc_accumulate_images.restype = ci
+    lib.psfmc_accumulate_images.argtypes = [vp, ci, _c_double_p]
+    lib.psfmc_get_accumulated.restype = ci
+    lib.psfmc_get_accumulated.argtypes = [vp] + [_c_double_p] * 5 + [ctypes.POINTER(ctypes.c_longlong)]
+    lib.psfmc_reset_accumulated.restype = ci
+    lib.psfmc_reset_accumulated.argtypes = [vp]
     lib.psfmc_debug_math.restype = ci
     lib.psfmc_debug_math.argtypes = [ci, ci, ci, _c_double_p, _c_double_p]
     if lib.psfmc_abi_version() != 1:
@@ -213,6 +219,24 @@ class Context(object):
         if n_w:
             self._check(self._lib.psfmc_eval_images(self._ctx, n_w, _dp(rows), *args))
         return bufs
+
+    def accumulate(self, rows):
+        """Add the five images of every row's walker to the device-resident
+        posterior sums."""
+        rows = self._rows(rows)
+        if len(rows):
+            self._check(self._lib.psfmc_accumulate_images(self._ctx, len(rows), _dp(rows)))
+
+    def accumulated(self):
+        """(dict kind -> mean image, sample count) of the device sums."""
+        bufs = {k: np.empty(self.shape, dtype=np.float64) for k in self.IMAGE_KINDS}
+        count = ctypes.c_longlong(0)
+        self._check(self._lib.psfmc_get_accumulated(
+            self._ctx, *[_dp(bufs[k]) for k in self.IMAGE_KINDS], ctypes.byref(count)))
+        return bufs, int(count.value)
+
+    def reset_accumulated(self):
+        self._check(self._lib.psfmc_reset_accumulated(self._ctx))
 
     def spectra(self):
         """(psf_spec, var_spec) complex128 [n_psf, ny, nx//2+1] as computed on

@@ -72,8 +72,8 @@ def model_galaxy_mcmc(model_file, output_name=None, write_fits=default_filetypes
             for step, result in enumerate(sampler.sample(param_vec, lnprob0=lnprob,
                                                          iterations=iterations)):
                 param_vec, lnprob = result[0], result[1]
-                if accumulate:      # images of the walkers' current positions, one batch
-                    mc_model.accumulate_images(mc_model.sample_images(param_vec))
+                if accumulate:      # images of the walkers' current positions, summed on the GPU
+                    mc_model.accumulate_samples(param_vec)
                 sampler.clear_blobs()
                 if not quiet:
                     print_progress(step, iterations, 'Sampling')

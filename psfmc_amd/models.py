@@ -79,6 +79,7 @@ class MultiComponentModel(object):
         self.blob_images = False      # log_posterior() returns image blobs
         self.posterior_images = {}
         self.accumulated_samples = 0
+        self._device_samples = 0
         self.reset_images()
 
     # -- engine --------------------------------------------------------------
@@ -270,13 +271,47 @@ class MultiComponentModel(object):
     def reset_images(self):
         shape = self.config.obs_data.shape
         self.accumulated_samples = 0
+        self._device_samples = 0
+        if self._engine is not None:
+            self._engine.reset_accumulated()
         for kind in IMAGE_KINDS:
             self.posterior_images[kind] = np.ones(shape, dtype=np.float64)
+
+    def accumulate_samples(self, theta):
+        """Add the images of W parameter vectors to the posterior means ON THE
+        DEVICE (no image leaves the GPU until `collect_posterior_images`)."""
+        theta = self._theta(theta)
+        rows = self.derived_rows(theta)
+        for lo in range(0, len(rows), self._max_walkers):
+            self.engine.accumulate(rows[lo:lo + self._max_walkers])
+        self._device_samples += len(rows)
+        self.accumulated_samples += len(rows)
+
+    def collect_posterior_images(self):
+        """Merge the device-resident sums into `posterior_images` (sample-count
+        weighted; the weight map in the variance domain) and return that dict."""
+        if self._device_samples:
+            dev, n_dev = self.engine.accumulated()
+            n_host = self.accumulated_samples - self._device_samples
+            post = self.posterior_images
+            with np.errstate(all='ignore'):
+                for kind in IMAGE_KINDS:
+                    if n_host == 0:
+                        post[kind] = dev[kind]
+                    elif kind == 'composite_ivm':
+                        post[kind] = (n_host + n_dev) / (n_host / post[kind] + n_dev / dev[kind])
+                    else:
+                        post[kind] = (n_host * post[kind] + n_dev * dev[kind]) / (n_host + n_dev)
+            self.engine.reset_accumulated()
+            self._device_samples = 0
+            self._merged_device = True
+        return self.posterior_images
 
     def accumulate_images(self, sample_images):
         """Running mean of the per-sample images; the weight map is averaged
         as a variance (models.py:74-97).  `sample_images`: list of dicts
         {kind: [ny, nx]} (emcee blobs) or one dict {kind: [W, ny, nx]}."""
+        self.collect_posterior_images()
         if isinstance(sample_images, dict):
             n_w = len(next(iter(sample_images.values())))
             sample_images = [{k: v[i] for k, v in sample_images.items()}

@@ -60,3 +60,41 @@ def test_model_galaxy_mcmc_example(tmp_path):
     assert np.array_equal(db3['lnprobability'], db2['lnprobability'])
     model.close()
     model2.close()
+
+
+@pytest.mark.parametrize('backend', ['fused', 'hipfft'])
+def test_device_accumulation_matches_reference_running_mean(tmp_path, backend):
+    """psfmc_accumulate_images vs the reference's running mean (models.py:74-97)
+    restated with numpy on the per-sample images."""
+    case = helpers.load_case('edge')
+    model = helpers.build_model('edge', case, tmp_path, backend=backend, max_walkers=16)
+    ok = np.isfinite(case['lnprob'])
+    theta = case['params'][ok][:40]
+    imgs = model.sample_images(theta)
+    want = {k: np.ones(imgs[k].shape[1:]) for k in imgs}
+    with np.errstate(all='ignore'):
+        want['composite_ivm'] = 1 / want['composite_ivm']
+        for i in range(len(theta)):
+            n = i + 1
+            for k in imgs:
+                step = 1 / imgs[k][i] if k == 'composite_ivm' else imgs[k][i]
+                want[k] = (want[k] * (n - 1) + step) / n
+        want['composite_ivm'] = 1 / want['composite_ivm']
+    model.reset_images()
+    model.accumulate_samples(theta[:13])             # slices larger than max_walkers too
+    model.accumulate_samples(theta[13:])
+    assert model.accumulated_samples == 40
+    got = model.collect_posterior_images()
+    for k in want:
+        fin = np.isfinite(want[k])
+        assert np.array_equal(np.isfinite(got[k]), fin), k
+        assert np.allclose(got[k][fin], want[k][fin], rtol=1e-11, atol=1e-13 * np.abs(want[k][fin]).max()), k
+    # host-side accumulation of blobs keeps working and merges with device sums
+    model.reset_images()
+    model.accumulate_samples(theta[:20])
+    model.accumulate_images({k: v[20:] for k, v in imgs.items()})
+    both = model.collect_posterior_images()
+    for k in want:
+        fin = np.isfinite(want[k])
+        assert np.allclose(both[k][fin], want[k][fin], rtol=1e-11, atol=1e-13 * np.abs(want[k][fin]).max()), k
+    model.close()
