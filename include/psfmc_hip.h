@@ -118,6 +118,42 @@ int psfmc_eval_images(psfmc_ctx* ctx, int W, const double* rows,
                       double* ps_sub);
 
 /*
+ * Raw emcee parameter vectors on the device: with the model's parameter layout and
+ * its priors registered, psfmc_eval_theta computes the complete log-posterior
+ * (models.py:193-243) of W vectors without any host arithmetic -- joint log-prior
+ * (distributions.py:112-127 for the families below, Sersic.py:41-45), early-out,
+ * Sersic kappa = gammaincinv(2n, 1/2) and Sigma_e (Sersic.py:47-71), flux
+ * (utils.py:160-164), ellipse matrix (Sersic.py:80-91), likelihood, NaN -> -inf.
+ *
+ * Slots, in this order: n_sky x [adu] | n_ps x [mag, x, y] | n_sersic x [angle, index,
+ * mag, reff, reff_b, x, y] | [psf_index].  slot_col[i] is the column of the vector that
+ * feeds slot i (packing contract of ComponentBase.py:45-74 / models.py:174-185) or -1
+ * for a constant slot_const[i].
+ * Prior families per vector column: 0 = evaluated by the host (passed per walker in
+ * `extra_lnprior`), 1 uniform(loc=p0, scale=p1), 2 normal(loc=p0, scale=p1),
+ * 3 weibull_min(c=p0, loc=p1, scale=p2), 4 randint(low=p0, high=p1) on the rounded value.
+ */
+#define PSFMC_PRIOR_HOST         0
+#define PSFMC_PRIOR_UNIFORM      1
+#define PSFMC_PRIOR_NORMAL       2
+#define PSFMC_PRIOR_WEIBULL_MIN  3
+#define PSFMC_PRIOR_RANDINT      4
+int psfmc_set_layout(psfmc_ctx* ctx, int n_sky, int n_params, const int* slot_col,
+                     const double* slot_const, const int* ps_method, const int* sersic_degrees,
+                     double mag_zeropoint, const int* family, const double* p0, const double* p1,
+                     const double* p2);
+/* host buffers theta [W][n_params], extra_lnprior [W] or NULL, lnprob [W] */
+int psfmc_eval_theta(psfmc_ctx* ctx, int W, const double* theta, const double* extra_lnprior,
+                     double* lnprob);
+/* device buffers, enqueued on `stream` (NULL = the context's stream), not synchronised */
+int psfmc_eval_theta_device(psfmc_ctx* ctx, int W, const double* d_theta, const double* d_extra_lnprior,
+                            double* d_lnprob, void* stream);
+/* test hook: the derived rows [W][row_len], log-priors [W] and skip flags [W] the device
+ * computes for W vectors */
+int psfmc_debug_theta_rows(psfmc_ctx* ctx, int W, const double* theta, double* rows, double* lnprior,
+                           uint8_t* skip);
+
+/*
  * Posterior-image accumulation on the device (replaces the per-sample blob
  * hand-over and the running mean of MultiComponentModel.accumulate_images,
  * models.py:74-97, fed from fitting.py:83).  psfmc_accumulate_images adds the images

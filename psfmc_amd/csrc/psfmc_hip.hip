@@ -17,6 +17,7 @@
 #include "psfmc_device.h"
 #include "psfmc_hipfft_path.h"
 #include "psfmc_fused_path.h"
+#include "psfmc_theta.h"
 
 using namespace psfmc;
 
@@ -115,6 +116,11 @@ struct psfmc_ctx {
     int rg_log2 = 0;          // log2(rows per wave of the row kernels)
     double *d_img0 = nullptr, *d_img1 = nullptr;      // [chunk][S] staging for eval_images
     int img_cap = 0;
+    // raw-vector path (psfmc_set_layout)
+    bool has_layout = false;
+    ThetaLayout layout{};
+    void* d_layout_blob = nullptr;           // one allocation behind the layout's pointers
+    double *d_theta = nullptr, *d_extra = nullptr, *d_lnprior = nullptr;
     double* d_acc = nullptr;  // [4][S] sums: raw, conv, model variance, PS-only conv
     long long acc_count = 0;
     int cols_grid = 0;
@@ -489,6 +495,7 @@ extern "C" int psfmc_ctx_destroy(psfmc_ctx* c) {
     void* bufs[] = {c->d_sci,  c->d_var,  c->d_bad,     c->d_pspec, c->d_vspec, c->d_rows, c->d_prep,
                     c->d_like, c->d_skip, c->d_partial, c->d_real,  c->d_spec,  c->d_Ts[0], c->d_Kraw,
                     c->d_Kt,   c->d_twx,  c->d_twy,     c->d_img0,  c->d_img1, c->d_rho,   c->d_field, c->d_Ts[1], c->d_acc,
+                    c->d_layout_blob, c->d_theta, c->d_extra, c->d_lnprior,
                     c->d_Ts[2], c->d_Ts[3]};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
@@ -583,10 +590,9 @@ static int hipfft_convolve(psfmc_ctx* c, int n, const double* d_prep, const uint
     return PSFMC_OK;
 }
 
-static int eval_device(psfmc_ctx* c, int W, const double* d_rows, const uint8_t* d_skip,
-                       double* d_like, hipStream_t st) {
-    hipLaunchKernelGGL(k_prep, dim3((W + 127) / 128), dim3(128), 0, st, d_rows, c->d_prep, W, c->n_ps,
-                       c->n_sersic, c->ny, c->nx, c->d_rho);
+// the likelihood pipeline over walkers whose prep records are in c->d_prep;
+// leaves the chi^2 partial sums in c->d_partial
+static int run_pipeline(psfmc_ctx* c, int W, const uint8_t* d_skip, hipStream_t st) {
     const bool fused = c->backend == PSFMC_BACKEND_FUSED;
     // Fused path: pass i runs on stream i % n_streams with its own T buffer, so the
     // VALU-bound row kernels of one pass overlap the HBM-bound column kernel of its
@@ -619,8 +625,28 @@ static int eval_device(psfmc_ctx* c, int W, const double* d_rows, const uint8_t*
         HIP_TRY(hipEventRecord(c->ev_join[i], c->side[i]));
         HIP_TRY(hipStreamWaitEvent(st, c->ev_join[i], 0));
     }
+    return PSFMC_OK;
+}
+
+static int eval_device(psfmc_ctx* c, int W, const double* d_rows, const uint8_t* d_skip,
+                       double* d_like, hipStream_t st) {
+    hipLaunchKernelGGL(k_prep, dim3((W + 127) / 128), dim3(128), 0, st, d_rows, c->d_prep, W, c->n_ps,
+                       c->n_sersic, c->ny, c->nx, c->d_rho);
+    RC_TRY(run_pipeline(c, W, d_skip, st));
     hipLaunchKernelGGL(k_finish, dim3((W + 127) / 128), dim3(128), 0, st, c->d_partial, d_skip, d_like,
                        W, c->nblk);
+    HIP_TRY(hipGetLastError());
+    return PSFMC_OK;
+}
+
+// raw vectors -> log-posterior, everything on the device
+static int eval_theta_device(psfmc_ctx* c, int W, const double* d_theta, const double* d_extra,
+                             double* d_lnprob, hipStream_t st) {
+    hipLaunchKernelGGL(k_theta_prep, dim3((W + 63) / 64), dim3(64), 0, st, c->layout, d_theta, d_extra,
+                       c->d_rows, c->d_prep, c->d_lnprior, c->d_skip, W, c->ny, c->nx, c->d_rho);
+    RC_TRY(run_pipeline(c, W, c->d_skip, st));
+    hipLaunchKernelGGL(k_finish_posterior, dim3((W + 127) / 128), dim3(128), 0, st, c->d_partial, c->d_skip,
+                       c->d_lnprior, d_lnprob, W, c->nblk);
     HIP_TRY(hipGetLastError());
     return PSFMC_OK;
 }
@@ -735,6 +761,115 @@ extern "C" int psfmc_eval_images(psfmc_ctx* c, int W, const double* rows, double
     (void)hipFree(d_out);
     if (rc == PSFMC_OK) HIP_TRY(hipGetLastError());
     return rc;
+}
+
+// ---------------------------------------------------------------------------
+// raw-vector path
+// ---------------------------------------------------------------------------
+extern "C" int psfmc_set_layout(psfmc_ctx* c, int n_sky, int n_params, const int* slot_col,
+                                const double* slot_const, const int* ps_method, const int* sersic_degrees,
+                                double mag_zeropoint, const int* family, const double* p0,
+                                const double* p1, const double* p2) {
+    if (!c) return fail(PSFMC_EINVAL, "ctx is NULL");
+    if (n_sky < 0 || n_sky > 16 || n_params < 0 || n_params > 4096) return fail(PSFMC_EINVAL, "bad counts");
+    const int ns = n_slots(n_sky, c->n_ps, c->n_sersic);
+    if (!slot_col || !slot_const || (c->n_ps && !ps_method) || (c->n_sersic && !sersic_degrees) ||
+        (n_params && (!family || !p0 || !p1 || !p2)))
+        return fail(PSFMC_EINVAL, "NULL layout array");
+    for (int i = 0; i < ns; ++i)
+        if (slot_col[i] < -1 || slot_col[i] >= n_params)
+            return fail(PSFMC_EINVAL, "slot %d refers to column %d of %d", i, slot_col[i], n_params);
+    for (int i = 0; i < n_params; ++i)
+        if (family[i] < 0 || family[i] > PRIOR_RANDINT)
+            return fail(PSFMC_EINVAL, "unknown prior family %d for column %d", family[i], i);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    // pack everything into one device allocation (8-byte units)
+    const size_t n_int = (size_t)ns + c->n_ps + c->n_sersic + n_params;
+    const size_t n_dbl = (size_t)ns + 3 * (size_t)n_params;
+    const size_t int_bytes = (n_int * sizeof(int) + 7) / 8 * 8;
+    std::vector<unsigned char> blob(int_bytes + n_dbl * sizeof(double));
+    int* ip = reinterpret_cast<int*>(blob.data());
+    double* dp = reinterpret_cast<double*>(blob.data() + int_bytes);
+    memcpy(ip, slot_col, ns * sizeof(int));
+    if (c->n_ps) memcpy(ip + ns, ps_method, c->n_ps * sizeof(int));
+    if (c->n_sersic) memcpy(ip + ns + c->n_ps, sersic_degrees, c->n_sersic * sizeof(int));
+    if (n_params) memcpy(ip + ns + c->n_ps + c->n_sersic, family, n_params * sizeof(int));
+    memcpy(dp, slot_const, ns * sizeof(double));
+    if (n_params) {
+        memcpy(dp + ns, p0, n_params * sizeof(double));
+        memcpy(dp + ns + n_params, p1, n_params * sizeof(double));
+        memcpy(dp + ns + 2 * n_params, p2, n_params * sizeof(double));
+    }
+    if (c->d_layout_blob) { (void)hipFree(c->d_layout_blob); c->d_layout_blob = nullptr; }
+    HIP_TRY(hipMalloc(&c->d_layout_blob, blob.size()));
+    HIP_TRY(hipMemcpy(c->d_layout_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    const int* dip = reinterpret_cast<const int*>(c->d_layout_blob);
+    const double* ddp = reinterpret_cast<const double*>(static_cast<unsigned char*>(c->d_layout_blob) + int_bytes);
+    ThetaLayout& L = c->layout;
+    L.n_sky = n_sky; L.n_ps = c->n_ps; L.n_sersic = c->n_sersic; L.n_params = n_params; L.n_psf = c->n_psf;
+    L.mag_zp = mag_zeropoint;
+    L.slot_col = dip; L.ps_method = dip + ns; L.sersic_deg = dip + ns + c->n_ps;
+    L.family = dip + ns + c->n_ps + c->n_sersic;
+    L.slot_const = ddp; L.pa = ddp + ns; L.pb = ddp + ns + n_params; L.pc = ddp + ns + 2 * n_params;
+    for (double** p : {&c->d_theta, &c->d_extra, &c->d_lnprior})
+        if (*p) { (void)hipFree(*p); *p = nullptr; }
+    HIP_TRY(hipMalloc(&c->d_theta, (size_t)c->max_walkers * (n_params > 0 ? n_params : 1) * sizeof(double)));
+    HIP_TRY(hipMalloc(&c->d_extra, (size_t)c->max_walkers * sizeof(double)));
+    HIP_TRY(hipMalloc(&c->d_lnprior, (size_t)c->max_walkers * sizeof(double)));
+    c->has_layout = true;
+    return PSFMC_OK;
+}
+
+static int check_theta_call(psfmc_ctx* c, int W, const void* theta, const void* out) {
+    RC_TRY(check_call(c, W, theta ? theta : out, out));
+    if (!c->has_layout) return fail(PSFMC_EINVAL, "psfmc_set_layout has not been called");
+    if (W > 0 && c->layout.n_params > 0 && !theta) return fail(PSFMC_EINVAL, "NULL theta");
+    return PSFMC_OK;
+}
+
+extern "C" int psfmc_eval_theta_device(psfmc_ctx* c, int W, const double* d_theta, const double* d_extra,
+                                       double* d_lnprob, void* stream) {
+    int rc = check_theta_call(c, W, d_theta, d_lnprob);
+    if (rc != PSFMC_OK || W == 0) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    return eval_theta_device(c, W, d_theta, d_extra, d_lnprob, stream ? (hipStream_t)stream : c->stream);
+}
+
+extern "C" int psfmc_eval_theta(psfmc_ctx* c, int W, const double* theta, const double* extra,
+                                double* lnprob) {
+    int rc = check_theta_call(c, W, theta, lnprob);
+    if (rc != PSFMC_OK || W == 0) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    if (c->layout.n_params)
+        HIP_TRY(hipMemcpyAsync(c->d_theta, theta, (size_t)W * c->layout.n_params * sizeof(double),
+                               hipMemcpyHostToDevice, st));
+    if (extra) HIP_TRY(hipMemcpyAsync(c->d_extra, extra, (size_t)W * sizeof(double), hipMemcpyHostToDevice, st));
+    RC_TRY(eval_theta_device(c, W, c->d_theta, extra ? c->d_extra : nullptr, c->d_like, st));
+    HIP_TRY(hipMemcpyAsync(lnprob, c->d_like, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return PSFMC_OK;
+}
+
+extern "C" int psfmc_debug_theta_rows(psfmc_ctx* c, int W, const double* theta, double* rows,
+                                      double* lnprior, uint8_t* skip) {
+    int rc = check_theta_call(c, W, theta, rows);
+    if (rc != PSFMC_OK || W == 0) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    if (c->layout.n_params)
+        HIP_TRY(hipMemcpyAsync(c->d_theta, theta, (size_t)W * c->layout.n_params * sizeof(double),
+                               hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(c->d_rows, 0, (size_t)W * c->rlen * sizeof(double), st));
+    hipLaunchKernelGGL(k_theta_prep, dim3((W + 63) / 64), dim3(64), 0, st, c->layout, c->d_theta,
+                       (const double*)nullptr, c->d_rows, c->d_prep, c->d_lnprior, c->d_skip, W, c->ny,
+                       c->nx, c->d_rho);
+    HIP_TRY(hipMemcpyAsync(rows, c->d_rows, (size_t)W * c->rlen * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (lnprior) HIP_TRY(hipMemcpyAsync(lnprior, c->d_lnprior, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (skip) HIP_TRY(hipMemcpyAsync(skip, c->d_skip, (size_t)W, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return PSFMC_OK;
 }
 
 // ---------------------------------------------------------------------------

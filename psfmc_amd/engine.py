@@ -77,6 +77,16 @@ def load_library():
     lib.psfmc_set_option.argtypes = [vp, ctypes.c_char_p, cd]
     lib.psfmc_get_option.restype = cd
     lib.psfmc_get_option.argtypes = [vp, ctypes.c_char_p]
+    ip = ctypes.POINTER(ctypes.c_int)
+    lib.psfmc_set_layout.restype = ci
+    lib.psfmc_set_layout.argtypes = [vp, ci, ci, ip, _c_double_p, ip, ip, cd, ip, _c_double_p,
+                                     _c_double_p, _c_double_p]
+    lib.psfmc_eval_theta.restype = ci
+    lib.psfmc_eval_theta.argtypes = [vp, ci, _c_double_p, _c_double_p, _c_double_p]
+    lib.psfmc_eval_theta_device.restype = ci
+    lib.psfmc_eval_theta_device.argtypes = [vp, ci, vp, vp, vp, vp]
+    lib.psfmc_debug_theta_rows.restype = ci
+    lib.psfmc_debug_theta_rows.argtypes = [vp, ci, _c_double_p, _c_double_p, _c_double_p, _c_u8_p]
     lib.psfmc_accumulate_images.restype = ci
     lib.psfmc_accumulate_images.argtypes = [vp, ci, _c_double_p]
     lib.psfmc_get_accumulated.restype = ci
@@ -219,6 +229,61 @@ class Context(object):
         if n_w:
             self._check(self._lib.psfmc_eval_images(self._ctx, n_w, _dp(rows), *args))
         return bufs
+
+    # -- raw emcee vectors (device-side priors and derivation) ---------------
+    def set_layout(self, n_sky, n_params, slot_col, slot_const, ps_method, sersic_degrees,
+                   mag_zeropoint, family, p0, p1, p2):
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        ipt = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+        slot_col, ps_method, sersic_degrees, family = map(i32, (slot_col, ps_method, sersic_degrees,
+                                                                family))
+        slot_const, p0, p1, p2 = map(_f64, (slot_const, p0, p1, p2))
+        self._check(self._lib.psfmc_set_layout(
+            self._ctx, int(n_sky), int(n_params), ipt(slot_col), _dp(slot_const), ipt(ps_method),
+            ipt(sersic_degrees), float(mag_zeropoint), ipt(family), _dp(p0), _dp(p1), _dp(p2)))
+        self.n_params = int(n_params)
+
+    def _theta(self, theta):
+        theta = _f64(theta)
+        if theta.ndim != 2 or theta.shape[1] != self.n_params:
+            raise ValueError('theta must be [W, {}], got {}'.format(self.n_params, theta.shape))
+        if theta.shape[0] > self.max_walkers:
+            raise ValueError('W={} exceeds max_walkers={}'.format(theta.shape[0], self.max_walkers))
+        return theta
+
+    def logpost_theta(self, theta, extra_lnprior=None):
+        """[W, P] raw parameter vectors -> [W] log-posteriors, all on the device
+        (never NaN; outside the priors or non-finite likelihood -> -inf)."""
+        theta = self._theta(theta)
+        n_w = theta.shape[0]
+        out = np.empty(n_w)
+        if n_w == 0:
+            return out
+        extra = None
+        if extra_lnprior is not None:
+            extra = _f64(extra_lnprior)
+            if extra.shape != (n_w,):
+                raise ValueError('extra_lnprior must be [W]')
+        self._check(self._lib.psfmc_eval_theta(self._ctx, n_w, _dp(theta),
+                                               _dp(extra) if extra is not None else None, _dp(out)))
+        return out
+
+    def logpost_theta_device(self, n_w, d_theta, d_extra, d_out, stream=None):
+        self._check(self._lib.psfmc_eval_theta_device(
+            self._ctx, int(n_w), ctypes.c_void_p(d_theta), ctypes.c_void_p(d_extra) if d_extra else None,
+            ctypes.c_void_p(d_out), ctypes.c_void_p(stream) if stream else None))
+
+    def debug_theta_rows(self, theta):
+        """(rows [W, row_len], lnprior [W], skip [W]) as derived on the device."""
+        theta = self._theta(theta)
+        n_w = theta.shape[0]
+        rows = np.zeros((n_w, self.row_len))
+        lnprior = np.zeros(n_w)
+        skip = np.zeros(n_w, dtype=np.uint8)
+        if n_w:
+            self._check(self._lib.psfmc_debug_theta_rows(self._ctx, n_w, _dp(theta), _dp(rows),
+                                                         _dp(lnprior), skip.ctypes.data_as(_c_u8_p)))
+        return rows, lnprior, skip.astype(bool)
 
     def accumulate(self, rows):
         """Add the five images of every row's walker to the device-resident

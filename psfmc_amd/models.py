@@ -21,6 +21,31 @@ from . import engine
 IMAGE_KINDS = engine.Context.IMAGE_KINDS
 
 
+def _device_prior(prior, width):
+    """(family, p0, p1, p2) if the library evaluates this prior itself
+    (include/psfmc_hip.h PSFMC_PRIOR_*), else None."""
+    rv = getattr(prior, 'rv_frozen', None)
+    if rv is None:
+        return None
+    try:
+        shapes, loc, scale = rv.dist._parse_args(*rv.args, **rv.kwds)
+    except Exception:
+        return None
+    name = rv.dist.name
+    ok_size = all(np.size(v) in (1, width) for v in (loc, scale) + tuple(shapes))
+    if not ok_size:
+        return None
+    if name == 'uniform':
+        return 1, loc, scale, 0.0
+    if name == 'norm':
+        return 2, loc, scale, 0.0
+    if name == 'weibull_min':
+        return 3, shapes[0], loc, scale
+    if name == 'randint' and np.all(np.asarray(loc) == 0):
+        return 4, shapes[0], shapes[1], 0.0
+    return None
+
+
 class MultiComponentModel(object):
     """A 2-D surface-brightness model made of components (Sky, PointSource,
     Sersic) plus one Configuration, given as a model file or a list
@@ -93,7 +118,64 @@ class MultiComponentModel(object):
                 n_ps=len(self._ps), n_sersic=len(self._sersic),
                 max_walkers=self._max_walkers, device=self._device,
                 backend=self._backend)
+            self._register_layout(self._engine)
         return self._engine
+
+    def _register_layout(self, eng):
+        """Hand the parameter layout and the priors to the library so that raw
+        emcee vectors can be evaluated without host arithmetic.  Priors of
+        families the library does not know stay on the host (`_host_priors`)."""
+        col_of = {}                                   # (component id, attr, element) -> column
+        family = np.zeros(self.num_params, dtype=np.int32)
+        p0, p1, p2 = (np.zeros(self.num_params) for _ in range(3))
+        self._host_priors = []                        # (prior, column slice)
+        for comp, span in zip(self.components, self._spans):
+            pos = span.start
+            for name, width in zip(comp.free_names(), comp.stochastic_lens()):
+                prior = comp._priors[name]
+                desc = _device_prior(prior, width)
+                if desc is None:
+                    self._host_priors.append((prior, slice(pos, pos + width)))
+                for j in range(width):
+                    col_of[(id(comp), name, j)] = pos + j
+                    if desc is not None:
+                        family[pos + j] = desc[0]
+                        p0[pos + j], p1[pos + j], p2[pos + j] = (np.ravel(v)[j if np.size(v) > 1 else 0]
+                                                                 for v in desc[1:])
+                pos += width
+        slot_col, slot_const = [], []
+
+        def add(comp, name, elem=0):
+            key = (id(comp), name, elem)
+            if key in col_of:
+                slot_col.append(col_of[key])
+                slot_const.append(0.0)
+            else:
+                slot_col.append(-1)
+                slot_const.append(float(np.ravel(comp._constants[name])[elem]))
+        for c in self._sky:
+            add(c, 'adu')
+        for c in self._ps:
+            add(c, 'mag'); add(c, 'xy', 0); add(c, 'xy', 1)
+        for c in self._sersic:
+            for name in ('angle', 'index', 'mag', 'reff', 'reff_b'):
+                add(c, name)
+            add(c, 'xy', 0); add(c, 'xy', 1)
+        add(self.config.psf_selector, 'psf_index')
+        eng.set_layout(len(self._sky), self.num_params, slot_col, slot_const,
+                       [SHIFT_METHODS[c.shift_method] for c in self._ps],
+                       [int(bool(c.angle_degrees)) for c in self._sersic],
+                       self.config.mag_zeropoint, family, p0, p1, p2)
+
+    def _host_prior_sum(self, theta):
+        """log-prior of the priors the library leaves to the host, or None."""
+        if not self._host_priors:
+            return None
+        total = np.zeros(theta.shape[0])
+        with np.errstate(all='ignore'):
+            for prior, cols in self._host_priors:
+                total = total + prior.logp_batch(theta[:, cols])
+        return total
 
     def close(self):
         if self._engine is not None:
@@ -216,8 +298,22 @@ class MultiComponentModel(object):
         return np.where(np.isfinite(ll), ll, -np.inf)
 
     def log_posterior_batch(self, theta):
-        """log-posterior of W parameter vectors in one GPU batch.  Walkers
-        whose prior is not finite are not evaluated (models.py:208-211)."""
+        """log-posterior of W parameter vectors in one GPU batch: priors with the
+        non-finite early-out (models.py:208-211), Sersic constants and likelihood
+        all on the device; only priors of families the library does not know are
+        evaluated here with scipy and passed along per walker."""
+        theta = self._theta(theta)
+        eng = self.engine
+        extra = self._host_prior_sum(theta)
+        cap = self._max_walkers
+        parts = [eng.logpost_theta(theta[lo:lo + cap], None if extra is None else extra[lo:lo + cap])
+                 for lo in range(0, theta.shape[0], cap)]
+        return np.concatenate(parts) if parts else np.zeros(0)
+
+    def log_posterior_batch_host(self, theta):
+        """The same through host-side priors and derived rows (scipy.stats /
+        scipy.special exactly as the reference calls them); the device only runs the
+        likelihood.  Kept as the cross-check of the raw-vector path."""
         theta = self._theta(theta)
         lnprior = self.log_priors_batch(theta)
         skip = ~np.isfinite(lnprior)

@@ -139,3 +139,35 @@ def test_rectangular_and_small_sizes_fused():
                       index=2.2, angle=0.7, angle_degrees=False)]
         want = orc.log_likelihood(field, comps, raw_dtype=np.float64)
         assert abs(vals['fused'][0] - want) <= 1e-11 * abs(want), (ny, nx)
+
+
+@pytest.mark.parametrize('backend', ['fused', 'hipfft'])
+def test_degenerate_component_sets(backend):
+    """Models with no point source / no Sersic / nothing but sky, W = 1, all-skipped batches."""
+    from psfmc_amd import MultiComponentModel
+    from psfmc_amd.ModelComponents import Configuration, Sky, PointSource, Sersic
+    from psfmc_amd.distributions import Uniform
+    fld = synth_field.make_field(128, 1, seed=2)
+    field = orc.make_field(fld['sci'], fld['ivm'], [fld['psf']], [fld['psf_ivm']], mag_zp=25.0)
+    sets = {
+        'sky': ([Sky(adu=0.02)], [dict(type='sky', adu=0.02)]),
+        'sersic': ([Sersic(xy=(60.2, 66.9), mag=19.5, reff=7.0, reff_b=4.0, index=1.3, angle=20.0,
+                           angle_degrees=True)],
+                   [dict(type='sersic', xy=(60.2, 66.9), mag=19.5, reff=7.0, reff_b=4.0, index=1.3,
+                         angle=20.0, angle_degrees=True)]),
+        'ps3': ([PointSource(xy=(10.5 + 30 * k, 100.25 - 20 * k), mag=18.0 + k) for k in range(3)],
+                [dict(type='ps', xy=(10.5 + 30 * k, 100.25 - 20 * k), mag=18.0 + k) for k in range(3)]),
+    }
+    for name, (comps, ocomps) in sets.items():
+        cfg = Configuration(fld['sci'], fld['ivm'], fld['psf'], fld['psf_ivm'], mag_zeropoint=25.0)
+        model = MultiComponentModel([cfg] + comps, backend=backend, max_walkers=4)
+        got = model.log_likelihood_batch(np.zeros((1, 0)))
+        want = orc.log_likelihood(field, ocomps, raw_dtype=np.float64)
+        assert got.shape == (1,) and abs(got[0] - want) <= 1e-11 * abs(want), name
+        model.close()
+    # a free-parameter model where every walker is outside the prior support
+    cfg = Configuration(fld['sci'], fld['ivm'], fld['psf'], fld['psf_ivm'], mag_zeropoint=25.0)
+    model = MultiComponentModel([cfg, Sky(adu=Uniform(loc=0, scale=1))], backend=backend, max_walkers=4)
+    assert np.all(model.log_posterior_batch(np.array([[2.0], [-1.0], [5.0]])) == -np.inf)
+    assert np.isfinite(model.log_posterior_batch(np.array([[0.5]]))).all()
+    model.close()

@@ -183,3 +183,67 @@ def test_device_math():
     assert np.max(np.abs(engine.debug_math('rcp', z) * z - 1.0)) <= 4e-16
     assert np.max(np.abs(engine.debug_math('rsqrt', z) * np.sqrt(z) - 1.0)) <= 6e-16
     assert np.isnan(engine.debug_math('rcp', np.array([0.0]))[0] * 0.0)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_device_derivation_and_priors_match_host(models, name):
+    """Raw-vector path: rows (flux, kappa, Sigma_e, ellipse matrix), log-priors and
+    skip flags computed on the device vs scipy on the host (= the reference's calls)."""
+    case, model = models(name, 'fused')
+    theta = case['params']
+    rows, lnprior, skip = model.engine.debug_theta_rows(theta)
+    want_prior = model.log_priors_batch(theta)
+    assert np.array_equal(skip, ~np.isfinite(want_prior))
+    assert helpers.rel_err(np.where(skip, -np.inf, lnprior), np.where(skip, -np.inf, want_prior)) <= 1e-13
+    ok = ~skip
+    want_rows = model.derived_rows(theta[ok])
+    err = np.abs(rows[ok] - want_rows) / np.maximum(np.abs(want_rows), 1e-300)
+    assert err.max() <= 5e-14, err.max()
+    # and the full posterior through both routes
+    dev = model.log_posterior_batch(theta)
+    host = model.log_posterior_batch_host(theta)
+    cond = helpers.well_conditioned(name, len(theta))
+    assert helpers.rel_err(dev[cond], host[cond]) <= 1e-11
+    assert helpers.rel_err(dev[~cond], host[~cond]) <= 1e-5
+
+
+def test_device_kappa_over_the_index_range(tmp_path):
+    """kappa = gammaincinv(2n, 1/2) on the device vs scipy, n from 0.05 to 60."""
+    from scipy.special import gammaincinv, gamma
+    from psfmc_amd import MultiComponentModel
+    from psfmc_amd.ModelComponents import Configuration, Sersic
+    from psfmc_amd.distributions import Uniform
+    case = helpers.load_case('synth128x2')
+    cfg = Configuration(case['sci'], case['ivm'], case['psfs'][0], case['psf_ivms'][0], mag_zeropoint=25.0)
+    model = MultiComponentModel([cfg, Sersic(xy=(64.2, 63.1), mag=20.0, reff=8.0, reff_b=5.0,
+                                             index=Uniform(loc=0.01, scale=100.0), angle=0.3)],
+                                max_walkers=512)
+    n = np.concatenate([np.linspace(0.05, 1.0, 96), np.linspace(1.0, 12.0, 256), np.linspace(12, 60, 100)])
+    rows, _, skip = model.engine.debug_theta_rows(n[:, None])
+    assert not skip.any()
+    kap = gammaincinv(2 * n, 0.5)
+    assert np.max(np.abs(rows[:, 7] - kap) / kap) <= 2e-14
+    flux = 10 ** (-0.4 * (20.0 - 25.0))
+    sbe = flux / (np.pi * 8.0 * 5.0 * 2 * n * np.exp(kap + np.log(kap) * -2 * n) * gamma(2 * n))
+    assert np.max(np.abs(rows[:, 9] - sbe) / sbe) <= 2e-12
+    model.close()
+
+
+def test_host_only_prior_families_are_combined(tmp_path):
+    """A prior family the library does not evaluate (here a Gamma distribution) stays
+    on the host and is added per walker."""
+    from psfmc_amd import MultiComponentModel
+    from psfmc_amd.ModelComponents import Configuration, Sersic, Sky
+    from psfmc_amd.distributions import Gamma, Normal
+    case = helpers.load_case('synth128x2')
+    cfg = Configuration(case['sci'], case['ivm'], case['psfs'][0], case['psf_ivms'][0], mag_zeropoint=25.0)
+    model = MultiComponentModel([cfg, Sky(adu=Normal(loc=0, scale=0.02)),
+                                 Sersic(xy=(64.2, 63.1), mag=20.0, reff=8.0, reff_b=5.0,
+                                        index=Gamma(2.0, scale=1.5), angle=0.3)], max_walkers=8)
+    model.engine                                     # context + layout are created on first use
+    assert len(model._host_priors) == 1
+    theta = np.array([[0.01, 2.0], [-0.02, 0.7], [0.0, -1.0]])
+    dev = model.log_posterior_batch(theta)
+    host = model.log_posterior_batch_host(theta)
+    assert dev[2] == -np.inf and helpers.rel_err(dev, host) <= 1e-12
+    model.close()
