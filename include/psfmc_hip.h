@@ -154,6 +154,27 @@ int psfmc_debug_theta_rows(psfmc_ctx* ctx, int W, const double* theta, double* r
                            uint8_t* skip);
 
 /*
+ * Stretch-move ensemble sampling with the walkers resident on the device: n_iter
+ * iterations of the two half-ensemble proposals of emcee 2.2.1's EnsembleSampler
+ * (the sampler the reference drives, psfMC/fitting.py:56-86; algorithm restated in
+ * SURVEY.md Appendix A).  The caller supplies the random numbers in emcee's draw order
+ * (per half-step: z, partner index, ln u), so a run reproduces the host-side sampler;
+ * nothing is copied to the host between iterations.  Needs psfmc_set_layout with every
+ * prior on the device (no PSFMC_PRIOR_HOST column).
+ *   pos [W][P], lnprob [W]      in/out (host); lnprob is computed first if !lnprob_valid
+ *   lz, log_u [n_iter][2][W/2]  (P-1) ln z and ln u;  z [n_iter][2][W/2]
+ *   partner [n_iter][2][W/2]    index into the complementary half-ensemble
+ *   chain [W][n_iter][P], lnprob_chain [W][n_iter]   outputs (host, may be NULL)
+ *   naccepted [W]               in/out acceptance counters
+ *   accumulate                  nonzero: after every iteration add the images of all W
+ *                               positions to the posterior sums (psfmc_accumulate_images)
+ */
+int psfmc_stretch_run(psfmc_ctx* ctx, int W, int n_iter, double* pos, double* lnprob,
+                      int lnprob_valid, const double* z, const double* lz, const int* partner,
+                      const double* log_u, double* chain, double* lnprob_chain,
+                      long long* naccepted, int accumulate);
+
+/*
  * Posterior-image accumulation on the device (replaces the per-sample blob
  * hand-over and the running mean of MultiComponentModel.accumulate_images,
  * models.py:74-97, fed from fitting.py:83).  psfmc_accumulate_images adds the images

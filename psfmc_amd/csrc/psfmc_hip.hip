@@ -122,6 +122,7 @@ struct psfmc_ctx {
     void* d_layout_blob = nullptr;           // one allocation behind the layout's pointers
     double *d_theta = nullptr, *d_extra = nullptr, *d_lnprior = nullptr;
     double* d_acc = nullptr;  // [4][S] sums: raw, conv, model variance, PS-only conv
+    double* d_rawstage = nullptr;   // [img_cap][S] raw-model staging for the sums
     long long acc_count = 0;
     int cols_grid = 0;
 };
@@ -495,7 +496,7 @@ extern "C" int psfmc_ctx_destroy(psfmc_ctx* c) {
     void* bufs[] = {c->d_sci,  c->d_var,  c->d_bad,     c->d_pspec, c->d_vspec, c->d_rows, c->d_prep,
                     c->d_like, c->d_skip, c->d_partial, c->d_real,  c->d_spec,  c->d_Ts[0], c->d_Kraw,
                     c->d_Kt,   c->d_twx,  c->d_twy,     c->d_img0,  c->d_img1, c->d_rho,   c->d_field, c->d_Ts[1], c->d_acc,
-                    c->d_layout_blob, c->d_theta, c->d_extra, c->d_lnprior,
+                    c->d_layout_blob, c->d_theta, c->d_extra, c->d_lnprior, c->d_rawstage,
                     c->d_Ts[2], c->d_Ts[3]};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
@@ -524,6 +525,7 @@ extern "C" int psfmc_set_option(psfmc_ctx* c, const char* key, double value) {
         c->chunk = v;
         if (c->d_img0) { (void)hipFree(c->d_img0); c->d_img0 = nullptr; }
         if (c->d_img1) { (void)hipFree(c->d_img1); c->d_img1 = nullptr; }
+        if (c->d_rawstage) { (void)hipFree(c->d_rawstage); c->d_rawstage = nullptr; }
         c->img_cap = 0;
         return alloc_work(c);
     }
@@ -689,6 +691,7 @@ static int ensure_image_staging(psfmc_ctx* c) {
     if (c->img_cap >= c->chunk) return PSFMC_OK;
     if (c->d_img0) { (void)hipFree(c->d_img0); c->d_img0 = nullptr; }
     if (c->d_img1) { (void)hipFree(c->d_img1); c->d_img1 = nullptr; }
+    if (c->d_rawstage) { (void)hipFree(c->d_rawstage); c->d_rawstage = nullptr; }
     c->img_cap = 0;
     HIP_TRY(hipMalloc(&c->d_img0, (size_t)c->chunk * c->S * sizeof(double)));
     HIP_TRY(hipMalloc(&c->d_img1, (size_t)c->chunk * c->S * sizeof(double)));
@@ -885,19 +888,11 @@ extern "C" int psfmc_reset_accumulated(psfmc_ctx* c) {
     return PSFMC_OK;
 }
 
-extern "C" int psfmc_accumulate_images(psfmc_ctx* c, int W, const double* rows) {
-    int rc = check_call(c, W, rows, rows);
-    if (rc != PSFMC_OK || W == 0) return rc;
-    HIP_TRY(hipSetDevice(c->device));
-    if (!c->d_acc) RC_TRY(psfmc_reset_accumulated(c));
-    hipStream_t st = c->stream;
+// add the images of the W walkers whose prep records are in c->d_prep to the sums
+static int accumulate_from_prep(psfmc_ctx* c, int W, hipStream_t st) {
     const bool fused = c->backend == PSFMC_BACKEND_FUSED;
-    HIP_TRY(hipMemcpyAsync(c->d_rows, rows, (size_t)W * c->rlen * sizeof(double), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_prep, dim3((W + 127) / 128), dim3(128), 0, st, c->d_rows, c->d_prep, W, c->n_ps,
-                       c->n_sersic, c->ny, c->nx, c->d_rho);
     RC_TRY(ensure_image_staging(c));
-    double* d_raw = nullptr;
-    if (fused) HIP_TRY(hipMalloc(&d_raw, (size_t)c->chunk * c->S * sizeof(double)));
+    if (fused && !c->d_rawstage) HIP_TRY(hipMalloc(&c->d_rawstage, (size_t)c->img_cap * c->S * sizeof(double)));
     const double* conv_src = fused ? c->d_img0 : c->d_real;
     const double* var_src = fused ? c->d_img1 : c->d_real;
     const int stride = fused ? 1 : 2, var_c = fused ? 0 : 1;
@@ -905,39 +900,147 @@ extern "C" int psfmc_accumulate_images(psfmc_ctx* c, int W, const double* rows) 
         hipLaunchKernelGGL(k_accumulate, dim3(256), dim3(256), 0, st, src, c->d_acc + (size_t)slot * c->S,
                            c->S, n, strd, comp);
     };
-    for (int w0 = 0; w0 < W && rc == PSFMC_OK; w0 += c->chunk) {
+    for (int w0 = 0; w0 < W; w0 += c->chunk) {
         const int n = W - w0 < c->chunk ? W - w0 : c->chunk;
         const double* prep = c->d_prep + (size_t)w0 * c->plen;
         if (fused) {
-            rc = fused_forward(c, n, c->d_T, prep, nullptr, 0, d_raw, st);
-            if (rc == PSFMC_OK) rc = fused_inverse(c, n, c->d_T, prep, nullptr, c->d_partial, c->d_img0, c->d_img1, st);
-            if (rc != PSFMC_OK) break;
-            acc(d_raw, 1, 0, 0, n);
+            RC_TRY(fused_forward(c, n, c->d_T, prep, nullptr, 0, c->d_rawstage, st));
+            RC_TRY(fused_inverse(c, n, c->d_T, prep, nullptr, c->d_partial, c->d_img0, c->d_img1, st));
+            acc(c->d_rawstage, 1, 0, 0, n);
         } else {
             hipLaunchKernelGGL(k_raster, dim3((c->S + 1023) / 1024, n), dim3(256),
                                (size_t)c->plen * sizeof(double), st, prep, (const uint8_t*)nullptr,
                                c->d_real, c->n_ps, c->n_sersic, c->ny, c->nx, 0);
             acc(c->d_real, 2, 0, 0, n);
-            rc = hipfft_convolve(c, n, prep, nullptr, st, 0);
-            if (rc != PSFMC_OK) break;
+            RC_TRY(hipfft_convolve(c, n, prep, nullptr, st, 0));
         }
         acc(conv_src, stride, 0, 1, n);
         acc(var_src, stride, var_c, 2, n);
         if (fused) {
-            rc = fused_forward(c, n, c->d_T, prep, nullptr, 1, nullptr, st);
-            if (rc == PSFMC_OK) rc = fused_inverse(c, n, c->d_T, prep, nullptr, c->d_partial, c->d_img0, c->d_img1, st);
+            RC_TRY(fused_forward(c, n, c->d_T, prep, nullptr, 1, nullptr, st));
+            RC_TRY(fused_inverse(c, n, c->d_T, prep, nullptr, c->d_partial, c->d_img0, c->d_img1, st));
         } else {
-            rc = hipfft_convolve(c, n, prep, nullptr, st, 1);
+            RC_TRY(hipfft_convolve(c, n, prep, nullptr, st, 1));
         }
-        if (rc != PSFMC_OK) break;
         acc(conv_src, stride, 0, 3, n);
     }
+    c->acc_count += W;
+    return PSFMC_OK;
+}
+
+extern "C" int psfmc_accumulate_images(psfmc_ctx* c, int W, const double* rows) {
+    int rc = check_call(c, W, rows, rows);
+    if (rc != PSFMC_OK || W == 0) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->d_acc) RC_TRY(psfmc_reset_accumulated(c));
+    hipStream_t st = c->stream;
+    HIP_TRY(hipMemcpyAsync(c->d_rows, rows, (size_t)W * c->rlen * sizeof(double), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_prep, dim3((W + 127) / 128), dim3(128), 0, st, c->d_rows, c->d_prep, W, c->n_ps,
+                       c->n_sersic, c->ny, c->nx, c->d_rho);
+    rc = accumulate_from_prep(c, W, st);
     (void)hipStreamSynchronize(st);
-    if (d_raw) (void)hipFree(d_raw);
-    if (rc == PSFMC_OK) {
-        HIP_TRY(hipGetLastError());
-        c->acc_count += W;
+    if (rc == PSFMC_OK) HIP_TRY(hipGetLastError());
+    return rc;
+}
+
+// ---------------------------------------------------------------------------
+// device-resident stretch-move sampling
+// ---------------------------------------------------------------------------
+extern "C" int psfmc_stretch_run(psfmc_ctx* c, int W, int n_iter, double* pos, double* lnprob,
+                                 int lnprob_valid, const double* z, const double* lz, const int* partner,
+                                 const double* log_u, double* chain, double* lnprob_chain,
+                                 long long* naccepted, int accumulate) {
+    if (!c) return fail(PSFMC_EINVAL, "ctx is NULL");
+    if (!c->has_layout) return fail(PSFMC_EINVAL, "psfmc_set_layout has not been called");
+    if (W < 2 || (W & 1) || W > c->max_walkers) return fail(PSFMC_EINVAL, "W must be even, 2..max_walkers");
+    if (n_iter < 0 || !pos || !lnprob || !naccepted || (n_iter && (!z || !lz || !partner || !log_u)))
+        return fail(PSFMC_EINVAL, "NULL buffer");
+    const int P = c->layout.n_params, half = W / 2;
+    if (P < 1) return fail(PSFMC_EINVAL, "model has no free parameter");
+    {   // every prior must be evaluated on the device
+        std::vector<int> fam(P);
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipMemcpy(fam.data(), c->layout.family, P * sizeof(int), hipMemcpyDeviceToHost));
+        for (int f : fam)
+            if (f == PRIOR_HOST) return fail(PSFMC_EINVAL, "a prior is evaluated on the host; use the host sampler");
     }
+    hipStream_t st = c->stream;
+    const size_t n_rand = (size_t)n_iter * W;
+    double *d_pos = nullptr, *d_lnp = nullptr, *d_q = nullptr, *d_new = nullptr, *d_rand = nullptr;
+    double *d_chain = nullptr, *d_lnchain = nullptr;
+    int* d_partner = nullptr;
+    long long* d_nacc = nullptr;
+    int rc = PSFMC_OK;
+    auto cleanup = [&]() {
+        void* bufs[] = {d_pos, d_lnp, d_q, d_new, d_rand, d_chain, d_lnchain, d_partner, d_nacc};
+        for (void* p : bufs)
+            if (p) (void)hipFree(p);
+    };
+#define SR_TRY(expr)                                                                         \
+    do {                                                                                     \
+        if ((expr) != hipSuccess) {                                                          \
+            rc = fail(PSFMC_EHIP, "%s failed: %s", #expr, hipGetErrorString(hipGetLastError())); \
+            cleanup();                                                                       \
+            return rc;                                                                       \
+        }                                                                                    \
+    } while (0)
+    SR_TRY(hipMalloc(&d_pos, (size_t)W * P * sizeof(double)));
+    SR_TRY(hipMalloc(&d_lnp, (size_t)W * sizeof(double)));
+    SR_TRY(hipMalloc(&d_q, (size_t)half * P * sizeof(double)));
+    SR_TRY(hipMalloc(&d_new, (size_t)half * sizeof(double)));
+    SR_TRY(hipMalloc(&d_nacc, (size_t)W * sizeof(long long)));
+    if (n_rand) {
+        SR_TRY(hipMalloc(&d_rand, 3 * n_rand * sizeof(double)));
+        SR_TRY(hipMalloc(&d_partner, n_rand * sizeof(int)));
+        SR_TRY(hipMemcpyAsync(d_rand, z, n_rand * sizeof(double), hipMemcpyHostToDevice, st));
+        SR_TRY(hipMemcpyAsync(d_rand + n_rand, lz, n_rand * sizeof(double), hipMemcpyHostToDevice, st));
+        SR_TRY(hipMemcpyAsync(d_rand + 2 * n_rand, log_u, n_rand * sizeof(double), hipMemcpyHostToDevice, st));
+        SR_TRY(hipMemcpyAsync(d_partner, partner, n_rand * sizeof(int), hipMemcpyHostToDevice, st));
+    }
+    if (chain && n_iter) SR_TRY(hipMalloc(&d_chain, (size_t)W * n_iter * P * sizeof(double)));
+    if (chain && n_iter) SR_TRY(hipMalloc(&d_lnchain, (size_t)W * n_iter * sizeof(double)));
+    SR_TRY(hipMemcpyAsync(d_pos, pos, (size_t)W * P * sizeof(double), hipMemcpyHostToDevice, st));
+    SR_TRY(hipMemcpyAsync(d_nacc, naccepted, (size_t)W * sizeof(long long), hipMemcpyHostToDevice, st));
+    if (lnprob_valid)
+        SR_TRY(hipMemcpyAsync(d_lnp, lnprob, (size_t)W * sizeof(double), hipMemcpyHostToDevice, st));
+    else
+        rc = eval_theta_device(c, W, d_pos, nullptr, d_lnp, st);
+    if (accumulate && rc == PSFMC_OK && !c->d_acc) rc = psfmc_reset_accumulated(c);
+    for (int it = 0; it < n_iter && rc == PSFMC_OK; ++it) {
+        for (int h = 0; h < 2 && rc == PSFMC_OK; ++h) {
+            const size_t off = ((size_t)it * 2 + h) * half;
+            hipLaunchKernelGGL(k_stretch_propose, dim3((half * P + 255) / 256), dim3(256), 0, st, d_pos, d_q,
+                               d_rand + off, d_partner + off, half, h, P);
+            rc = eval_theta_device(c, half, d_q, nullptr, d_new, st);
+            hipLaunchKernelGGL(k_stretch_accept, dim3((half + 127) / 128), dim3(128), 0, st, d_pos, d_lnp, d_q,
+                               d_new, d_rand + n_rand + off, d_rand + 2 * n_rand + off, d_nacc, half, h, P);
+        }
+        if (rc != PSFMC_OK) break;
+        if (d_chain)
+            hipLaunchKernelGGL(k_stretch_store, dim3((W * P + 255) / 256), dim3(256), 0, st, d_pos, d_lnp,
+                               d_chain, d_lnchain, W, P, it, n_iter);
+        if (accumulate) {
+            hipLaunchKernelGGL(k_theta_prep, dim3((W + 63) / 64), dim3(64), 0, st, c->layout, d_pos,
+                               (const double*)nullptr, c->d_rows, c->d_prep, c->d_lnprior, c->d_skip, W,
+                               c->ny, c->nx, c->d_rho);
+            rc = accumulate_from_prep(c, W, st);
+        }
+    }
+    if (rc == PSFMC_OK) {
+        SR_TRY(hipMemcpyAsync(pos, d_pos, (size_t)W * P * sizeof(double), hipMemcpyDeviceToHost, st));
+        SR_TRY(hipMemcpyAsync(lnprob, d_lnp, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, st));
+        SR_TRY(hipMemcpyAsync(naccepted, d_nacc, (size_t)W * sizeof(long long), hipMemcpyDeviceToHost, st));
+        if (d_chain) {
+            SR_TRY(hipMemcpyAsync(chain, d_chain, (size_t)W * n_iter * P * sizeof(double), hipMemcpyDeviceToHost, st));
+            if (lnprob_chain)
+                SR_TRY(hipMemcpyAsync(lnprob_chain, d_lnchain, (size_t)W * n_iter * sizeof(double),
+                                      hipMemcpyDeviceToHost, st));
+        }
+    }
+    SR_TRY(hipStreamSynchronize(st));
+    if (rc == PSFMC_OK && hipGetLastError() != hipSuccess) rc = fail(PSFMC_EHIP, "kernel launch failed");
+    cleanup();
+#undef SR_TRY
     return rc;
 }
 

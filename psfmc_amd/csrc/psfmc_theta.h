@@ -203,4 +203,51 @@ __global__ void k_finish_posterior(const double* __restrict__ partial, const uin
     lnprob[w] = fin ? ll + lnprior[w] : -INFINITY;
 }
 
+// ---------------------------------------------------------------------------
+// stretch move (Goodman & Weare 2010; emcee 2.2.1 `_propose_stretch`)
+// ---------------------------------------------------------------------------
+// q[i] = c[j_i] - z_i (c[j_i] - s_i), s = half `h` of pos, c = the other half.
+// No FMA contraction: the same three roundings as the numpy expression emcee uses.
+__global__ void k_stretch_propose(const double* __restrict__ pos, double* __restrict__ q,
+                                  const double* __restrict__ z, const int* __restrict__ partner,
+                                  int half, int h, int P) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= half * P) return;
+    const int w = i / P, d = i - w * P;
+    const double s = pos[(size_t)(h * half + w) * P + d];
+    const double c = pos[(size_t)((1 - h) * half + partner[w]) * P + d];
+    const double diff = c - s;
+    const double step = z[w] * diff;
+    q[i] = c - step;
+}
+
+// accept where lz + newlnp - lnp > ln u; move the walker, count it
+__global__ void k_stretch_accept(double* __restrict__ pos, double* __restrict__ lnprob,
+                                 const double* __restrict__ q, const double* __restrict__ newlnp,
+                                 const double* __restrict__ lz, const double* __restrict__ log_u,
+                                 long long* __restrict__ nacc, int half, int h, int P) {
+#pragma clang fp contract(off)
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= half) return;
+    const int g = h * half + w;
+    const double diff = (lz[w] + newlnp[w]) - lnprob[g];
+    if (diff > log_u[w]) {
+        for (int d = 0; d < P; ++d) pos[(size_t)g * P + d] = q[(size_t)w * P + d];
+        lnprob[g] = newlnp[w];
+        nacc[g] += 1;
+    }
+}
+
+// chain[w][it][:] = pos[w][:], lnchain[w][it] = lnprob[w]
+__global__ void k_stretch_store(const double* __restrict__ pos, const double* __restrict__ lnprob,
+                                double* __restrict__ chain, double* __restrict__ lnchain, int W, int P,
+                                int it, int n_iter) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W * P) return;
+    const int w = i / P, d = i - w * P;
+    chain[((size_t)w * n_iter + it) * P + d] = pos[i];
+    if (d == 0) lnchain[(size_t)w * n_iter + it] = lnprob[w];
+}
+
 }  // namespace psfmc

@@ -87,6 +87,10 @@ def load_library():
     lib.psfmc_eval_theta_device.argtypes = [vp, ci, vp, vp, vp, vp]
     lib.psfmc_debug_theta_rows.restype = ci
     lib.psfmc_debug_theta_rows.argtypes = [vp, ci, _c_double_p, _c_double_p, _c_double_p, _c_u8_p]
+    lib.psfmc_stretch_run.restype = ci
+    lib.psfmc_stretch_run.argtypes = [vp, ci, ci, _c_double_p, _c_double_p, ci, _c_double_p, _c_double_p,
+                                      ip, _c_double_p, _c_double_p, _c_double_p,
+                                      ctypes.POINTER(ctypes.c_longlong), ci]
     lib.psfmc_accumulate_images.restype = ci
     lib.psfmc_accumulate_images.argtypes = [vp, ci, _c_double_p]
     lib.psfmc_get_accumulated.restype = ci
@@ -284,6 +288,30 @@ class Context(object):
             self._check(self._lib.psfmc_debug_theta_rows(self._ctx, n_w, _dp(theta), _dp(rows),
                                                          _dp(lnprior), skip.ctypes.data_as(_c_u8_p)))
         return rows, lnprior, skip.astype(bool)
+
+    def stretch_run(self, pos, lnprob, z, lz, partner, log_u, naccepted, store=True,
+                    accumulate=False):
+        """Run z.shape[0] stretch-move iterations on the device (include/psfmc_hip.h
+        psfmc_stretch_run).  pos [W,P], lnprob [W] or None, z/lz/log_u/partner
+        [n_iter, 2, W/2], naccepted int64 [W].  Returns (pos, lnprob, chain
+        [W,n_iter,P] | None, lnprob_chain [W,n_iter] | None); naccepted is updated."""
+        pos = np.array(pos, dtype=np.float64, order='C')
+        n_w, n_p = pos.shape
+        n_iter = int(np.shape(z)[0])
+        have = lnprob is not None
+        lnp = np.array(lnprob, dtype=np.float64) if have else np.empty(n_w)
+        z, lz, log_u = (_f64(a).reshape(n_iter, 2, n_w // 2) for a in (z, lz, log_u))
+        partner = np.ascontiguousarray(partner, dtype=np.int32).reshape(n_iter, 2, n_w // 2)
+        if naccepted.dtype != np.int64 or naccepted.shape != (n_w,):
+            raise ValueError('naccepted must be int64 [W]')
+        chain = np.empty((n_w, n_iter, n_p)) if store and n_iter else None
+        lnchain = np.empty((n_w, n_iter)) if store and n_iter else None
+        self._check(self._lib.psfmc_stretch_run(
+            self._ctx, n_w, n_iter, _dp(pos), _dp(lnp), int(have), _dp(z), _dp(lz),
+            partner.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), _dp(log_u),
+            _dp(chain) if chain is not None else None, _dp(lnchain) if lnchain is not None else None,
+            naccepted.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), int(bool(accumulate))))
+        return pos, lnp, chain, lnchain
 
     def accumulate(self, rows):
         """Add the five images of every row's walker to the device-resident

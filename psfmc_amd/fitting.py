@@ -15,7 +15,7 @@ import numpy as np
 from .analysis import check_convergence_autocorr, save_posterior_images, default_filetypes
 from .database import save_database, load_database
 from .models import MultiComponentModel
-from .sampler import EnsembleSampler
+from .sampler import EnsembleSampler, DeviceEnsembleSampler
 from .utils import print_progress
 
 
@@ -44,8 +44,15 @@ def model_galaxy_mcmc(model_file, output_name=None, write_fits=default_filetypes
     if chains > mc_model._max_walkers:
         raise ValueError('model was built for at most {} walkers'.format(mc_model._max_walkers))
 
-    cls = sampler_class or EnsembleSampler
-    if cls is EnsembleSampler:
+    cls = sampler_class
+    if cls is None:           # walkers resident on the GPU whenever every prior can be
+        mc_model.engine
+        cls = EnsembleSampler if mc_model._host_priors else DeviceEnsembleSampler
+    device_acc = False
+    if cls is DeviceEnsembleSampler:
+        sampler = cls(chains, mc_model)
+        device_acc = accumulate
+    elif cls is EnsembleSampler:
         sampler = cls(chains, mc_model.num_params, batch_lnpostfn=mc_model.log_posterior_batch)
     else:                      # a real emcee: batch through its pool hook
         from .batch import BatchLogPosterior
@@ -68,11 +75,13 @@ def model_galaxy_mcmc(model_file, output_name=None, write_fits=default_filetypes
         sampler.reset()
 
         converged = False
+        if device_acc:              # images are summed inside the device sampling loop
+            sampler.accumulate = True
         for sampling_iter in range(max_iterations):
             for step, result in enumerate(sampler.sample(param_vec, lnprob0=lnprob,
                                                          iterations=iterations)):
                 param_vec, lnprob = result[0], result[1]
-                if accumulate:      # images of the walkers' current positions, summed on the GPU
+                if accumulate and not device_acc:   # current positions, summed on the GPU
                     mc_model.accumulate_samples(param_vec)
                 sampler.clear_blobs()
                 if not quiet:

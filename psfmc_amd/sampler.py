@@ -22,7 +22,7 @@ call per walker.
 """
 import numpy as np
 
-__all__ = ['EnsembleSampler', 'AutocorrError', 'integrated_time']
+__all__ = ['EnsembleSampler', 'DeviceEnsembleSampler', 'AutocorrError', 'integrated_time']
 
 
 class AutocorrError(Exception):
@@ -237,3 +237,85 @@ class EnsembleSampler(object):
             pass
         self._last_run_mcmc_result = results[:3] if results is not None else None
         return results
+
+
+class DeviceEnsembleSampler(EnsembleSampler):
+    """The same sampler with the walkers resident on the GPU: proposal, log-posterior
+    (priors included), acceptance and chain storage all run on the device
+    (`psfmc_stretch_run`); the host only draws the random numbers, from the same
+    `RandomState` in the same order as the host loop, so both samplers produce the
+    same chain.  `block` iterations are enqueued per library call (nothing is copied
+    back in between); `sample()` still yields once per iteration.
+
+    Needs a `MultiComponentModel` whose priors all belong to the families the library
+    evaluates (uniform, normal, weibull_min, discrete uniform); otherwise use
+    `EnsembleSampler(batch_lnpostfn=model.log_posterior_batch)`.
+    """
+
+    def __init__(self, nwalkers, model, a=2.0, live_dangerously=False, block=64, accumulate=False):
+        super(DeviceEnsembleSampler, self).__init__(nwalkers, model.num_params, a=a,
+                                                    batch_lnpostfn=model.log_posterior_batch,
+                                                    live_dangerously=live_dangerously)
+        self.model = model
+        self.block = int(block)
+        self.accumulate = bool(accumulate)
+        if nwalkers > model._max_walkers:
+            raise ValueError('model was built for at most {} walkers'.format(model._max_walkers))
+        model.engine                      # context + layout
+        if model._host_priors:
+            raise ValueError('priors {} are evaluated on the host: the device sampler cannot be '
+                             'used'.format([p.name for p, _ in model._host_priors]))
+
+    def _draw(self, n_iter):
+        """Random numbers of n_iter iterations in emcee's order (per half-step:
+        rand(Ns) -> z, randint(Nc, Ns) -> partner, rand(Ns) -> ln u)."""
+        half = self.k // 2
+        z = np.empty((n_iter, 2, half))
+        partner = np.empty((n_iter, 2, half), dtype=np.int32)
+        log_u = np.empty((n_iter, 2, half))
+        for it in range(n_iter):
+            for h in range(2):
+                z[it, h] = ((self.a - 1.0) * self._random.rand(half) + 1) ** 2.0 / self.a
+                partner[it, h] = self._random.randint(half, size=(half,))
+                log_u[it, h] = np.log(self._random.rand(half))
+        return z, (self.dim - 1.0) * np.log(z), partner, log_u
+
+    def sample(self, p0, lnprob0=None, rstate0=None, blobs0=None, iterations=1, thin=1,
+               storechain=True):
+        if rstate0 is not None:
+            self.random_state = rstate0
+        p = np.array(p0, dtype=np.float64)
+        if p.shape != (self.k, self.dim):
+            raise ValueError('p0 must have shape ({}, {})'.format(self.k, self.dim))
+        if np.any(~np.isfinite(p)):
+            raise ValueError('At least one parameter value was infinite or NaN.')
+        lnprob = None if lnprob0 is None else np.array(lnprob0, dtype=np.float64)
+        if lnprob is None:
+            lnprob, _ = self._get_lnprob(p)
+        if np.any(np.isnan(lnprob)):
+            raise ValueError('The initial lnprob was NaN.')
+        i0 = self._chain.shape[1]
+        if storechain:
+            n_keep = int(iterations // thin)
+            self._chain = np.concatenate((self._chain, np.zeros((self.k, n_keep, self.dim))), axis=1)
+            self._lnprob = np.concatenate((self._lnprob, np.zeros((self.k, n_keep))), axis=1)
+        nacc = self.naccepted.astype(np.int64)
+        done = 0
+        while done < iterations:
+            n = min(self.block, iterations - done)
+            z, lz, partner, log_u = self._draw(n)
+            p, lnprob, chain, lnchain = self.model.engine.stretch_run(
+                p, lnprob, z, lz, partner, log_u, nacc, store=True, accumulate=self.accumulate)
+            if self.accumulate:
+                self.model._device_samples += n * self.k
+                self.model.accumulated_samples += n * self.k
+            for j in range(n):
+                i = done + j
+                self.iterations += 1
+                if storechain and i % thin == 0:
+                    ind = i0 + int(i // thin)
+                    self._chain[:, ind, :] = chain[:, j, :]
+                    self._lnprob[:, ind] = lnchain[:, j]
+                self.naccepted = nacc.astype(np.float64)
+                yield chain[:, j, :].copy(), lnchain[:, j].copy(), self.random_state
+            done += n

@@ -98,3 +98,42 @@ def test_device_accumulation_matches_reference_running_mean(tmp_path, backend):
         fin = np.isfinite(want[k])
         assert np.allclose(both[k][fin], want[k][fin], rtol=1e-11, atol=1e-13 * np.abs(want[k][fin]).max()), k
     model.close()
+
+
+def test_device_sampler_reproduces_host_sampler(tmp_path):
+    """Walkers resident on the GPU (psfmc_stretch_run) vs the host loop around the
+    batched posterior: same RandomState, same draw order -> the same chain."""
+    from psfmc_amd.sampler import EnsembleSampler, DeviceEnsembleSampler
+    case = helpers.load_case('synth128x2')
+    model = helpers.build_model('synth128x2', case, tmp_path, max_walkers=64)
+    np.random.seed(2)
+    p0 = model.init_params_from_priors(40)
+    host = EnsembleSampler(40, model.num_params, batch_lnpostfn=model.log_posterior_batch)
+    dev = DeviceEnsembleSampler(40, model, block=7)
+    for s in (host, dev):
+        s.random_state = np.random.RandomState(11).get_state()
+    out_h = list(host.sample(p0, iterations=25))
+    out_d = list(dev.sample(p0, iterations=25))
+    assert np.array_equal(dev.chain, host.chain)
+    assert np.array_equal(dev.naccepted, host.naccepted)
+    assert helpers.rel_err(dev.lnprobability, host.lnprobability) <= 1e-13
+    assert np.array_equal(out_d[-1][0], out_h[-1][0]) and len(out_d) == 25
+    assert 0.05 < dev.acceptance_fraction.mean() < 0.9
+    # continuing a run (lnprob0 given) and thinning
+    more_h = list(host.sample(out_h[-1][0], lnprob0=out_h[-1][1], iterations=6, thin=2))
+    more_d = list(dev.sample(out_d[-1][0], lnprob0=out_d[-1][1], iterations=6, thin=2))
+    assert dev.chain.shape == (40, 28, model.num_params) and np.array_equal(dev.chain, host.chain)
+    # accumulation inside the device loop == accumulating every iteration's positions
+    model.reset_images()
+    acc = DeviceEnsembleSampler(40, model, block=4, accumulate=True)
+    acc.random_state = np.random.RandomState(3).get_state()
+    steps = list(acc.sample(p0, iterations=5))
+    got = {k: v.copy() for k, v in model.collect_posterior_images().items()}
+    assert model.accumulated_samples == 200
+    model.reset_images()
+    for pos, _, _ in steps:
+        model.accumulate_samples(pos)
+    want = model.collect_posterior_images()
+    for k in want:      # (device-derived vs host-derived Sersic constants: 1e-14 apart)
+        assert np.allclose(got[k], want[k], rtol=1e-11, atol=1e-12 * np.abs(want[k]).max()), k
+    model.close()
