@@ -102,6 +102,7 @@ struct psfmc_ctx {
     hipStream_t side[kMaxStreams] = {nullptr, nullptr, nullptr, nullptr};   // side[0] unused
     hipEvent_t ev_fork = nullptr, ev_join[kMaxStreams] = {nullptr, nullptr, nullptr, nullptr};
     int n_streams = 2;
+    int min_split = 1 << 30;  // split a single-pass batch over both streams from this size (off: no gain measured)
     // optional per-kernel timing with HIP events (set_option "profile")
     bool profile = false;
     struct ProfRec { int kind; hipEvent_t a, b; };
@@ -202,8 +203,12 @@ template <int NY, bool CONVOLVE>
 static int launch_cols(psfmc_ctx* c, cd* Tbuf, int n_cols, const double* prep, const uint8_t* skip,
                        hipStream_t st) {
     constexpr size_t lds = fused_col_lds_bytes<NY>();
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cols<NY, CONVOLVE>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static thread_local int attr_device = -1;          // raise the dynamic-LDS limit once per device
+    if (attr_device != c->device) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cols<NY, CONVOLVE>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_device = c->device;
+    }
     const int groups = (n_cols + col_ffts_per_block<NY>() - 1) / col_ffts_per_block<NY>();
     const int grid = groups < c->cols_grid ? groups : c->cols_grid;
     hipLaunchKernelGGL((k_cols<NY, CONVOLVE>), dim3(grid), dim3(kColThreads), lds, st, Tbuf, c->d_Kt,
@@ -534,6 +539,10 @@ extern "C" int psfmc_set_option(psfmc_ctx* c, const char* key, double value) {
         c->cols_grid = (int)value;
         return PSFMC_OK;
     }
+    if (!strcmp(key, "min_split")) {
+        c->min_split = value < 1 ? 1 : (int)value;
+        return PSFMC_OK;
+    }
     if (!strcmp(key, "profile")) {
         HIP_TRY(hipSetDevice(c->device));
         HIP_TRY(hipDeviceSynchronize());
@@ -599,15 +608,18 @@ static int run_pipeline(psfmc_ctx* c, int W, const uint8_t* d_skip, hipStream_t 
     // Fused path: pass i runs on stream i % n_streams with its own T buffer, so the
     // VALU-bound row kernels of one pass overlap the HBM-bound column kernel of its
     // neighbours.  Fork/join on events keeps the caller's stream semantics.
-    const int npass = (W + c->chunk - 1) / c->chunk;
+    // a batch that fits one pass is still split in two so both streams have work
+    int chunk = c->chunk;
+    if (fused && c->n_streams > 1 && W <= chunk && W / 2 >= c->min_split) chunk = ((W + 1) / 2 + 7) & ~7;
+    const int npass = (W + chunk - 1) / chunk;
     const int lanes = !fused ? 1 : (npass < c->n_streams ? npass : c->n_streams);
     if (lanes > 1) {
         HIP_TRY(hipEventRecord(c->ev_fork, st));
         for (int i = 1; i < lanes; ++i) HIP_TRY(hipStreamWaitEvent(c->side[i], c->ev_fork, 0));
     }
     int pass = 0;
-    for (int w0 = 0; w0 < W; w0 += c->chunk, ++pass) {
-        const int n = W - w0 < c->chunk ? W - w0 : c->chunk;
+    for (int w0 = 0; w0 < W; w0 += chunk, ++pass) {
+        const int n = W - w0 < chunk ? W - w0 : chunk;
         const double* prep = c->d_prep + (size_t)w0 * c->plen;
         const uint8_t* skip = d_skip ? d_skip + w0 : nullptr;
         double* partial = c->d_partial + (size_t)w0 * c->nblk;

@@ -71,14 +71,25 @@ __device__ inline double gamma_median(double a) {
         x = a - 1.0 / 3.0 + i * (4.0 / 405.0 + i * (46.0 / 25515.0 + i * (131.0 / 1148175.0 -
             i * (2194697.0 / 30690717750.0))));
     }
-    for (int it = 0; it < 30; ++it) {                            // Halley on P(a, x) = 1/2
-        const double f = igam_series(a, x) - 0.5;
-        const double d1 = exp(igam_log_prefactor(a, x)) * a / x;    // dP/dx = x^(a-1) e^-x / Gamma(a)
+    // Halley on P(a, x) = 1/2: cubic convergence, so a step below 1e-6 x leaves an
+    // error of order 1e-18 x and the iteration stops there (the starting values are
+    // good to 1e-3 ... 1e-9, i.e. one or two steps)
+    for (int it = 0; it < 12; ++it) {
+        const double pre = exp(igam_log_prefactor(a, x));         // x^a e^-x / Gamma(a+1)
+        double term = 1.0, sum = 1.0, ap = a;
+        for (int k = 0; k < 2000; ++k) {
+            ap += 1.0;
+            term *= x * fast_rcp(ap);
+            sum += term;
+            if (term < 1e-17 * sum) break;
+        }
+        const double f = sum * pre - 0.5;
+        const double d1 = pre * a / x;                            // dP/dx = x^(a-1) e^-x / Gamma(a)
         const double r = f / d1;
         const double dx = r / (1.0 + 0.5 * r * (1.0 - (a - 1.0) / x));
         x -= dx;
         if (!(x > 0.0)) x = 0.5 * (x + dx);
-        if (fabs(dx) <= 2e-16 * x) break;
+        if (fabs(dx) <= 1e-6 * x) break;
     }
     return x;
 }
