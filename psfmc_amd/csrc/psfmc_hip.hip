@@ -120,6 +120,7 @@ struct psfmc_ctx {
     // raw-vector path (psfmc_set_layout)
     bool has_layout = false;
     ThetaLayout layout{};
+    size_t theta_lds = 0;
     void* d_layout_blob = nullptr;           // one allocation behind the layout's pointers
     double *d_theta = nullptr, *d_extra = nullptr, *d_lnprior = nullptr;
     double* d_acc = nullptr;  // [4][S] sums: raw, conv, model variance, PS-only conv
@@ -656,8 +657,9 @@ static int eval_device(psfmc_ctx* c, int W, const double* d_rows, const uint8_t*
 // raw vectors -> log-posterior, everything on the device
 static int eval_theta_device(psfmc_ctx* c, int W, const double* d_theta, const double* d_extra,
                              double* d_lnprob, hipStream_t st) {
-    hipLaunchKernelGGL(k_theta_prep, dim3((W + 63) / 64), dim3(64), 0, st, c->layout, d_theta, d_extra,
-                       c->d_rows, c->d_prep, c->d_lnprior, c->d_skip, W, c->ny, c->nx, c->d_rho);
+    hipLaunchKernelGGL(k_theta_prep, dim3((W + kThetaThreads - 1) / kThetaThreads), dim3(kThetaThreads),
+                       c->theta_lds, st, c->layout, d_theta, d_extra, (double*)nullptr, c->d_prep,
+                       c->d_lnprior, c->d_skip, W, c->ny, c->nx, c->d_rho);
     RC_TRY(run_pipeline(c, W, c->d_skip, st));
     hipLaunchKernelGGL(k_finish_posterior, dim3((W + 127) / 128), dim3(128), 0, st, c->d_partial, c->d_skip,
                        c->d_lnprior, d_lnprob, W, c->nblk);
@@ -832,6 +834,11 @@ extern "C" int psfmc_set_layout(psfmc_ctx* c, int n_sky, int n_params, const int
     HIP_TRY(hipMalloc(&c->d_theta, (size_t)c->max_walkers * (n_params > 0 ? n_params : 1) * sizeof(double)));
     HIP_TRY(hipMalloc(&c->d_extra, (size_t)c->max_walkers * sizeof(double)));
     HIP_TRY(hipMalloc(&c->d_lnprior, (size_t)c->max_walkers * sizeof(double)));
+    c->theta_lds = theta_prep_lds_bytes(n_sky, c->n_ps, c->n_sersic, n_params);
+    if (c->theta_lds > 64 * 1024) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_theta_prep),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->theta_lds));
+    }
     c->has_layout = true;
     return PSFMC_OK;
 }
@@ -877,9 +884,9 @@ extern "C" int psfmc_debug_theta_rows(psfmc_ctx* c, int W, const double* theta, 
         HIP_TRY(hipMemcpyAsync(c->d_theta, theta, (size_t)W * c->layout.n_params * sizeof(double),
                                hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(c->d_rows, 0, (size_t)W * c->rlen * sizeof(double), st));
-    hipLaunchKernelGGL(k_theta_prep, dim3((W + 63) / 64), dim3(64), 0, st, c->layout, c->d_theta,
-                       (const double*)nullptr, c->d_rows, c->d_prep, c->d_lnprior, c->d_skip, W, c->ny,
-                       c->nx, c->d_rho);
+    hipLaunchKernelGGL(k_theta_prep, dim3((W + kThetaThreads - 1) / kThetaThreads), dim3(kThetaThreads),
+                       c->theta_lds, st, c->layout, c->d_theta, (const double*)nullptr, c->d_rows, c->d_prep,
+                       c->d_lnprior, c->d_skip, W, c->ny, c->nx, c->d_rho);
     HIP_TRY(hipMemcpyAsync(rows, c->d_rows, (size_t)W * c->rlen * sizeof(double), hipMemcpyDeviceToHost, st));
     if (lnprior) HIP_TRY(hipMemcpyAsync(lnprior, c->d_lnprior, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, st));
     if (skip) HIP_TRY(hipMemcpyAsync(skip, c->d_skip, (size_t)W, hipMemcpyDeviceToHost, st));
@@ -1032,9 +1039,9 @@ extern "C" int psfmc_stretch_run(psfmc_ctx* c, int W, int n_iter, double* pos, d
             hipLaunchKernelGGL(k_stretch_store, dim3((W * P + 255) / 256), dim3(256), 0, st, d_pos, d_lnp,
                                d_chain, d_lnchain, W, P, it, n_iter);
         if (accumulate) {
-            hipLaunchKernelGGL(k_theta_prep, dim3((W + 63) / 64), dim3(64), 0, st, c->layout, d_pos,
-                               (const double*)nullptr, c->d_rows, c->d_prep, c->d_lnprior, c->d_skip, W,
-                               c->ny, c->nx, c->d_rho);
+            hipLaunchKernelGGL(k_theta_prep, dim3((W + kThetaThreads - 1) / kThetaThreads),
+                               dim3(kThetaThreads), c->theta_lds, st, c->layout, d_pos, (const double*)nullptr,
+                               (double*)nullptr, c->d_prep, c->d_lnprior, c->d_skip, W, c->ny, c->nx, c->d_rho);
             rc = accumulate_from_prep(c, W, st);
         }
     }

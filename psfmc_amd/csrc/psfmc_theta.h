@@ -188,16 +188,54 @@ __device__ inline void theta_to_prep(const ThetaLayout& L, const double* __restr
     build_prep(row, prep, L.n_ps, L.n_sersic, ny, nx, rho);
 }
 
-__global__ void k_theta_prep(ThetaLayout L, const double* __restrict__ theta,
-                             const double* __restrict__ extra, double* __restrict__ rows,
-                             double* __restrict__ prep, double* __restrict__ lnprior,
-                             uint8_t* __restrict__ skip, int W, int ny, int nx,
-                             const double* __restrict__ rho) {
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+// LDS bytes of k_theta_prep: the layout tables, and per thread its parameter vector
+// and its derived row (the walk through the slots is a long chain of dependent small
+// loads: from global memory it cost 45 us per call, from LDS it is a few us)
+constexpr int kThetaThreads = 64;
+__host__ inline size_t theta_prep_lds_bytes(int n_sky, int n_ps, int n_sersic, int n_params) {
+    const size_t ns = n_slots(n_sky, n_ps, n_sersic);
+    const size_t n_int = ((ns + n_ps + n_sersic + n_params + 1) / 2) * 2;           // 8-byte multiple
+    const size_t n_dbl = ns + 3 * (size_t)n_params;
+    return n_int * sizeof(int) + (n_dbl + (size_t)kThetaThreads * (n_params + row_len(n_ps, n_sersic))) *
+                                     sizeof(double);
+}
+
+__global__ void __launch_bounds__(kThetaThreads)
+k_theta_prep(ThetaLayout G, const double* __restrict__ theta,
+             const double* __restrict__ extra, double* __restrict__ rows,
+             double* __restrict__ prep, double* __restrict__ lnprior,
+             uint8_t* __restrict__ skip, int W, int ny, int nx,
+             const double* __restrict__ rho) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int ns = n_slots(G.n_sky, G.n_ps, G.n_sersic);
+    const int n_int = ((ns + G.n_ps + G.n_sersic + G.n_params + 1) / 2) * 2;
+    const int n_dbl = ns + 3 * G.n_params;
+    const int rlen = row_len(G.n_ps, G.n_sersic);
+    int* li = reinterpret_cast<int*>(lds_raw);
+    double* ld = reinterpret_cast<double*>(lds_raw + (size_t)n_int * sizeof(int));
+    double* th_tile = ld + n_dbl;
+    double* row_tile = th_tile + (size_t)kThetaThreads * G.n_params;
+    // the four int tables and the four double tables are contiguous in the blob
+    for (int i = threadIdx.x; i < ns + G.n_ps + G.n_sersic + G.n_params; i += kThetaThreads) li[i] = G.slot_col[i];
+    for (int i = threadIdx.x; i < n_dbl; i += kThetaThreads) ld[i] = G.slot_const[i];
+    const int w0 = blockIdx.x * kThetaThreads;
+    const int n_here = W - w0 < kThetaThreads ? W - w0 : kThetaThreads;
+    for (int i = threadIdx.x; i < n_here * G.n_params; i += kThetaThreads)      // coalesced tile load
+        th_tile[i] = theta[(size_t)w0 * G.n_params + i];
+    __syncthreads();
+    ThetaLayout L = G;
+    L.slot_col = li; L.ps_method = li + ns; L.sersic_deg = li + ns + G.n_ps;
+    L.family = li + ns + G.n_ps + G.n_sersic;
+    L.slot_const = ld; L.pa = ld + ns; L.pb = ld + ns + G.n_params; L.pc = ld + ns + 2 * G.n_params;
+    const int w = w0 + threadIdx.x;
     if (w >= W) return;
-    theta_to_prep(L, theta + (size_t)w * L.n_params, extra ? extra[w] : 0.0,
-                  rows + (size_t)w * row_len(L.n_ps, L.n_sersic),
-                  prep + (size_t)w * prep_len(L.n_ps, L.n_sersic), lnprior + w, skip + w, ny, nx, rho);
+    double* row = row_tile + (size_t)threadIdx.x * rlen;
+    theta_to_prep(L, th_tile + (size_t)threadIdx.x * G.n_params, extra ? extra[w] : 0.0, row,
+                  prep + (size_t)w * prep_len(G.n_ps, G.n_sersic), lnprior + w, skip + w, ny, nx, rho);
+    if (rows) {
+        double* out = rows + (size_t)w * rlen;
+        for (int i = 0; i < rlen; ++i) out[i] = row[i];
+    }
 }
 
 // lnprob[w] = loglike + lnprior, non-finite likelihood -> -inf (models.py:238-243)
