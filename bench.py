@@ -129,6 +129,42 @@ def cpu_baseline(args, fld, theta, budget_s):
             'sample': '%d walkers of the same batch, one per call, %.1f s' % (done, el)}, vals
 
 
+def cpu_worker(args):
+    """Child process of cpu_baseline_multi: evaluate walkers with the oracle for
+    --cpu-seconds and print how many were done (no GPU, no torch)."""
+    import synth_field
+    fld = synth_field.make_field(args.size, args.sersic, seed=0)
+    half = args.walkers // 2
+    theta = np.vstack([
+        synth_field.draw_walkers(args.size, args.sersic, half, seed=1),
+        synth_field.draw_walkers(args.size, args.sersic, args.walkers - half, seed=2,
+                                 near_truth=fld['truth'])])
+    _, vals = cpu_baseline(args, fld, theta[args.cpu_worker::7], args.cpu_seconds)
+    print('CPU_WORKER_DONE %d' % len(vals))
+
+
+def cpu_baseline_multi(args, n_procs):
+    """The best the reference could do had `threads=n` worked: one
+    single-threaded process per core, walkers split between them."""
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS='1', MKL_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1')
+    cmd = [sys.executable, os.path.abspath(__file__), '--size', str(args.size), '--sersic',
+           str(args.sersic), '--walkers', str(args.walkers), '--cpu-seconds', str(args.cpu_seconds)]
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen(cmd + ['--cpu-worker', str(i)], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.DEVNULL, text=True) for i in range(n_procs)]
+    done = 0
+    for p in procs:
+        out, _ = p.communicate(timeout=args.cpu_seconds * 4 + 120)
+        for line in out.splitlines():
+            if line.startswith('CPU_WORKER_DONE'):
+                done += int(line.split()[1])
+    el = time.perf_counter() - t0
+    return {'value': done / args.cpu_seconds, 'unit': 'evals/s', 'cores': n_procs, 'kind': 'port',
+            'sample': '%d single-threaded processes x %.0f s of walkers of the same batch '
+                      '(wall %.1f s incl. start-up)' % (n_procs, args.cpu_seconds, el)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -142,7 +178,17 @@ def main():
     ap.add_argument('--opt', action='append', default=[], help='library option key=value (tuning)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--cpu-procs', type=int, default=min(16, os.cpu_count() or 1),
+                    help='processes of the all-cores CPU baseline (0 = skip)')
+    ap.add_argument('--cpu-worker', type=int, default=-1, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker >= 0:
+        return cpu_worker(args)
+    # the all-cores CPU baseline runs first, in child processes, before this process
+    # touches the GPU (rank 0, N = 1 only)
+    multi = None
+    if (not args.no_cpu and args.cpu_procs > 1 and int(os.environ.get('WORLD_SIZE', '1')) == 1):
+        multi = cpu_baseline_multi(args, args.cpu_procs)
 
     import torch
     import torch.distributed as dist
@@ -262,6 +308,8 @@ def main():
         if not args.no_cpu:
             base, vals = cpu_baseline(args, fld, theta, args.cpu_seconds)
             line['cpu_baseline'] = base
+            if multi:
+                line['cpu_baseline_all_cores'] = multi
             ref = np.array(vals)[:len(lnlike)]
             got = lnlike[:len(ref)]
             fin = np.isfinite(ref)
