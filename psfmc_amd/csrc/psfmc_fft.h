@@ -115,23 +115,6 @@ template <int SIGN> struct Dft<2, SIGN> {
     }
 };
 
-// Per-lane inter-stage twiddles W_N^(t*c), c < P, from the table tw[k] =
-// exp(-2 pi i k/N).  For P <= 16 they live in registers for the whole kernel;
-// for P = 32 that would cost 128 VGPRs, so they are re-read from the (L1/L2
-// resident) table at each use instead.
-template <int N> constexpr bool fft_tw_in_regs() { return FftShape<N>::P <= 16; }
-template <int N> constexpr int fft_tw_regs() { return fft_tw_in_regs<N>() ? FftShape<N>::P : 1; }
-
-template <int N>
-__device__ __forceinline__ void load_twiddles(cd (&w)[fft_tw_regs<N>()], const cd* __restrict__ table, int t) {
-    if constexpr (fft_tw_in_regs<N>()) {
-#pragma unroll
-        for (int c = 0; c < FftShape<N>::P; ++c) w[c] = table[t * c];
-    } else {
-        w[0] = cd{1.0, 0.0};
-    }
-}
-
 // LDS hand-off between lanes of ONE wave.  A wave's DS instructions execute in
 // program order, so a ds_read issued after a ds_write of the same wave observes
 // it; all that is needed is that the compiler keeps that order (the fences) and
@@ -142,6 +125,42 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Per-lane inter-stage twiddles W_N^(t*c), c < P, from the table tw[k] =
+// exp(-2 pi i k/N).  Three homes (PSFMC_TW_MODE):
+//   0  registers for the whole kernel (P <= 16 only): fastest per transform, but
+//      4 P VGPRs that cap the waves a SIMD can hold
+//   1  a per-wave LDS table twl[c][t] (lane-contiguous, conflict-free reads), filled
+//      once per wave: a few extra ds_read_b128 per transform, 60 VGPRs back
+//   2  re-read from the global table at every use (always for P = 32)
+// Measured at 256^2 (bench.py, MI355X): mode 0 1.085 M evals/s at 2-3 waves/SIMD, mode 1
+// 1.06 M at 4 waves/SIMD -- the row kernels are not occupancy-limited, so the default is 0.
+#ifndef PSFMC_TW_MODE
+#define PSFMC_TW_MODE 0
+#endif
+template <int N> constexpr int fft_tw_mode() { return FftShape<N>::P > 16 ? 2 : PSFMC_TW_MODE; }
+template <int N> constexpr bool fft_tw_in_regs() { return fft_tw_mode<N>() == 0; }
+template <int N> constexpr int fft_tw_regs() { return fft_tw_in_regs<N>() ? FftShape<N>::P : 1; }
+// LDS complex elements of the per-wave twiddle table (mode 1)
+template <int N> constexpr int fft_tw_lds_elems() { return fft_tw_mode<N>() == 1 ? FftShape<N>::P * FftShape<N>::T : 0; }
+
+// `twl`: this wave's LDS table (mode 1) -- every lane of the wave must call.
+template <int N>
+__device__ __forceinline__ void load_twiddles(cd (&w)[fft_tw_regs<N>()], const cd* __restrict__ table, int t,
+                                              cd* __restrict__ twl, int lane) {
+    constexpr int P = FftShape<N>::P, T = FftShape<N>::T;
+    if constexpr (fft_tw_mode<N>() == 0) {
+#pragma unroll
+        for (int c = 0; c < P; ++c) w[c] = table[t * c];
+    } else {
+        w[0] = cd{1.0, 0.0};
+        if constexpr (fft_tw_mode<N>() == 1) {
+#pragma unroll
+            for (int i = lane; i < P * T; i += 64) twl[i] = table[(i / T) * (i % T)];   // twl[c][t] = W^(t c)
+            wave_lds_sync();
+        }
+    }
+}
+
 // The cooperative transform.  `xbuf` = this transform's private LDS region of
 // fft_lds_elems<N>() DOUBLES; the T lanes of a transform sit in one wave (T <= 32),
 // `t` in [0,T).  `w` from load_twiddles (forward table).  Converged call only.
@@ -150,13 +169,16 @@ __device__ __forceinline__ void wave_lds_sync() {
 // waves a CU can hold, for the same number of LDS bytes moved.
 template <int N, int SIGN>
 __device__ __forceinline__ void fft_wave(cd (&v)[FftShape<N>::P], const cd (&w)[fft_tw_regs<N>()],
-                                         const cd* __restrict__ table, int t, double* __restrict__ xbuf) {
+                                         const cd* __restrict__ table, int t, double* __restrict__ xbuf,
+                                         const cd* __restrict__ twl) {
     constexpr int P = FftShape<N>::P, T = FftShape<N>::T;
     Dft<P, SIGN>::run(v);
 #pragma unroll
     for (int c = 1; c < P; ++c) {
         cd wc;
-        if constexpr (fft_tw_in_regs<N>()) wc = w[c]; else wc = table[t * c];
+        if constexpr (fft_tw_mode<N>() == 0) wc = w[c];
+        else if constexpr (fft_tw_mode<N>() == 1) wc = twl[c * T + t];
+        else wc = table[t * c];
         v[c] = cmul(v[c], SIGN < 0 ? wc : cconj(wc));
     }
     double* row = xbuf + t * (P + 1);

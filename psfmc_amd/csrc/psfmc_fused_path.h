@@ -32,16 +32,27 @@
 
 namespace psfmc {
 
-constexpr int kRowThreads = 64;      // row kernels: one autonomous wave per workgroup
+#ifndef PSFMC_ROW_WAVES
+#define PSFMC_ROW_WAVES 1
+#endif
+constexpr int kRowWaves = PSFMC_ROW_WAVES;   // autonomous waves per row-kernel workgroup (consecutive row groups)
+constexpr int kRowThreads = 64 * kRowWaves;
 constexpr int kColThreads = 256;     // column kernel: 4 waves, persistent
 
 template <int NX> constexpr int row_group() { return 64 / FftShape<NX>::T; }      // rows per wave
+// per wave: the exchange regions of its RG transforms, then its twiddle table
+template <int NX> constexpr size_t fused_row_wave_lds_doubles() {
+    return (size_t)row_group<NX>() * fft_lds_elems<NX>() + 2 * (size_t)fft_tw_lds_elems<NX>();
+}
 template <int NX> constexpr size_t fused_row_lds_bytes() {
-    return (size_t)row_group<NX>() * fft_lds_elems<NX>() * sizeof(double);
+    return (size_t)kRowWaves * fused_row_wave_lds_doubles<NX>() * sizeof(double);
 }
 template <int NY> constexpr int col_ffts_per_block() { return kColThreads / FftShape<NY>::T; }
+template <int NY> constexpr size_t fused_col_wave_lds_doubles() {
+    return (size_t)(64 / FftShape<NY>::T) * fft_lds_elems<NY>() + 2 * (size_t)fft_tw_lds_elems<NY>();
+}
 template <int NY> constexpr size_t fused_col_lds_bytes() {
-    return (size_t)col_ffts_per_block<NY>() * fft_lds_elems<NY>() * sizeof(double);
+    return (size_t)(kColThreads / 64) * fused_col_wave_lds_doubles<NY>() * sizeof(double);
 }
 // waves per SIMD the register allocator must leave room for
 template <int N> constexpr int fused_min_waves() { return FftShape<N>::P > 16 ? 1 : 2; }
@@ -90,8 +101,9 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
     extern __shared__ __align__(16) double smem[];
     const int w = blockIdx.y;
     if (skip && skip[w]) return;
-    const int f = threadIdx.x / T, t = threadIdx.x % T;
-    const int yg = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int f = lane / T, t = lane % T;
+    const int yg = blockIdx.x * kRowWaves + wave;
     const int iy = yg * RG + f;
     const size_t S = (size_t)ny * NX;
 
@@ -115,10 +127,12 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
             for (int k = 0; k < P; ++k) o[T * k + t] = v[k].x;
         }
     }
+    double* wave_lds = smem + (size_t)wave * fused_row_wave_lds_doubles<NX>();
+    cd* twl = reinterpret_cast<cd*>(wave_lds + (size_t)RG * fft_lds_elems<NX>());
     cd tw[fft_tw_regs<NX>()];
-    load_twiddles<NX>(tw, twx, t);
-    double* xbuf = smem + (size_t)f * fft_lds_elems<NX>();
-    fft_wave<NX, -1>(v, tw, twx, t, xbuf);
+    load_twiddles<NX>(tw, twx, t, twl, lane);
+    double* xbuf = wave_lds + (size_t)f * fft_lds_elems<NX>();
+    fft_wave<NX, -1>(v, tw, twx, t, xbuf, twl);
 
     // Untangle.  Lane t holds Z[k], k = t + T e.  Z[NX - k] is held by lane
     // (T - t) % T at e' = P-1-e (t != 0) or P-e (t == 0), i.e. in the upper half of
@@ -164,9 +178,12 @@ k_cols(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restric
     constexpr int FPB = col_ffts_per_block<NY>();
     extern __shared__ __align__(16) double smem[];
     const int s = threadIdx.x / T, t = threadIdx.x % T;
-    double* xbuf = smem + (size_t)s * fft_lds_elems<NY>();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* wave_lds = smem + (size_t)wave * fused_col_wave_lds_doubles<NY>();
+    double* xbuf = wave_lds + (size_t)(lane / T) * fft_lds_elems<NY>();
+    cd* twl = reinterpret_cast<cd*>(wave_lds + (size_t)(64 / T) * fft_lds_elems<NY>());
     cd tw[fft_tw_regs<NY>()];
-    load_twiddles<NY>(tw, twy, t);
+    load_twiddles<NY>(tw, twy, t, twl, lane);
     const int n_groups = (n_cols + FPB - 1) / FPB;
     for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const int col = grp * FPB + s;
@@ -182,13 +199,13 @@ k_cols(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restric
         cd v[P];
 #pragma unroll
         for (int a = 0; a < P; ++a) v[a] = active ? base[2 * T * a] : cd{0.0, 0.0};
-        fft_wave<NY, -1>(v, tw, twy, t, xbuf);
+        fft_wave<NY, -1>(v, tw, twy, t, xbuf, twl);
         if constexpr (CONVOLVE) {
             const int psf = active ? (int)prep[(size_t)w * plen + kPrepPsfIdx] : 0;
             const cd* k = Kt + (((size_t)psf * nxh + kx) * 2 + c) * NY;
 #pragma unroll
             for (int e = 0; e < P; ++e) v[e] = cmul(v[e], k[t + T * e]);
-            fft_wave<NY, +1>(v, tw, twy, t, xbuf);
+            fft_wave<NY, +1>(v, tw, twy, t, xbuf, twl);
         }
         if (active) {
 #pragma unroll
@@ -214,8 +231,9 @@ k_rows_inv(const cd* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
 
     const int w = blockIdx.y;
     if (skip && skip[w]) return;
-    const int f = threadIdx.x / T, t = threadIdx.x % T;
-    const int yg = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int f = lane / T, t = lane % T;
+    const int yg = blockIdx.x * kRowWaves + wave;
     const int iy = yg * RG + f;
     const cd* src = Tbuf + (size_t)w * 2 * NXH * ny + t_elem(iy, 0, __builtin_ctz(RG));
     const size_t kstride = (size_t)2 * ny;
@@ -230,9 +248,11 @@ k_rows_inv(const cd* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
         const cd g = p[0], h = p[RG];
         v[a] = direct ? cd{g.x - h.y, g.y + h.x} : cd{g.x + h.y, h.x - g.y};
     }
+    double* wave_lds = smem + (size_t)wave * fused_row_wave_lds_doubles<NX>();
+    cd* twl = reinterpret_cast<cd*>(wave_lds + (size_t)RG * fft_lds_elems<NX>());
     cd tw[fft_tw_regs<NX>()];
-    load_twiddles<NX>(tw, twx, t);
-    fft_wave<NX, +1>(v, tw, twx, t, smem + (size_t)f * fft_lds_elems<NX>());
+    load_twiddles<NX>(tw, twx, t, twl, lane);
+    fft_wave<NX, +1>(v, tw, twx, t, wave_lds + (size_t)f * fft_lds_elems<NX>(), twl);
     // imaginary part is lambda * model variance (see build_prep)
     const double inv_lambda = prep[(size_t)w * plen + kPrepInvLambda];
 #pragma unroll
@@ -246,7 +266,7 @@ k_rows_inv(const cd* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
             var_out[rowoff + T * e + t] = v[e].y;
         }
     }
-    const FieldPx* fp = field + (size_t)yg * P * 64 + threadIdx.x;
+    const FieldPx* fp = field + (size_t)yg * P * 64 + lane;
     double acc = 0.0;
 #pragma unroll
     for (int e = 0; e < P; ++e) {
@@ -256,7 +276,7 @@ k_rows_inv(const cd* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-    if (threadIdx.x == 0) partial[(size_t)w * gridDim.x + yg] = acc;
+    if (lane == 0) partial[(size_t)w * gridDim.x * kRowWaves + yg] = acc;
 }
 
 // Kt[psf][kx][c][ky] = spec_c[psf][ky][kx] * (-1)^(kx+ky) / S from the

@@ -30,6 +30,10 @@ class NativeError(RuntimeError):
 
 
 def library_path():
+    """The in-tree extension; PSFMC_LIB may name another build of it (A/B runs)."""
+    override = os.environ.get('PSFMC_LIB')
+    if override:
+        return override
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
 
 
