@@ -150,3 +150,24 @@ def test_native_argument_errors_without_gpu():
                               1, 2, 2, a.ctypes.data_as(dp), a.ctypes.data_as(dp), 1, 1, 8, 1)
     assert rc == -1 and b'even' in lib.psfmc_last_error()
     assert handle.value is None
+
+
+def test_no_gpu_fails_loudly(tmp_path):
+    """The product has no CPU fallback: without a gfx950 device the context
+    cannot be created and the error says so."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is present')
+    case = helpers.load_case('synth128x2')
+    model = helpers.build_model('synth128x2', case, tmp_path)
+    with pytest.raises(engine.NativeError) as err:
+        model.log_posterior_batch(case['params'][:2])
+    assert err.value.code == -4 and 'HIP device' in str(err.value)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(engine, '_lib', None)
+    monkeypatch.setenv('PSFMC_LIB', '/nonexistent/libpsfmc_hip.so')
+    with pytest.raises(ImportError) as err:
+        engine.load_library()
+    assert 'no' in str(err.value).lower() and 'CPU fallback' in str(err.value)
