@@ -48,12 +48,12 @@ def pmc_traffic(args, kernel):
         return None
 
 
-def build_problem(args, device):
+def build_problem(args, device, seed=0):
     """Synthetic field + walker rows.  Returns (model, theta[W,P])."""
     import tempfile
     import synth_field
     from psfmc_amd import MultiComponentModel, fits_io
-    fld = synth_field.make_field(args.size, args.sersic, seed=0)
+    fld = synth_field.make_field(args.size, args.sersic, seed=seed)
     tmp = tempfile.mkdtemp(prefix='psfmc_bench_')
     for key, name in (('sci', 'sci.fits'), ('ivm', 'ivm.fits'), ('psf', 'psf.fits'),
                       ('psf_ivm', 'psf_ivm.fits')):
@@ -165,6 +165,65 @@ def cpu_baseline_multi(args, n_procs):
                       '(wall %.1f s incl. start-up)' % (n_procs, args.cpu_seconds, el)}
 
 
+def many_fields(args, torch, dist, world, rank, local, dev):
+    """BASELINE config 5: every rank owns --fields independent fields (own context,
+    own streams, own walkers); a step evaluates all of them.  Fields shard across
+    ranks with no data-path collective."""
+    probs = [build_problem(args, local, seed=rank * args.fields + f) for f in range(args.fields)]
+    engs, rows, outs = [], [], []
+    for model, theta, _ in probs:
+        engs.append(model.engine)
+        rows.append(torch.from_numpy(model.derived_rows(theta)).to(dev))
+        outs.append(torch.empty(args.walkers, dtype=torch.float64, device=dev))
+
+    def step():
+        for eng, r, o in zip(engs, rows, outs):       # each context enqueues on its own stream
+            eng.loglike_device(args.walkers, r.data_ptr(), 0, o.data_ptr(), None)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    finite = int(sum(int(torch.isfinite(o).sum().item()) for o in outs))
+    if rank == 0:
+        total = args.walkers * args.fields * world * args.steps
+        b_eval = algorithmic_bytes_per_eval(args.size)
+        achieved = b_eval * total / elapsed / world / 1e9
+        print(json.dumps({
+            'metric': 'walker log-posterior evals/sec, 256x256 image, 1 PSF+1 Sersic',
+            'value': total / elapsed, 'unit': 'evals/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+            'data': 'synthetic',
+            'config': {'workload': '%d independent synthetic %dx%d fields per GPU x %d walkers each, '
+                                   '1 PointSource + %d Sersic, fp64' % (args.fields, args.size,
+                                                                       args.size, args.walkers,
+                                                                       args.sersic),
+                       'fields_per_gpu': args.fields, 'walkers_per_field': args.walkers,
+                       'backend': args.backend, 'parallelism': 'fields sharded x%d' % world},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
+                         'kernel': 'evaluation pipelines of all fields (per GPU)',
+                         'bytes_per_eval': b_eval},
+            'finite_loglikes': finite}))
+    for model, _, _ in probs:
+        model.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -174,6 +233,9 @@ def main():
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--sersic', type=int, default=1)
     ap.add_argument('--backend', default=os.environ.get('PSFMC_BACKEND', 'fused'))
+    ap.add_argument('--fields', type=int, default=1,
+                    help='independent fields per GPU, each with its own context and --walkers '
+                         'walkers (BASELINE config 5: 64 fields x 256 walkers over 8 GPUs)')
     ap.add_argument('--chunk', type=int, default=0, help='walkers per internal pass (0 = library default)')
     ap.add_argument('--opt', action='append', default=[], help='library option key=value (tuning)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
@@ -204,6 +266,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
+    if args.fields > 1:
+        return many_fields(args, torch, dist, world, rank, local, dev)
     model, theta, fld = build_problem(args, local)
     eng = model.engine
     if args.chunk:
