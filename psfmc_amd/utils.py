@@ -53,18 +53,65 @@ def preprocess_obs(obs_data, obs_ivm, mask_file=None):
 
 
 def mask_from_file(mask_file, obs_hdr, shape):
-    """FITS mask (nonzero = exclude) or array (utils.py:82-103).  ds9 region
-    files need pyregion, which is not available: like the reference without
-    pyregion, they are ignored with a warning."""
+    """FITS mask (nonzero = exclude), array, or ds9 region file in image
+    coordinates (utils.py:82-103).  Region files: the fitting region is the union of
+    the plain shapes minus the `-`-prefixed ones, applied in file order; everything
+    outside is excluded (the reference does `~filter.mask(shape)` with pyregion).
+    Only `circle`, `box` (unrotated) and `ellipse` (unrotated) in `image` coordinates
+    are understood; anything else is ignored with a warning, like the reference
+    without pyregion.  PARITY UNPINNED: pyregion is not available to compare with
+    (pixel (ix, iy), 0-based, has ds9 image coordinates (ix + 1, iy + 1))."""
     if not isinstance(mask_file, str):
         return np.asarray(mask_file).astype(bool)
     try:
         return fits_io.read_image(mask_file).astype(bool)
     except (IOError, OSError, KeyError, ValueError):
         pass
-    warn('{} is not a FITS mask; ds9 region masks are not supported here and '
-         'will be ignored.'.format(mask_file))
+    try:
+        return ~region_filter(mask_file, shape)
+    except (IOError, OSError, ValueError, UnicodeDecodeError) as err:
+        warn('{} is neither a FITS mask nor a supported ds9 region file ({}); it will be '
+             'ignored.'.format(mask_file, err))
     return None
+
+
+def region_filter(region_file, shape):
+    """Boolean image, True inside the fitting region of a ds9 region file."""
+    import re
+    yy, xx = np.mgrid[0:shape[0], 0:shape[1]].astype(np.float64)
+    inside = np.zeros(shape, dtype=bool)
+    system, n_shapes = 'image', 0
+    with open(region_file) as f:
+        for raw in f:
+            line = raw.split('#')[0].strip()
+            if not line or line.startswith('global'):
+                continue
+            if line.lower() in ('image', 'physical', 'fk5', 'icrs', 'galactic', 'j2000', 'fk4'):
+                system = line.lower()
+                continue
+            m = re.match(r'^(?:(\w+)\s*;\s*)?([+-]?)\s*(circle|box|ellipse)\s*\(([^)]*)\)', line, re.I)
+            if not m:
+                raise ValueError('unsupported region line: ' + line)
+            if (m.group(1) or system).lower() not in ('image', 'physical'):
+                raise ValueError('only image coordinates are supported, got ' + (m.group(1) or system))
+            args = [float(v.strip().rstrip('"\'')) for v in m.group(4).split(',')]
+            kind = m.group(3).lower()
+            dx, dy = xx - (args[0] - 1.0), yy - (args[1] - 1.0)
+            if kind == 'circle':
+                sel = dx * dx + dy * dy <= args[2] ** 2
+            elif kind == 'box':
+                if len(args) > 4 and args[4] != 0:
+                    raise ValueError('rotated boxes are not supported')
+                sel = (np.abs(dx) <= args[2] / 2) & (np.abs(dy) <= args[3] / 2)
+            else:
+                if len(args) > 4 and args[4] != 0:
+                    raise ValueError('rotated ellipses are not supported')
+                sel = (dx / args[2]) ** 2 + (dy / args[3]) ** 2 <= 1.0
+            inside = (inside & ~sel) if m.group(2) == '-' else (inside | sel)
+            n_shapes += 1
+    if n_shapes == 0:
+        raise ValueError('no shapes found')
+    return inside
 
 
 def preprocess_psf(psf_data, psf_ivm):

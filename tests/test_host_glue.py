@@ -171,3 +171,28 @@ def test_missing_library_fails_loudly(monkeypatch):
     with pytest.raises(ImportError) as err:
         engine.load_library()
     assert 'no' in str(err.value).lower() and 'CPU fallback' in str(err.value)
+
+
+def test_ds9_region_mask(tmp_path):
+    """ds9 region masks (circle / -circle / box in image coordinates).  Semantics as
+    documented in utils.mask_from_file; parity with pyregion is unpinned (not installed)."""
+    from psfmc_amd.utils import mask_from_file, region_filter
+    reg = tmp_path / 'm.reg'
+    reg.write_text('# Region file format: DS9 version 4.1\n'
+                   'global color=green dashlist=8 3 width=1\nimage\n'
+                   'circle(33,33,10)\n-circle(36,33,3)\nbox(10,50,6,4,0)\n')
+    inside = region_filter(str(reg), (64, 64))
+    assert inside[32, 30] and not inside[32, 35] and not inside[32, 44] and inside[32, 42]
+    assert inside[49, 9] and inside[49 + 2, 9 + 3] and not inside[49 + 3, 9]
+    bad = mask_from_file(str(reg), {}, (64, 64))
+    assert np.array_equal(bad, ~inside)
+    # the reference's example region file parses too
+    ex = tmp_path / 'ex.reg'
+    ex.write_text('image\ncircle(64.540771,64.079391,55.620614)\n-circle(111.37667,58.936343,11.905084)\n')
+    keep = region_filter(str(ex), (128, 128))
+    assert keep[63, 63] and not keep[0, 0] and not keep[58, 110]
+    # unsupported content -> ignored with a warning, like the reference without pyregion
+    other = tmp_path / 'o.reg'
+    other.write_text('fk5\ncircle(10:00:00,+02:00:00,5")\n')
+    with pytest.warns(UserWarning):
+        assert mask_from_file(str(other), {}, (8, 8)) is None
