@@ -27,6 +27,7 @@ for name in ['sq1','sq2','fetch','write']:
         agg[k][r['Counter_Name']] += float(r['Counter_Value'])
         cnt[(k, r['Counter_Name'])] += 1
     for k in sorted(agg):
-        if ('k_rows' in k or 'k_cols' in k) and 'true>' not in k.replace('k_cols','') and ', false>' not in k.replace('k_rows_fwd',''):
+        if k.startswith(('k_rows_fwd<', 'k_cols<', 'k_rows_inv<')) and not k.endswith((', true>', 'false> ')) \
+                and 'k_cols' not in k or k.startswith('k_cols') and k.endswith('true>'):
             print(name, k, {c: '%.4g' % (v / cnt[(k, c)]) for c, v in agg[k].items()})
 PY
