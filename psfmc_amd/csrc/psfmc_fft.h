@@ -32,6 +32,22 @@ __device__ __forceinline__ cd cmul(cd a, cd b) {
 }
 __device__ __forceinline__ cd cconj(cd a) { return cd{a.x, -a.y}; }
 
+// 16-byte load of a value that will not be read again by this kernel's launch
+// (streamed once): the non-temporal policy keeps it from displacing data that other
+// kernels of the pipeline are about to re-read from the caches.
+#ifndef PSFMC_NT_LOADS
+#define PSFMC_NT_LOADS 0      /* measured: hurts k_rows_inv (its mirrored re-reads want the cache), neutral elsewhere */
+#endif
+typedef double psfmc_v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cd load_stream(const cd* p) {
+#if PSFMC_NT_LOADS
+    const psfmc_v2d v = __builtin_nontemporal_load(reinterpret_cast<const psfmc_v2d*>(p));
+    return cd{v.x, v.y};
+#else
+    return *p;
+#endif
+}
+
 template <int N> struct FftShape;
 template <> struct FftShape<64>   { static constexpr int P = 8,  T = 8;  };
 template <> struct FftShape<128>  { static constexpr int P = 16, T = 8;  };

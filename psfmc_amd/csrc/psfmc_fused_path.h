@@ -198,7 +198,7 @@ k_cols(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restric
         cd* base = Tbuf + (size_t)pr * 2 * NY + (c << rg_log2) + t_elem(t, 0, rg_log2);
         cd v[P];
 #pragma unroll
-        for (int a = 0; a < P; ++a) v[a] = active ? base[2 * T * a] : cd{0.0, 0.0};
+        for (int a = 0; a < P; ++a) v[a] = active ? load_stream(base + 2 * T * a) : cd{0.0, 0.0};
         fft_wave<NY, -1>(v, tw, twy, t, xbuf, twl);
         if constexpr (CONVOLVE) {
             const int psf = active ? (int)prep[(size_t)w * plen + kPrepPsfIdx] : 0;
@@ -238,17 +238,37 @@ k_rows_inv(const cd* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
     const cd* src = Tbuf + (size_t)w * 2 * NXH * ny + t_elem(iy, 0, __builtin_ctz(RG));
     const size_t kstride = (size_t)2 * ny;
 
-    // Y[k], k = T a + t:  k <= NX/2: G[k] + i H[k];  else conj(G[NX-k]) + i conj(H[NX-k])
+    // Y[k], k = T a + t:  k <= NX/2: G[k] + i H[k];  else conj(G[NX-k]) + i conj(H[NX-k]).
+    // Every (G, H) pair is loaded once, by the lane that owns k <= NX/2; that lane also
+    // forms the mirrored value and hands it to the owner of NX - k (lane (T - t) % T, at
+    // a' = P-1-a for t != 0, P-a for t == 0) through the transform's LDS region.
+    double* wave_lds = smem + (size_t)wave * fused_row_wave_lds_doubles<NX>();
+    cd* mbuf = reinterpret_cast<cd*>(wave_lds + (size_t)f * fft_lds_elems<NX>());   // [P/2][T] complex
     cd v[P];
 #pragma unroll
-    for (int a = 0; a < P; ++a) {
-        const int k = T * a + t;
-        const bool direct = a < P / 2 || (a == P / 2 && t == 0);
-        const cd* p = src + (size_t)(direct ? k : NX - k) * kstride;
-        const cd g = p[0], h = p[RG];
-        v[a] = direct ? cd{g.x - h.y, g.y + h.x} : cd{g.x + h.y, h.x - g.y};
+    for (int a = 0; a < P / 2; ++a) {
+        const cd* p = src + (size_t)(T * a + t) * kstride;
+        const cd g = load_stream(p), h = load_stream(p + RG);
+        v[a] = cd{g.x - h.y, g.y + h.x};
+        mbuf[a * T + t] = cd{g.x + h.y, h.x - g.y};
     }
-    double* wave_lds = smem + (size_t)wave * fused_row_wave_lds_doubles<NX>();
+    {   // Nyquist column k = NX/2 (lane 0 only); the other lanes take a mirror for a = P/2
+        const cd* p = src + (size_t)(NX / 2) * kstride;
+        cd g = cd{0.0, 0.0}, h = cd{0.0, 0.0};
+        if (t == 0) { g = load_stream(p); h = load_stream(p + RG); }
+        v[P / 2] = cd{g.x - h.y, g.y + h.x};
+    }
+    wave_lds_sync();
+    {
+        const int tm = (T - t) % T;
+        const int shift = t ? P - 1 : P;
+#pragma unroll
+        for (int a = P / 2; a < P; ++a) {
+            if (a == P / 2 && t == 0) continue;               // lane 0 holds the Nyquist value
+            v[a] = mbuf[(shift - a) * T + tm];
+        }
+    }
+    wave_lds_sync();
     cd* twl = reinterpret_cast<cd*>(wave_lds + (size_t)RG * fft_lds_elems<NX>());
     cd tw[fft_tw_regs<NX>()];
     load_twiddles<NX>(tw, twx, t, twl, lane);
