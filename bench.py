@@ -369,7 +369,7 @@ def main():
         for _ in range(reps):
             model.log_posterior_batch(theta)
         line['host_path_evals_per_s'] = args.walkers * reps / (time.perf_counter() - t0)
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:      # CPU baseline: rank 0 at N = 1 only
             base, vals = cpu_baseline(args, fld, theta, args.cpu_seconds)
             line['cpu_baseline'] = base
             if multi:
@@ -381,6 +381,7 @@ def main():
         print(json.dumps(line))
     model.close()
     if world > 1:
+        dist.barrier()              # rank 0 may still have been in its profile pass
         dist.destroy_process_group()
 
 
