@@ -102,6 +102,9 @@ struct psfmc_ctx {
     hipStream_t side[kMaxStreams] = {nullptr, nullptr, nullptr, nullptr};   // side[0] unused
     hipEvent_t ev_fork = nullptr, ev_join[kMaxStreams] = {nullptr, nullptr, nullptr, nullptr};
     int n_streams = 2;
+    bool use_graph = false;   // psfmc_stretch_run replays a captured iteration (set_option "graph"; measured: no gain,
+                              // the iteration is kernel-time- not launch-bound)
+    long long graph_launches = 0;
     int min_split = 1 << 30;  // split a single-pass batch over both streams from this size (off: no gain measured)
     // optional per-kernel timing with HIP events (set_option "profile")
     bool profile = false;
@@ -463,10 +466,10 @@ extern "C" int psfmc_ctx_create(psfmc_ctx** out, int device, int ny, int nx, con
         c->rg_log2 = __builtin_ctz(ny / row_tiles);
         c->cols_grid = prop.multiProcessorCount * 2;
         // walkers per internal pass: the transposed half-spectra of one pass
-        // (two passes in flight, together about the 256 MiB Infinity Cache: measured
-        // best at 256^2)
+        // (two passes in flight, together just under the 256 MiB Infinity Cache: measured
+        // best at 256^2 -- 104..120 walkers; 136 and more fall off -- see DESIGN.md)
         const double per_walker = 2.0 * c->nxh * c->ny * 16.0;
-        int chunk = ((int)(128.0 * 1048576.0 / per_walker) + 8) & ~15;
+        int chunk = ((int)(112.0 * 1048576.0 / per_walker) + 8) & ~15;
         if (chunk < 16) chunk = 16;
         c->chunk = chunk;
     } else {
@@ -540,6 +543,10 @@ extern "C" int psfmc_set_option(psfmc_ctx* c, const char* key, double value) {
         c->cols_grid = (int)value;
         return PSFMC_OK;
     }
+    if (!strcmp(key, "graph")) {
+        c->use_graph = value != 0;
+        return PSFMC_OK;
+    }
     if (!strcmp(key, "min_split")) {
         c->min_split = value < 1 ? 1 : (int)value;
         return PSFMC_OK;
@@ -574,6 +581,7 @@ extern "C" double psfmc_get_option(const psfmc_ctx* cc, const char* key) {
         if (!strcmp(key, name)) { prof_collect(c); return (double)c->prof_n[i]; }
     }
     if (!strcmp(key, "row_group")) return 1 << c->rg_log2;
+    if (!strcmp(key, "graph_launches")) return (double)c->graph_launches;
     if (!strcmp(key, "chunk_walkers")) return c->chunk;
     if (!strcmp(key, "backend")) return c->backend;
     if (!strcmp(key, "max_walkers")) return c->max_walkers;
@@ -987,11 +995,11 @@ extern "C" int psfmc_stretch_run(psfmc_ctx* c, int W, int n_iter, double* pos, d
     const size_t n_rand = (size_t)n_iter * W;
     double *d_pos = nullptr, *d_lnp = nullptr, *d_q = nullptr, *d_new = nullptr, *d_rand = nullptr;
     double *d_chain = nullptr, *d_lnchain = nullptr;
-    int* d_partner = nullptr;
+    int *d_partner = nullptr, *d_iter = nullptr;
     long long* d_nacc = nullptr;
     int rc = PSFMC_OK;
     auto cleanup = [&]() {
-        void* bufs[] = {d_pos, d_lnp, d_q, d_new, d_rand, d_chain, d_lnchain, d_partner, d_nacc};
+        void* bufs[] = {d_pos, d_lnp, d_q, d_new, d_rand, d_chain, d_lnchain, d_partner, d_nacc, d_iter};
         for (void* p : bufs)
             if (p) (void)hipFree(p);
     };
@@ -1025,25 +1033,63 @@ extern "C" int psfmc_stretch_run(psfmc_ctx* c, int W, int n_iter, double* pos, d
     else
         rc = eval_theta_device(c, W, d_pos, nullptr, d_lnp, st);
     if (accumulate && rc == PSFMC_OK && !c->d_acc) rc = psfmc_reset_accumulated(c);
-    for (int it = 0; it < n_iter && rc == PSFMC_OK; ++it) {
-        for (int h = 0; h < 2 && rc == PSFMC_OK; ++h) {
-            const size_t off = ((size_t)it * 2 + h) * half;
+    if (accumulate && rc == PSFMC_OK) rc = ensure_image_staging(c);
+    if (accumulate && rc == PSFMC_OK && c->backend == PSFMC_BACKEND_FUSED && !c->d_rawstage)
+        SR_TRY(hipMalloc(&c->d_rawstage, (size_t)c->img_cap * c->S * sizeof(double)));
+    SR_TRY(hipMalloc(&d_iter, sizeof(int)));
+    SR_TRY(hipMemsetAsync(d_iter, 0, sizeof(int), st));
+    // one iteration: two half-ensemble proposals, chain store, optional image sums
+    auto iteration = [&]() -> int {
+        for (int h = 0; h < 2; ++h) {
             hipLaunchKernelGGL(k_stretch_propose, dim3((half * P + 255) / 256), dim3(256), 0, st, d_pos, d_q,
-                               d_rand + off, d_partner + off, half, h, P);
-            rc = eval_theta_device(c, half, d_q, nullptr, d_new, st);
+                               d_rand, d_partner, d_iter, half, h, P);
+            RC_TRY(eval_theta_device(c, half, d_q, nullptr, d_new, st));
             hipLaunchKernelGGL(k_stretch_accept, dim3((half + 127) / 128), dim3(128), 0, st, d_pos, d_lnp, d_q,
-                               d_new, d_rand + n_rand + off, d_rand + 2 * n_rand + off, d_nacc, half, h, P);
+                               d_new, d_rand + n_rand, d_rand + 2 * n_rand, d_nacc, d_iter, half, h, P);
         }
-        if (rc != PSFMC_OK) break;
         if (d_chain)
             hipLaunchKernelGGL(k_stretch_store, dim3((W * P + 255) / 256), dim3(256), 0, st, d_pos, d_lnp,
-                               d_chain, d_lnchain, W, P, it, n_iter);
+                               d_chain, d_lnchain, W, P, d_iter, n_iter);
         if (accumulate) {
             hipLaunchKernelGGL(k_theta_prep, dim3((W + kThetaThreads - 1) / kThetaThreads),
                                dim3(kThetaThreads), c->theta_lds, st, c->layout, d_pos, (const double*)nullptr,
                                (double*)nullptr, c->d_prep, c->d_lnprior, c->d_skip, W, c->ny, c->nx, c->d_rho);
-            rc = accumulate_from_prep(c, W, st);
+            RC_TRY(accumulate_from_prep(c, W, st));
         }
+        hipLaunchKernelGGL(k_stretch_next, dim3(1), dim3(1), 0, st, d_iter);
+        return PSFMC_OK;
+    };
+    // Capture one iteration into a hipGraph and replay it: a 128-walker half-step is
+    // ~10 short launches, and their launch gaps were a third of the iteration.
+    hipGraphExec_t exec = nullptr;
+    if (rc == PSFMC_OK && n_iter > 2 && c->use_graph && !c->profile && c->backend == PSFMC_BACKEND_FUSED) {
+        hipGraph_t graph = nullptr;
+        // un-captured warm-up of the pipeline: one-time attribute calls must not fall
+        // inside the capture
+        rc = eval_theta_device(c, half, d_pos, nullptr, d_new, st);
+        const long long count_before = c->acc_count;
+        if (rc == PSFMC_OK && hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            const int crc = iteration();
+            const hipError_t e = hipStreamEndCapture(st, &graph);
+            if (crc != PSFMC_OK || e != hipSuccess || !graph ||
+                hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess)
+                exec = nullptr;
+            if (graph) (void)hipGraphDestroy(graph);
+        }
+        (void)hipGetLastError();
+        c->acc_count = count_before;            // the captured pass did not run
+    }
+    for (int it = 0; it < n_iter && rc == PSFMC_OK; ++it) {
+        if (exec) {
+            if (hipGraphLaunch(exec, st) != hipSuccess) rc = fail(PSFMC_EHIP, "hipGraphLaunch failed");
+            else { ++c->graph_launches; if (accumulate) c->acc_count += W; }
+        } else {
+            rc = iteration();
+        }
+    }
+    if (exec) {
+        (void)hipStreamSynchronize(st);
+        (void)hipGraphExecDestroy(exec);
     }
     if (rc == PSFMC_OK) {
         SR_TRY(hipMemcpyAsync(pos, d_pos, (size_t)W * P * sizeof(double), hipMemcpyDeviceToHost, st));

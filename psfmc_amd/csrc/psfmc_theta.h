@@ -257,17 +257,20 @@ __global__ void k_finish_posterior(const double* __restrict__ partial, const uin
 // ---------------------------------------------------------------------------
 // q[i] = c[j_i] - z_i (c[j_i] - s_i), s = half `h` of pos, c = the other half.
 // No FMA contraction: the same three roundings as the numpy expression emcee uses.
+// The iteration number is read from device memory (*d_iter) so that one captured
+// hipGraph of an iteration can be replayed for every iteration.
 __global__ void k_stretch_propose(const double* __restrict__ pos, double* __restrict__ q,
                                   const double* __restrict__ z, const int* __restrict__ partner,
-                                  int half, int h, int P) {
+                                  const int* __restrict__ d_iter, int half, int h, int P) {
 #pragma clang fp contract(off)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= half * P) return;
+    const size_t off = ((size_t)*d_iter * 2 + h) * half;
     const int w = i / P, d = i - w * P;
     const double s = pos[(size_t)(h * half + w) * P + d];
-    const double c = pos[(size_t)((1 - h) * half + partner[w]) * P + d];
+    const double c = pos[(size_t)((1 - h) * half + partner[off + w]) * P + d];
     const double diff = c - s;
-    const double step = z[w] * diff;
+    const double step = z[off + w] * diff;
     q[i] = c - step;
 }
 
@@ -275,28 +278,34 @@ __global__ void k_stretch_propose(const double* __restrict__ pos, double* __rest
 __global__ void k_stretch_accept(double* __restrict__ pos, double* __restrict__ lnprob,
                                  const double* __restrict__ q, const double* __restrict__ newlnp,
                                  const double* __restrict__ lz, const double* __restrict__ log_u,
-                                 long long* __restrict__ nacc, int half, int h, int P) {
+                                 long long* __restrict__ nacc, const int* __restrict__ d_iter, int half,
+                                 int h, int P) {
 #pragma clang fp contract(off)
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= half) return;
+    const size_t off = ((size_t)*d_iter * 2 + h) * half;
     const int g = h * half + w;
-    const double diff = (lz[w] + newlnp[w]) - lnprob[g];
-    if (diff > log_u[w]) {
+    const double diff = (lz[off + w] + newlnp[w]) - lnprob[g];
+    if (diff > log_u[off + w]) {
         for (int d = 0; d < P; ++d) pos[(size_t)g * P + d] = q[(size_t)w * P + d];
         lnprob[g] = newlnp[w];
         nacc[g] += 1;
     }
 }
 
-// chain[w][it][:] = pos[w][:], lnchain[w][it] = lnprob[w]
+// chain[w][it][:] = pos[w][:], lnchain[w][it] = lnprob[w]; the last thread advances *d_iter
 __global__ void k_stretch_store(const double* __restrict__ pos, const double* __restrict__ lnprob,
                                 double* __restrict__ chain, double* __restrict__ lnchain, int W, int P,
-                                int it, int n_iter) {
+                                int* __restrict__ d_iter, int n_iter) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= W * P) return;
-    const int w = i / P, d = i - w * P;
-    chain[((size_t)w * n_iter + it) * P + d] = pos[i];
-    if (d == 0) lnchain[(size_t)w * n_iter + it] = lnprob[w];
+    const int it = *d_iter;
+    if (i < W * P && chain) {
+        const int w = i / P, d = i - w * P;
+        chain[((size_t)w * n_iter + it) * P + d] = pos[i];
+        if (d == 0) lnchain[(size_t)w * n_iter + it] = lnprob[w];
+    }
 }
+
+__global__ void k_stretch_next(int* __restrict__ d_iter) { *d_iter += 1; }
 
 }  // namespace psfmc
