@@ -223,4 +223,115 @@ __device__ __forceinline__ void fft_wave(cd (&v)[FftShape<N>::P], const cd (&w)[
     }
 }
 
+// ---------------------------------------------------------------------------
+// Wave-wide three-stage transform for long columns (N = 512, 1024): all 64 lanes of
+// a wave work on ONE transform, N = R1 * 8 * 8, lane t = 8 n2 + n3 holds
+//     v[a] = x[64 a + t]   on entry,   v[e] = X[t + 64 e]   on exit   (a, e < R1)
+// so every load / store instruction of the column kernel is one contiguous run and a
+// lane needs only R1 = 8 or 16 complex registers (the two-stage engine needs 32 for
+// these lengths, which left the column kernel at one wave per SIMD).
+//   stage 1  radix-R1 over a (registers), twiddle W_N^(t k1)
+//   exchange E1[k1][t]                                  (row stride 72 doubles)
+//   stage 2  R1/8 radix-8 DFTs over n2 per lane, twiddle W_64^(n3 k2)
+//   exchange E2[k2][n3][k1]                             (row stride R1+1 doubles)
+//   stage 3  R1/8 radix-8 DFTs over n3 per lane
+//   X[k1 + R1 k2 + 8 R1 k3]: lane t = (k1 + R1 k2) mod 64, e = (k1 + R1 k2)/64 + (R1/8) k3
+// Exchanges go through LDS one component at a time, wave-local (no barriers).
+// ---------------------------------------------------------------------------
+template <int N> struct Fft3Shape { static constexpr int R1 = N / 64; };
+template <int N> constexpr int fft3_lds_doubles() {
+    constexpr int R1 = Fft3Shape<N>::R1;
+    return (R1 * 72 > 64 * (R1 + 1)) ? R1 * 72 : 64 * (R1 + 1);
+}
+
+// per-lane twiddles: w1[k1] = W_N^(t k1) (k1 < R1), w2[k2] = W_N^(R1 n3 k2) (k2 < 8).
+// For R1 = 16 the stage-1 set would cost 64 VGPRs: it is re-read from the (cache
+// resident) table at each use instead.
+template <int N> constexpr int fft3_w1_regs() { return Fft3Shape<N>::R1 <= 8 ? Fft3Shape<N>::R1 : 1; }
+template <int N>
+__device__ __forceinline__ void load_twiddles3(cd (&w1)[fft3_w1_regs<N>()], cd (&w2)[8],
+                                               const cd* __restrict__ table, int t) {
+    constexpr int R1 = Fft3Shape<N>::R1;
+    if constexpr (R1 <= 8) {
+#pragma unroll
+        for (int k = 0; k < R1; ++k) w1[k] = table[t * k];
+    } else {
+        w1[0] = cd{1.0, 0.0};
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w2[k] = table[R1 * (t & 7) * k];
+}
+
+template <int N, int SIGN>
+__device__ __forceinline__ void fft_wave3(cd (&v)[Fft3Shape<N>::R1], const cd (&w1)[fft3_w1_regs<N>()],
+                                          const cd (&w2)[8], const cd* __restrict__ table, int t,
+                                          double* __restrict__ lds) {
+    constexpr int R1 = Fft3Shape<N>::R1, NB = R1 / 8, S1 = 72, S2 = R1 + 1;
+    const int n3 = t & 7, g = t >> 3;
+    // stage 1
+    Dft<R1, SIGN>::run(v);
+#pragma unroll
+    for (int k = 1; k < R1; ++k) {
+        cd wk;
+        if constexpr (R1 <= 8) wk = w1[k]; else wk = table[t * k];
+        v[k] = cmul(v[k], SIGN < 0 ? wk : cconj(wk));
+    }
+    // exchange 1 + stage 2
+    cd z[NB][8];
+#pragma unroll
+    for (int k = 0; k < R1; ++k) lds[k * S1 + t] = v[k].x;
+    wave_lds_sync();
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int n2 = 0; n2 < 8; ++n2) z[i][n2].x = lds[(g + 8 * i) * S1 + n2 * 8 + n3];
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < R1; ++k) lds[k * S1 + t] = v[k].y;
+    wave_lds_sync();
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int n2 = 0; n2 < 8; ++n2) z[i][n2].y = lds[(g + 8 * i) * S1 + n2 * 8 + n3];
+    wave_lds_sync();
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        Dft<8, SIGN>::run(z[i]);
+#pragma unroll
+        for (int k2 = 1; k2 < 8; ++k2) z[i][k2] = cmul(z[i][k2], SIGN < 0 ? w2[k2] : cconj(w2[k2]));
+    }
+    // exchange 2 + stage 3: E2[(k2*8 + n3)][k1], k1 = g + 8 i
+    cd y[NB][8];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) lds[(k2 * 8 + n3) * S2 + g + 8 * i] = z[i][k2].x;
+    wave_lds_sync();
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        const int c = t + 64 * q, k1 = c % R1, k2 = c / R1;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) y[q][m].x = lds[(k2 * 8 + m) * S2 + k1];
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) lds[(k2 * 8 + n3) * S2 + g + 8 * i] = z[i][k2].y;
+    wave_lds_sync();
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        const int c = t + 64 * q, k1 = c % R1, k2 = c / R1;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) y[q][m].y = lds[(k2 * 8 + m) * S2 + k1];
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        Dft<8, SIGN>::run(y[q]);
+#pragma unroll
+        for (int k3 = 0; k3 < 8; ++k3) v[q + NB * k3] = y[q][k3];
+    }
+}
+
 }  // namespace psfmc

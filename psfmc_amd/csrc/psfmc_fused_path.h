@@ -215,6 +215,49 @@ k_cols(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restric
 }
 
 // ---------------------------------------------------------------------------
+// cols3: the column kernel for ny = 512, 1024 on the wave-wide three-stage engine
+// (psfmc_fft.h fft_wave3): one wave per column, 4 waves per workgroup, persistent.
+// ---------------------------------------------------------------------------
+template <int NY> constexpr size_t fused_col3_lds_bytes() {
+    return (size_t)(kColThreads / 64) * fft3_lds_doubles<NY>() * sizeof(double);
+}
+
+template <int NY, bool CONVOLVE>
+__global__ void __launch_bounds__(kColThreads, Fft3Shape<NY>::R1 > 8 ? 1 : 2)
+k_cols3(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restrict__ prep,
+        const uint8_t* __restrict__ skip, const cd* __restrict__ twy, int plen, int nxh, int n_cols,
+        int rg_log2) {
+    constexpr int R1 = Fft3Shape<NY>::R1;
+    constexpr int WPB = kColThreads / 64;
+    extern __shared__ __align__(16) double smem[];
+    const int t = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* lds = smem + (size_t)wave * fft3_lds_doubles<NY>();
+    cd w1[fft3_w1_regs<NY>()], w2[8];
+    load_twiddles3<NY>(w1, w2, twy, t);
+    const int rg = 1 << rg_log2;
+    const int e0 = t_elem(t, 0, rg_log2);              // offset of y = t; y = 64 a + t adds 128 a
+    for (int col = blockIdx.x * WPB + wave; col < n_cols; col += gridDim.x * WPB) {
+        const int pr = col >> 1, c = col & 1;           // (walker, kx) pair, component
+        const int w = pr / nxh, kx = pr - w * nxh;
+        if (skip && skip[w]) continue;                   // wave-uniform
+        cd* base = Tbuf + (size_t)pr * 2 * NY + c * rg + e0;
+        cd v[R1];
+#pragma unroll
+        for (int a = 0; a < R1; ++a) v[a] = base[128 * a];
+        fft_wave3<NY, -1>(v, w1, w2, twy, t, lds);
+        if constexpr (CONVOLVE) {
+            const int psf = (int)prep[(size_t)w * plen + kPrepPsfIdx];
+            const cd* k = Kt + (((size_t)psf * nxh + kx) * 2 + c) * NY;
+#pragma unroll
+            for (int e = 0; e < R1; ++e) v[e] = cmul(v[e], k[t + 64 * e]);
+            fft_wave3<NY, +1>(v, w1, w2, twy, t, lds);
+        }
+#pragma unroll
+        for (int e = 0; e < R1; ++e) base[128 * e] = v[e];
+    }
+}
+
+// ---------------------------------------------------------------------------
 // rows_inv.  grid (ny / RG, n_walkers); one wave per workgroup.
 // partial[w][yg] = sum over the wave's good pixels of the chi^2 term.
 // conv_out / var_out (optional): [n][ny][nx] images (psfmc_eval_images)

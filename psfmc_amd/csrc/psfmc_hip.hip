@@ -102,6 +102,7 @@ struct psfmc_ctx {
     hipStream_t side[kMaxStreams] = {nullptr, nullptr, nullptr, nullptr};   // side[0] unused
     hipEvent_t ev_fork = nullptr, ev_join[kMaxStreams] = {nullptr, nullptr, nullptr, nullptr};
     int n_streams = 2;
+    bool cols3 = true;        // ny >= 512: column kernel on the wave-wide three-stage engine
     bool use_graph = false;   // psfmc_stretch_run replays a captured iteration (set_option "graph"; measured: no gain,
                               // the iteration is kernel-time- not launch-bound)
     long long graph_launches = 0;
@@ -206,6 +207,17 @@ static int launch_rows_fwd(psfmc_ctx* c, int n, const double* prep, const uint8_
 template <int NY, bool CONVOLVE>
 static int launch_cols(psfmc_ctx* c, cd* Tbuf, int n_cols, const double* prep, const uint8_t* skip,
                        hipStream_t st) {
+    if constexpr (NY >= 512) {          // long columns: wave-wide three-stage engine
+        if (c->cols3) {
+            constexpr size_t lds3 = fused_col3_lds_bytes<NY>();
+            const int per_block = kColThreads / 64;
+            const int blocks = (n_cols + per_block - 1) / per_block;
+            const int grid3 = blocks < 4 * c->cols_grid ? blocks : 4 * c->cols_grid;
+            hipLaunchKernelGGL((k_cols3<NY, CONVOLVE>), dim3(grid3), dim3(kColThreads), lds3, st, Tbuf,
+                               c->d_Kt, prep, skip, c->d_twy, c->plen, c->nxh, n_cols, c->rg_log2);
+            return PSFMC_OK;
+        }
+    }
     constexpr size_t lds = fused_col_lds_bytes<NY>();
     static thread_local int attr_device = -1;          // raise the dynamic-LDS limit once per device
     if (attr_device != c->device) {
@@ -541,6 +553,10 @@ extern "C" int psfmc_set_option(psfmc_ctx* c, const char* key, double value) {
     if (!strcmp(key, "cols_grid")) {
         if (value < 1) return fail(PSFMC_EINVAL, "cols_grid must be >= 1");
         c->cols_grid = (int)value;
+        return PSFMC_OK;
+    }
+    if (!strcmp(key, "cols3")) {
+        c->cols3 = value != 0;
         return PSFMC_OK;
     }
     if (!strcmp(key, "graph")) {
