@@ -1,0 +1,113 @@
+"""Randomised GPU-vs-oracle parity: random image shapes (square and rectangular),
+PSF shapes (odd and even), component sets, shift methods, angle units, bad pixels,
+masks, several PSFs -- every draw evaluated by both GPU back ends and by the fp64
+oracle on the same parameters."""
+import numpy as np
+import pytest
+
+import helpers
+import psfmc_oracle as orc
+import synth_field
+
+pytestmark = pytest.mark.gpu
+
+
+def random_case(seed):
+    rng = np.random.RandomState(seed)
+    ny, nx = rng.choice([64, 128, 256]), rng.choice([64, 128, 256])
+    n_psf = rng.choice([1, 1, 2, 3])
+    py, px = rng.choice([9, 16, 21, 32, 33]), rng.choice([9, 16, 21, 32, 33])
+    psfs, pivms = [], []
+    for k in range(n_psf):
+        yy, xx = np.mgrid[0:py, 0:px].astype(float)
+        fw = 1.6 + 0.4 * k + rng.uniform(0, 0.5)
+        core = (1 + ((xx - px // 2 - 0.2 * k) ** 2 + (yy - py // 2 + 0.1) ** 2) / fw ** 2) ** -2.5 * 300
+        var = 0.01 + np.abs(core) / rng.uniform(20, 60)
+        img = core + rng.normal(size=core.shape) * np.sqrt(var)
+        iv = 1.0 / var
+        if rng.rand() < 0.5:
+            iv[rng.randint(py), rng.randint(px)] = 0.0
+        psfs.append(img.astype(np.float32))
+        pivms.append(iv.astype(np.float32))
+    sci = (rng.normal(size=(ny, nx)) * 0.05).astype(np.float32)
+    ivm = (1.0 / rng.uniform(0.02, 0.08, size=(ny, nx)) ** 2).astype(np.float32)
+    for _ in range(rng.randint(0, 6)):
+        ivm[rng.randint(ny), rng.randint(nx)] = rng.choice([0.0, -1.0, np.nan])
+    for _ in range(rng.randint(0, 3)):
+        sci[rng.randint(ny), rng.randint(nx)] = np.nan
+    mask = None
+    if rng.rand() < 0.5:
+        mask = np.zeros((ny, nx), dtype=np.uint8)
+        y0, x0 = rng.randint(ny - 8), rng.randint(nx - 8)
+        mask[y0:y0 + rng.randint(1, 8), x0:x0 + rng.randint(1, 8)] = 1
+    zp = rng.uniform(22, 27)
+    comps = []
+    if rng.rand() < 0.6:
+        comps.append(dict(type='sky', adu=rng.normal() * 0.02))
+    for _ in range(rng.randint(0, 3)):
+        edge = rng.rand() < 0.3
+        xy = (rng.uniform(-3, nx + 3), rng.uniform(-3, ny + 3)) if edge else \
+            (rng.uniform(8, nx - 8), rng.uniform(8, ny - 8))
+        if rng.rand() < 0.2:
+            xy = (np.floor(xy[0]) + rng.choice([0.0, 0.5]), np.floor(xy[1]) + rng.choice([0.0, 0.5]))
+        comps.append(dict(type='ps', xy=xy, mag=rng.uniform(16, 22), method=rng.choice(['lanczos3', 'bilinear'])))
+    for _ in range(rng.randint(0, 4)):
+        reff = rng.uniform(1.5, min(ny, nx) / 6)
+        deg = bool(rng.rand() < 0.5)
+        comps.append(dict(type='sersic', xy=(rng.uniform(10, nx - 10), rng.uniform(10, ny - 10)),
+                          mag=rng.uniform(15, 23), reff=reff, reff_b=reff * rng.uniform(0.2, 1.0),
+                          index=rng.choice([0.5, 1.0, 4.0, rng.uniform(0.3, 8.0)]),
+                          angle=rng.uniform(0, 180) if deg else rng.uniform(-3.2, 3.2), angle_degrees=deg))
+    if not comps:
+        comps.append(dict(type='sky', adu=0.01))
+    psf_index = rng.randint(n_psf)
+    return dict(sci=sci, ivm=ivm, psfs=psfs, pivms=pivms, mask=mask, zp=zp, comps=comps, psf_index=psf_index)
+
+
+def build(case, backend):
+    from psfmc_amd import MultiComponentModel
+    from psfmc_amd.ModelComponents import Configuration, Sky, PointSource, Sersic
+    cfg = Configuration(case['sci'], case['ivm'], case['psfs'] if len(case['psfs']) > 1 else case['psfs'][0],
+                        case['pivms'] if len(case['pivms']) > 1 else case['pivms'][0],
+                        mask_file=case['mask'], mag_zeropoint=case['zp'])
+    objs = [cfg]
+    for c in case['comps']:
+        if c['type'] == 'sky':
+            objs.append(Sky(adu=c['adu']))
+        elif c['type'] == 'ps':
+            objs.append(PointSource(xy=c['xy'], mag=c['mag'], shift_method=c['method']))
+        else:
+            objs.append(Sersic(xy=c['xy'], mag=c['mag'], reff=c['reff'], reff_b=c['reff_b'], index=c['index'],
+                               angle=c['angle'], angle_degrees=c['angle_degrees']))
+    return MultiComponentModel(objs, backend=backend, max_walkers=4)
+
+
+@pytest.mark.parametrize('seed', range(24))
+def test_random_model_matches_oracle(seed):
+    case = random_case(seed)
+    field = orc.make_field(case['sci'], case['ivm'], case['psfs'], case['pivms'], mask=case['mask'],
+                           mag_zp=case['zp'])
+    want, imgs = orc.evaluate(field, case['comps'], case['psf_index'], raw_dtype=np.float64,
+                              want_ps_sub=True)
+    want = want if np.isfinite(want) else -np.inf
+    n_free = 1 if len(case['psfs']) > 1 else 0           # only psf_index is free
+    theta = np.full((2, n_free), float(case['psf_index']))
+    for backend in ('fused', 'hipfft'):
+        model = build(case, backend)
+        got = model.log_likelihood_batch(theta)
+        assert got[0] == got[1]
+        if np.isfinite(want):
+            assert abs(got[0] - want) <= 2e-10 * abs(want), (seed, backend, got[0], want)
+        else:
+            assert got[0] == -np.inf
+        if seed % 4 == 0 and np.isfinite(want):
+            dev = model.sample_images(theta[:1])
+            for kind, ref in imgs.items():
+                fin = np.isfinite(ref)
+                assert np.array_equal(np.isfinite(dev[kind][0]), fin), (seed, backend, kind)
+                scale = max(np.abs(ref[fin]).max(), 1e-300)
+                # the weight map divides by (model variance + obs_var): the packed-FFT
+                # variance channel is good to ~1e-11 of obs_var, not of its own tiny values
+                tol = 1e-9 if kind == 'composite_ivm' else 1e-11
+                assert np.abs(dev[kind][0][fin] - ref[fin]).max() <= tol * scale, (seed, backend, kind)
+        model.close()
