@@ -633,9 +633,14 @@ static int run_pipeline(psfmc_ctx* c, int W, const uint8_t* d_skip, hipStream_t 
     // Fused path: pass i runs on stream i % n_streams with its own T buffer, so the
     // VALU-bound row kernels of one pass overlap the HBM-bound column kernel of its
     // neighbours.  Fork/join on events keeps the caller's stream semantics.
-    // a batch that fits one pass is still split in two so both streams have work
+    // passes of equal size (no short tail), an even number of them when two run at a time
     int chunk = c->chunk;
     if (fused && c->n_streams > 1 && W <= chunk && W / 2 >= c->min_split) chunk = ((W + 1) / 2 + 7) & ~7;
+    if (fused && W > chunk) {
+        int np = (W + chunk - 1) / chunk;
+        if (c->n_streams == 2 && (np & 1)) ++np;
+        chunk = (((W + np - 1) / np) + 3) & ~3;
+    }
     const int npass = (W + chunk - 1) / chunk;
     const int lanes = !fused ? 1 : (npass < c->n_streams ? npass : c->n_streams);
     if (lanes > 1) {
