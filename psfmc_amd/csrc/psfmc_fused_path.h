@@ -32,20 +32,27 @@
 
 namespace psfmc {
 
+// Autonomous waves per row-kernel workgroup (they take consecutive row groups).  One is
+// enough while a wave's RG rows x {model, variance} fill a 128-B line per kx (RG >= 4:
+// nx <= 512; measured no difference between 1, 2 and 4).  At nx = 1024 a wave holds only
+// 2 rows (64-B pieces): four waves of a workgroup then share each line in one CU's L1/L2
+// (k_rows_inv<1024>: 130 -> 105 us).
 #ifndef PSFMC_ROW_WAVES
-#define PSFMC_ROW_WAVES 1
+#define PSFMC_ROW_WAVES 0          /* 0 = choose per shape */
 #endif
-constexpr int kRowWaves = PSFMC_ROW_WAVES;   // autonomous waves per row-kernel workgroup (consecutive row groups)
-constexpr int kRowThreads = 64 * kRowWaves;
 constexpr int kColThreads = 256;     // column kernel: 4 waves, persistent
 
 template <int NX> constexpr int row_group() { return 64 / FftShape<NX>::T; }      // rows per wave
+template <int NX> constexpr int row_waves() {
+    return PSFMC_ROW_WAVES ? PSFMC_ROW_WAVES : (row_group<NX>() >= 4 ? 1 : 4);
+}
+template <int NX> constexpr int row_threads() { return 64 * row_waves<NX>(); }
 // per wave: the exchange regions of its RG transforms, then its twiddle table
 template <int NX> constexpr size_t fused_row_wave_lds_doubles() {
     return (size_t)row_group<NX>() * fft_lds_elems<NX>() + 2 * (size_t)fft_tw_lds_elems<NX>();
 }
 template <int NX> constexpr size_t fused_row_lds_bytes() {
-    return (size_t)kRowWaves * fused_row_wave_lds_doubles<NX>() * sizeof(double);
+    return (size_t)row_waves<NX>() * fused_row_wave_lds_doubles<NX>() * sizeof(double);
 }
 template <int NY> constexpr int col_ffts_per_block() { return kColThreads / FftShape<NY>::T; }
 template <int NY> constexpr size_t fused_col_wave_lds_doubles() {
@@ -91,7 +98,7 @@ __global__ void k_pack_field(const double* __restrict__ sci, const double* __res
 // raw_out (optional): [n][ny][nx] copy of the raw model (psfmc_eval_images)
 // ---------------------------------------------------------------------------
 template <int NX, bool FROM_IMAGE>
-__global__ void __launch_bounds__(kRowThreads, fused_min_waves<NX>())
+__global__ void __launch_bounds__(row_threads<NX>(), fused_min_waves<NX>())
 k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
            const cd* __restrict__ twx, cd* __restrict__ Tbuf, int n_ps, int n_sersic, int ny,
            int ps_only, const double* __restrict__ img, const double* __restrict__ img_scale,
@@ -103,7 +110,7 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
     if (skip && skip[w]) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int f = lane / T, t = lane % T;
-    const int yg = blockIdx.x * kRowWaves + wave;
+    const int yg = blockIdx.x * row_waves<NX>() + wave;
     const int iy = yg * RG + f;
     const size_t S = (size_t)ny * NX;
 
@@ -263,7 +270,7 @@ k_cols3(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restri
 // conv_out / var_out (optional): [n][ny][nx] images (psfmc_eval_images)
 // ---------------------------------------------------------------------------
 template <int NX>
-__global__ void __launch_bounds__(kRowThreads, fused_min_waves<NX>())
+__global__ void __launch_bounds__(row_threads<NX>(), fused_min_waves<NX>())
 k_rows_inv(const cd* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const cd* __restrict__ twx,
            const FieldPx* __restrict__ field, double* __restrict__ partial, int ny,
            const double* __restrict__ prep, int plen,
@@ -276,7 +283,7 @@ k_rows_inv(const cd* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
     if (skip && skip[w]) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int f = lane / T, t = lane % T;
-    const int yg = blockIdx.x * kRowWaves + wave;
+    const int yg = blockIdx.x * row_waves<NX>() + wave;
     const int iy = yg * RG + f;
     const cd* src = Tbuf + (size_t)w * 2 * NXH * ny + t_elem(iy, 0, __builtin_ctz(RG));
     const size_t kstride = (size_t)2 * ny;
@@ -339,7 +346,7 @@ k_rows_inv(const cd* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-    if (lane == 0) partial[(size_t)w * gridDim.x * kRowWaves + yg] = acc;
+    if (lane == 0) partial[(size_t)w * gridDim.x * row_waves<NX>() + yg] = acc;
 }
 
 // Kt[psf][kx][c][ky] = spec_c[psf][ky][kx] * (-1)^(kx+ky) / S from the

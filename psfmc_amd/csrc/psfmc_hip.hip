@@ -198,8 +198,16 @@ static int launch_rows_fwd(psfmc_ctx* c, int n, const double* prep, const uint8_
                            int ps_only, const double* img, const double* img_scale, double* raw_out,
                            hipStream_t st) {
     constexpr size_t lds = fused_row_lds_bytes<NX>();
-    hipLaunchKernelGGL((k_rows_fwd<NX, FROM_IMAGE>), dim3(c->ny / row_group<NX>() / kRowWaves, n),
-                       dim3(kRowThreads), lds, st, prep, skip, c->d_twx, Tbuf, c->n_ps, c->n_sersic,
+    if constexpr (lds > 64 * 1024) {
+        static thread_local int attr_device = -1;
+        if (attr_device != c->device) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows_fwd<NX, FROM_IMAGE>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_device = c->device;
+        }
+    }
+    hipLaunchKernelGGL((k_rows_fwd<NX, FROM_IMAGE>), dim3(c->ny / row_group<NX>() / row_waves<NX>(), n),
+                       dim3(row_threads<NX>()), lds, st, prep, skip, c->d_twx, Tbuf, c->n_ps, c->n_sersic,
                        c->ny, ps_only, img, img_scale, raw_out);
     return PSFMC_OK;
 }
@@ -236,7 +244,15 @@ template <int NX>
 static int launch_rows_inv(psfmc_ctx* c, int n, const cd* Tbuf, const double* prep, const uint8_t* skip,
                            double* partial, double* conv_out, double* var_out, hipStream_t st) {
     constexpr size_t lds = fused_row_lds_bytes<NX>();
-    hipLaunchKernelGGL((k_rows_inv<NX>), dim3(c->ny / row_group<NX>() / kRowWaves, n), dim3(kRowThreads), lds, st,
+    if constexpr (lds > 64 * 1024) {
+        static thread_local int attr_device = -1;
+        if (attr_device != c->device) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows_inv<NX>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_device = c->device;
+        }
+    }
+    hipLaunchKernelGGL((k_rows_inv<NX>), dim3(c->ny / row_group<NX>() / row_waves<NX>(), n), dim3(row_threads<NX>()), lds, st,
                        Tbuf, skip, c->d_twx, c->d_field, partial, c->ny, prep, c->plen, conv_out,
                        var_out);
     return PSFMC_OK;
