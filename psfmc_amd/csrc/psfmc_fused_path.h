@@ -229,8 +229,11 @@ template <int NY> constexpr size_t fused_col3_lds_bytes() {
     return (size_t)(kColThreads / 64) * fft3_lds_doubles<NY>() * sizeof(double);
 }
 
+#ifndef PSFMC_COLS3_WAVES
+#define PSFMC_COLS3_WAVES 2     /* measured at 1024: 1 or 2 -> 178 us, 3 -> 273 us, 4 -> 374 us (spills) */
+#endif
 template <int NY, bool CONVOLVE>
-__global__ void __launch_bounds__(kColThreads, Fft3Shape<NY>::R1 > 8 ? 1 : 2)
+__global__ void __launch_bounds__(kColThreads, Fft3Shape<NY>::R1 > 8 ? PSFMC_COLS3_WAVES : 2)
 k_cols3(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restrict__ prep,
         const uint8_t* __restrict__ skip, const cd* __restrict__ twy, int plen, int nxh, int n_cols,
         int rg_log2) {
@@ -253,11 +256,16 @@ k_cols3(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restri
         for (int a = 0; a < R1; ++a) v[a] = base[128 * a];
         fft_wave3<NY, -1>(v, w1, w2, twy, t, lds);
         if constexpr (CONVOLVE) {
+            // keep the kernel-spectrum loads (and the next column's) out of the transform's
+            // register budget: occupancy, not load hoisting, hides their latency here
+            __builtin_amdgcn_sched_barrier(0);
             const int psf = (int)prep[(size_t)w * plen + kPrepPsfIdx];
             const cd* k = Kt + (((size_t)psf * nxh + kx) * 2 + c) * NY;
 #pragma unroll
             for (int e = 0; e < R1; ++e) v[e] = cmul(v[e], k[t + 64 * e]);
+            __builtin_amdgcn_sched_barrier(0);
             fft_wave3<NY, +1>(v, w1, w2, twy, t, lds);
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int e = 0; e < R1; ++e) base[128 * e] = v[e];
