@@ -22,7 +22,7 @@ from .utils import print_progress
 def model_galaxy_mcmc(model_file, output_name=None, write_fits=default_filetypes, iterations=0,
                       burn=0, chains=None, max_iterations=1,
                       convergence_check=check_convergence_autocorr, sampler_class=None,
-                      device=0, backend='fused', random_state=None, accumulate=True, quiet=False):
+                      device=0, backend='auto', random_state=None, accumulate=True, quiet=False):
     """Model a galaxy's surface brightness with MCMC.
 
     model_file, output_name, write_fits, iterations, burn, chains, max_iterations,

@@ -52,10 +52,11 @@ class MultiComponentModel(object):
     (reference: models.py:9-61).
 
     device / backend / max_walkers configure the GPU context, which is created
-    on first use.
+    on first use.  backend: 'fused' (hand-written FFT kernels; power-of-two sides
+    64...1024), 'hipfft' (any even size) or 'auto' (fused whenever the shape allows).
     """
 
-    def __init__(self, components, device=0, backend='fused', max_walkers=4096):
+    def __init__(self, components, device=0, backend='auto', max_walkers=4096):
         np.seterr(divide='ignore')
         if isinstance(components, str):
             try:
@@ -97,6 +98,10 @@ class MultiComponentModel(object):
         self._sky = [c for c in components if isinstance(c, Sky)]
         self._ps = self.psf_comps
         self._sersic = [c for c in components if isinstance(c, Sersic)]
+        if backend == 'auto':
+            ny, nx = config.obs_data.shape
+            pow2 = all(64 <= n <= 1024 and n & (n - 1) == 0 for n in (ny, nx))
+            backend = 'fused' if pow2 else 'hipfft'
         self._device, self._backend = device, backend
         self._max_walkers = int(max_walkers)
         self._engine = None

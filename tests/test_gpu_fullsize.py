@@ -171,3 +171,36 @@ def test_degenerate_component_sets(backend):
     assert np.all(model.log_posterior_batch(np.array([[2.0], [-1.0], [5.0]])) == -np.inf)
     assert np.isfinite(model.log_posterior_batch(np.array([[0.5]]))).all()
     model.close()
+
+
+def test_hipfft_backend_handles_any_even_size_and_fused_refuses():
+    """Non-power-of-two (even) images: the hipFFT back end evaluates them, the fused one
+    says clearly that it cannot; odd sizes are rejected by the setup like in the reference."""
+    from psfmc_amd import MultiComponentModel, engine
+    from psfmc_amd.ModelComponents import Configuration, Sky, PointSource, Sersic
+    rng = np.random.RandomState(12)
+    ny, nx = 100, 90
+    sci = (rng.normal(size=(ny, nx)) * 0.05).astype(np.float32)
+    ivm = np.full((ny, nx), 400.0, dtype=np.float32)
+    psf = synth_field.moffat_psf(21, fwhm=2.4).astype(np.float32) * 100
+    pivm = (1.0 / (0.01 + np.abs(psf) / 30)).astype(np.float32)
+    comps = [dict(type='sky', adu=0.01), dict(type='ps', xy=(40.3, 52.6), mag=18.0),
+             dict(type='sersic', xy=(47.2, 49.3), mag=17.0, reff=6.0, reff_b=3.5, index=2.2, angle=0.7,
+                  angle_degrees=False)]
+
+    def build(backend):
+        cfg = Configuration(sci, ivm, psf, pivm, mag_zeropoint=24.0)
+        return MultiComponentModel([cfg, Sky(adu=0.01), PointSource(xy=(40.3, 52.6), mag=18.0),
+                                    Sersic(xy=(47.2, 49.3), mag=17.0, reff=6.0, reff_b=3.5, index=2.2,
+                                           angle=0.7)], backend=backend, max_walkers=4)
+    model = build('hipfft')
+    got = model.log_likelihood_batch(np.zeros((2, 0)))
+    field = orc.make_field(sci, ivm, [psf], [pivm], mag_zp=24.0)
+    want = orc.log_likelihood(field, comps, raw_dtype=np.float64)
+    assert abs(got[0] - want) <= 1e-11 * abs(want)
+    model.close()
+    with pytest.raises(engine.NativeError) as err:
+        build('fused').log_likelihood_batch(np.zeros((1, 0)))
+    assert 'power-of-two' in str(err.value)
+    with pytest.raises(ValueError):
+        Configuration(sci[:99], ivm[:99], psf, pivm)
