@@ -238,6 +238,9 @@ def main():
                          'walkers (BASELINE config 5: 64 fields x 256 walkers over 8 GPUs)')
     ap.add_argument('--chunk', type=int, default=0, help='walkers per internal pass (0 = library default)')
     ap.add_argument('--opt', action='append', default=[], help='library option key=value (tuning)')
+    ap.add_argument('--dist-backend', default='nccl',
+                    help="'nccl' (RCCL over xGMI; the real thing) or 'gloo' (rehearsal of the "
+                         "multi-rank path on a box with fewer GPUs than ranks: ranks share devices)")
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--cpu-procs', type=int, default=min(16, os.cpu_count() or 1),
@@ -257,12 +260,17 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (there is no CPU fallback)')
+    if args.dist_backend == 'gloo':          # rehearsal: several ranks may share one device
+        local = local % torch.cuda.device_count()
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a GPU (there is no CPU fallback)')
+        if args.dist_backend == 'gloo':
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
@@ -283,9 +291,15 @@ def main():
     stream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)
 
+    gloo = world > 1 and args.dist_backend == 'gloo'
+    if gloo:
+        gathered = gathered.cpu()
+
     def step():
         eng.loglike_device(args.walkers, rows.data_ptr(), 0, out.data_ptr(), stream.cuda_stream)
-        if world > 1:
+        if gloo:                         # host staging only in the rehearsal back end
+            dist.all_gather_into_tensor(gathered, out.cpu())
+        elif world > 1:
             dist.all_gather_into_tensor(gathered, out)
 
     for _ in range(args.warmup):
@@ -306,9 +320,12 @@ def main():
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if gloo else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        # every rank evaluated the same walkers of the same field: the gathered blocks agree
+        blocks = gathered.reshape(world, args.walkers)
+        assert bool((blocks == blocks[0]).all()), 'ranks disagree on the gathered log-likelihoods'
 
     # sanity: the batch the timing ran on is numerically right
     lnlike = out.cpu().numpy()
