@@ -69,34 +69,34 @@ __device__ inline void ps_window(double c, int n, int method, int* lo, int* cnt)
 // mu ~ 1/peak(raw) (then mu*raw^2 ~ raw) and lambda = mu*rho with rho ~ 1/sum(psf
 // variance map) a per-PSF constant already folded into the kernel spectrum
 // (then lambda*var ~ conv).  `peak` only needs the right order of magnitude.
-__device__ inline void build_prep(const double* __restrict__ row, double* __restrict__ prep,
-                                  int n_ps, int n_sersic, int ny, int nx,
-                                  const double* __restrict__ rho) {
-    prep[0] = row[0];
-    double peak = fabs(row[0]);
-    const double* r = row + kRowSky;
-    double* p = prep + kPrepHead;
-    for (int k = 0; k < n_ps; ++k, r += kRowPs, p += kPrepPs) {
-        const double flux = r[0], x0 = r[1], y0 = r[2];
-        const int method = (int)r[3];
-        int ylo, yn, xlo, xn;
-        ps_window(y0, ny, method, &ylo, &yn);
-        ps_window(x0, nx, method, &xlo, &xn);
-        p[0] = ylo; p[1] = yn; p[2] = xlo; p[3] = xn;
-        for (int t = 0; t < kTaps; ++t) {
-            p[4 + t] = t < yn ? ps_weight((double)(ylo + t) - y0, method) : 0.0;
-            p[4 + kTaps + t] = t < xn ? ps_weight((double)(xlo + t) - x0, method) * flux : 0.0;
-        }
-        peak = fmax(peak, fabs(flux));
+// The three pieces of a prep record.  Each component block is independent of the
+// others (k_theta_prep builds them on different waves); the head needs the largest
+// of the components' peak estimates.
+__device__ inline double prep_ps_block(const double* __restrict__ r, double* __restrict__ p, int ny, int nx) {
+    const double flux = r[0], x0 = r[1], y0 = r[2];
+    const int method = (int)r[3];
+    int ylo, yn, xlo, xn;
+    ps_window(y0, ny, method, &ylo, &yn);
+    ps_window(x0, nx, method, &xlo, &xn);
+    p[0] = ylo; p[1] = yn; p[2] = xlo; p[3] = xn;
+    for (int t = 0; t < kTaps; ++t) {
+        p[4 + t] = t < yn ? ps_weight((double)(ylo + t) - y0, method) : 0.0;
+        p[4 + kTaps + t] = t < xn ? ps_weight((double)(xlo + t) - x0, method) * flux : 0.0;
     }
-    for (int k = 0; k < n_sersic; ++k, r += kRowSersic, p += kPrepSersic) {
-        for (int j = 0; j < kRowSersic; ++j) p[j] = r[j];
-        // brightness half a pixel from the centre along the minor axis
-        const double rho2 = 0.25 * fmax(r[2] * r[2] + r[4] * r[4], r[3] * r[3] + r[5] * r[5]);
-        const double core = r[8] * exp(-r[6] * expm1(log(rho2) * r[7]));
-        if (core == core) peak = fmax(peak, fabs(core));
-    }
-    const int psf = (int)r[0];
+    return fabs(flux);
+}
+
+__device__ inline double prep_sersic_block(const double* __restrict__ r, double* __restrict__ p) {
+    for (int j = 0; j < kRowSersic; ++j) p[j] = r[j];
+    // brightness half a pixel from the centre along the minor axis
+    const double rho2 = 0.25 * fmax(r[2] * r[2] + r[4] * r[4], r[3] * r[3] + r[5] * r[5]);
+    const double core = r[8] * exp(-r[6] * expm1(log(rho2) * r[7]));
+    return core == core ? fabs(core) : 0.0;
+}
+
+__device__ inline void prep_head(double* __restrict__ prep, double sky, int psf, double peak,
+                                 const double* __restrict__ rho) {
+    prep[0] = sky;
     prep[kPrepPsfIdx] = (double)psf;
     double mu = 1.0;
     if (peak > 0.0 && peak < 1e300) {
@@ -107,6 +107,18 @@ __device__ inline void build_prep(const double* __restrict__ row, double* __rest
     const double lambda = mu * (rho ? rho[psf] : 1.0);
     prep[kPrepMu] = mu;
     prep[kPrepInvLambda] = 1.0 / lambda;
+}
+
+__device__ inline void build_prep(const double* __restrict__ row, double* __restrict__ prep,
+                                  int n_ps, int n_sersic, int ny, int nx,
+                                  const double* __restrict__ rho) {
+    double peak = fabs(row[0]);
+    const double* r = row + kRowSky;
+    double* p = prep + kPrepHead;
+    for (int k = 0; k < n_ps; ++k, r += kRowPs, p += kPrepPs) peak = fmax(peak, prep_ps_block(r, p, ny, nx));
+    for (int k = 0; k < n_sersic; ++k, r += kRowSersic, p += kPrepSersic)
+        peak = fmax(peak, prep_sersic_block(r, p));
+    prep_head(prep, row[0], (int)r[0], peak, rho);
 }
 
 // ---------------------------------------------------------------------------
@@ -343,5 +355,20 @@ __device__ inline double block_sum(double v, double* lds /* >= blockDim/64 doubl
     }
     return total;
 }
+
+// Sum of one walker's nblk partial chi^2 sums by the 64 lanes of a wave: lane-strided
+// accumulation, then a butterfly, so every lane holds the total.  ONE summation order
+// for every finishing kernel (k_finish, k_finish_posterior, k_stretch_finish): the
+// host-loop and the device-resident samplers must see the same bits.  (One thread per
+// walker walked nblk dependent strided loads: 13 us for a 128-walker half-ensemble.)
+__device__ inline double wave_sum_partials(const double* __restrict__ p, int nblk, int lane) {
+    double s = 0.0;
+    for (int i = lane; i < nblk; i += 64) s += p[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    return s;
+}
+constexpr int kFinishThreads = 256;                       // 4 waves = 4 walkers per workgroup
+__host__ inline int finish_blocks(int W) { return (W + kFinishThreads / 64 - 1) / (kFinishThreads / 64); }
 
 }  // namespace psfmc

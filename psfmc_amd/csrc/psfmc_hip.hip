@@ -78,6 +78,7 @@ struct psfmc_ctx {
     int ny = 0, nx = 0, nxh = 0, S = 0, F = 0;
     int n_psf = 0, n_ps = 0, n_sersic = 0;
     int max_walkers = 0, chunk = 0, backend = 0;
+    int single_cap = 0;                               // walkers T buffer 0 holds (>= chunk)
     int rlen = 0, plen = 0;
     int nblk = 0;                 // chi^2 partial sums per walker
     hipStream_t stream = nullptr;
@@ -177,8 +178,11 @@ static int alloc_work(psfmc_ctx* c) {
         HIP_TRY(hipMalloc(&c->d_spec, nimg * c->F * sizeof(double2)));
         return use_plans(c, (int)nimg);
     }
+    // buffer 0 also serves batches of up to two chunks that run as ONE pass (run_pipeline)
+    c->single_cap = 2 * c->chunk < c->max_walkers ? 2 * c->chunk : c->max_walkers;
+    if (c->single_cap < c->chunk) c->single_cap = c->chunk;
     for (int i = 0; i < c->n_streams; ++i)
-        HIP_TRY(hipMalloc(&c->d_Ts[i], (size_t)c->chunk * 2 * c->nxh * c->ny * sizeof(cd)));
+        HIP_TRY(hipMalloc(&c->d_Ts[i], (size_t)(i ? c->chunk : c->single_cap) * 2 * c->nxh * c->ny * sizeof(cd)));
     c->d_T = c->d_Ts[0];
     return PSFMC_OK;
 }
@@ -650,12 +654,21 @@ static int run_pipeline(psfmc_ctx* c, int W, const uint8_t* d_skip, hipStream_t 
     // VALU-bound row kernels of one pass overlap the HBM-bound column kernel of its
     // neighbours.  Fork/join on events keeps the caller's stream semantics.
     // passes of equal size (no short tail), an even number of them when two run at a time
+    // A batch of up to two chunks runs as ONE pass: with only two passes the fork/join
+    // between the streams costs more than their overlap gains (256^2, MI355X: W = 128
+    // 148 vs 157 us, W = 224 228 vs 237 us, W = 256 264 vs 269 us, W = 320 353 vs 338 us).
     int chunk = c->chunk;
     if (fused && c->n_streams > 1 && W <= chunk && W / 2 >= c->min_split) chunk = ((W + 1) / 2 + 7) & ~7;
-    if (fused && W > chunk) {
+    if (fused && W > chunk && W <= c->single_cap && c->min_split > W / 2) {
+        chunk = W;
+    } else if (fused && W > chunk) {
         int np = (W + chunk - 1) / chunk;
         if (c->n_streams == 2 && (np & 1)) ++np;
         chunk = (((W + np - 1) / np) + 3) & ~3;
+        // the T buffers hold c->chunk walkers: rounding up must never pass that
+        if (chunk > c->chunk) chunk = c->chunk;
+    } else if (chunk > c->chunk) {
+        chunk = c->chunk;
     }
     const int npass = (W + chunk - 1) / chunk;
     const int lanes = !fused ? 1 : (npass < c->n_streams ? npass : c->n_streams);
@@ -693,20 +706,28 @@ static int eval_device(psfmc_ctx* c, int W, const double* d_rows, const uint8_t*
     hipLaunchKernelGGL(k_prep, dim3((W + 127) / 128), dim3(128), 0, st, d_rows, c->d_prep, W, c->n_ps,
                        c->n_sersic, c->ny, c->nx, c->d_rho);
     RC_TRY(run_pipeline(c, W, d_skip, st));
-    hipLaunchKernelGGL(k_finish, dim3((W + 127) / 128), dim3(128), 0, st, c->d_partial, d_skip, d_like,
+    hipLaunchKernelGGL(k_finish, dim3(finish_blocks(W)), dim3(kFinishThreads), 0, st, c->d_partial, d_skip, d_like,
                        W, c->nblk);
     HIP_TRY(hipGetLastError());
     return PSFMC_OK;
 }
 
+// raw vectors (or, with sp.pos set, stretch-move proposals formed on the fly) -> prep
+// records, log-priors and skip flags of W walkers
+static void launch_theta_prep(psfmc_ctx* c, int W, const double* d_theta, const double* d_extra,
+                              double* d_rows, hipStream_t st, const StretchIn& sp) {
+    hipLaunchKernelGGL(k_theta_prep, dim3((W + kThetaThreads - 1) / kThetaThreads),
+                       dim3(kThetaThreads, theta_task_waves(c->n_ps, c->n_sersic)), c->theta_lds, st,
+                       c->layout, d_theta, d_extra, d_rows, c->d_prep, c->d_lnprior, c->d_skip, W, c->ny,
+                       c->nx, c->d_rho, sp);
+}
+
 // raw vectors -> log-posterior, everything on the device
 static int eval_theta_device(psfmc_ctx* c, int W, const double* d_theta, const double* d_extra,
                              double* d_lnprob, hipStream_t st) {
-    hipLaunchKernelGGL(k_theta_prep, dim3((W + kThetaThreads - 1) / kThetaThreads), dim3(kThetaThreads),
-                       c->theta_lds, st, c->layout, d_theta, d_extra, (double*)nullptr, c->d_prep,
-                       c->d_lnprior, c->d_skip, W, c->ny, c->nx, c->d_rho);
+    launch_theta_prep(c, W, d_theta, d_extra, nullptr, st, StretchIn{});
     RC_TRY(run_pipeline(c, W, c->d_skip, st));
-    hipLaunchKernelGGL(k_finish_posterior, dim3((W + 127) / 128), dim3(128), 0, st, c->d_partial, c->d_skip,
+    hipLaunchKernelGGL(k_finish_posterior, dim3(finish_blocks(W)), dim3(kFinishThreads), 0, st, c->d_partial, c->d_skip,
                        c->d_lnprior, d_lnprob, W, c->nblk);
     HIP_TRY(hipGetLastError());
     return PSFMC_OK;
@@ -929,9 +950,7 @@ extern "C" int psfmc_debug_theta_rows(psfmc_ctx* c, int W, const double* theta, 
         HIP_TRY(hipMemcpyAsync(c->d_theta, theta, (size_t)W * c->layout.n_params * sizeof(double),
                                hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(c->d_rows, 0, (size_t)W * c->rlen * sizeof(double), st));
-    hipLaunchKernelGGL(k_theta_prep, dim3((W + kThetaThreads - 1) / kThetaThreads), dim3(kThetaThreads),
-                       c->theta_lds, st, c->layout, c->d_theta, (const double*)nullptr, c->d_rows, c->d_prep,
-                       c->d_lnprior, c->d_skip, W, c->ny, c->nx, c->d_rho);
+    launch_theta_prep(c, W, c->d_theta, nullptr, c->d_rows, st, StretchIn{});
     HIP_TRY(hipMemcpyAsync(rows, c->d_rows, (size_t)W * c->rlen * sizeof(double), hipMemcpyDeviceToHost, st));
     if (lnprior) HIP_TRY(hipMemcpyAsync(lnprior, c->d_lnprior, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, st));
     if (skip) HIP_TRY(hipMemcpyAsync(skip, c->d_skip, (size_t)W, hipMemcpyDeviceToHost, st));
@@ -1075,31 +1094,36 @@ extern "C" int psfmc_stretch_run(psfmc_ctx* c, int W, int n_iter, double* pos, d
         SR_TRY(hipMalloc(&c->d_rawstage, (size_t)c->img_cap * c->S * sizeof(double)));
     SR_TRY(hipMalloc(&d_iter, sizeof(int)));
     SR_TRY(hipMemsetAsync(d_iter, 0, sizeof(int), st));
-    // one iteration: two half-ensemble proposals, chain store, optional image sums
+    // one iteration: two half-ensemble proposals (chain entries included), optional image
+    // sums.  The kernels take the iteration number by value, or from *d_iter when one
+    // captured iteration is replayed as a hipGraph.
+    const bool use_d_iter = n_iter > 2 && c->use_graph && !c->profile && c->backend == PSFMC_BACKEND_FUSED;
+    int it_host = 0;
     auto iteration = [&]() -> int {
+        // a half-step is three stages: proposals + priors + prep records (one kernel), the
+        // likelihood pipeline, and sum + accept + move + chain entry (one kernel)
         for (int h = 0; h < 2; ++h) {
-            hipLaunchKernelGGL(k_stretch_propose, dim3((half * P + 255) / 256), dim3(256), 0, st, d_pos, d_q,
-                               d_rand, d_partner, d_iter, half, h, P);
-            RC_TRY(eval_theta_device(c, half, d_q, nullptr, d_new, st));
-            hipLaunchKernelGGL(k_stretch_accept, dim3((half + 127) / 128), dim3(128), 0, st, d_pos, d_lnp, d_q,
-                               d_new, d_rand + n_rand, d_rand + 2 * n_rand, d_nacc, d_iter, half, h, P);
+            launch_theta_prep(c, half, nullptr, nullptr, nullptr, st,
+                              StretchIn{d_pos, d_q, d_rand, d_partner, use_d_iter ? d_iter : nullptr, it_host,
+                                        half, h});
+            RC_TRY(run_pipeline(c, half, c->d_skip, st));
+            hipLaunchKernelGGL(k_stretch_finish, dim3(finish_blocks(half)), dim3(kFinishThreads), 0, st, c->d_partial,
+                               c->d_skip, c->d_lnprior, c->nblk, d_pos, d_lnp, d_q, d_rand + n_rand,
+                               d_rand + 2 * n_rand, d_nacc, d_chain, d_lnchain,
+                               use_d_iter ? d_iter : nullptr, it_host, n_iter, half, h, P);
         }
-        if (d_chain)
-            hipLaunchKernelGGL(k_stretch_store, dim3((W * P + 255) / 256), dim3(256), 0, st, d_pos, d_lnp,
-                               d_chain, d_lnchain, W, P, d_iter, n_iter);
         if (accumulate) {
-            hipLaunchKernelGGL(k_theta_prep, dim3((W + kThetaThreads - 1) / kThetaThreads),
-                               dim3(kThetaThreads), c->theta_lds, st, c->layout, d_pos, (const double*)nullptr,
-                               (double*)nullptr, c->d_prep, c->d_lnprior, c->d_skip, W, c->ny, c->nx, c->d_rho);
+            launch_theta_prep(c, W, d_pos, nullptr, nullptr, st, StretchIn{});
             RC_TRY(accumulate_from_prep(c, W, st));
         }
-        hipLaunchKernelGGL(k_stretch_next, dim3(1), dim3(1), 0, st, d_iter);
+        if (use_d_iter) hipLaunchKernelGGL(k_stretch_next, dim3(1), dim3(1), 0, st, d_iter);
+        ++it_host;
         return PSFMC_OK;
     };
     // Capture one iteration into a hipGraph and replay it: a 128-walker half-step is
     // ~10 short launches, and their launch gaps were a third of the iteration.
     hipGraphExec_t exec = nullptr;
-    if (rc == PSFMC_OK && n_iter > 2 && c->use_graph && !c->profile && c->backend == PSFMC_BACKEND_FUSED) {
+    if (rc == PSFMC_OK && use_d_iter) {
         hipGraph_t graph = nullptr;
         // un-captured warm-up of the pipeline: one-time attribute calls must not fall
         // inside the capture

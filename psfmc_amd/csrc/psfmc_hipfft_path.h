@@ -85,15 +85,16 @@ k_chi2(const double* __restrict__ real, const double* __restrict__ sci,
     if (threadIdx.x == 0) partial[(size_t)w * gridDim.x + blockIdx.x] = tot;
 }
 
-// loglike[w] = -0.5 * sum(partials) in a fixed order; skipped walkers -> -inf
+// loglike[w] = -0.5 * sum(partials) in a fixed order; skipped walkers -> -inf.
+// One wave per walker (launch: finish_blocks(W) x kFinishThreads).
 __global__ void k_finish(const double* __restrict__ partial, const uint8_t* __restrict__ skip,
                          double* __restrict__ loglike, int W, int nblk) {
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * (kFinishThreads / 64) + (threadIdx.x >> 6);
     if (w >= W) return;
-    if (skip && skip[w]) { loglike[w] = -INFINITY; return; }
-    double s = 0.0;
-    for (int i = 0; i < nblk; ++i) s += partial[(size_t)w * nblk + i];
-    loglike[w] = -0.5 * s;
+    if (skip && skip[w]) { if (lane == 0) loglike[w] = -INFINITY; return; }
+    const double s = wave_sum_partials(partial + (size_t)w * nblk, nblk, lane);
+    if (lane == 0) loglike[w] = -0.5 * s;
 }
 
 // centre-pad a small image into an [ny][nx] canvas at offset pad/2 (utils.py:19-21)

@@ -37,16 +37,22 @@ struct ThetaLayout {
 // regularised lower incomplete gamma P(a, x), series form (valid and fast for
 // x < a + 1, which brackets the median), and its inverse at 1/2
 // ---------------------------------------------------------------------------
-// log of x^a e^-x / Gamma(a+1)
-__device__ inline double igam_log_prefactor(double a, double x) {
-    if (a < 20.0) return a * log(x) - x - lgamma(a + 1.0);
+// log of x^a e^-x / Gamma(a+1).  `lg1` = lgamma(a + 1) (a < 20) or the Stirling
+// tail of ln Gamma(a + 1) (a >= 20), from igam_lgamma_term: it depends on a only, so
+// an iteration over x computes it once.
+__device__ inline double igam_lgamma_term(double a) {
+    if (a < 20.0) return lgamma(a + 1.0);
     // Gamma(a+1) = sqrt(2 pi a) (a/e)^a exp(corr(a)):  avoids the cancellation of
     // a ln x - x against lgamma for large a
-    const double u = (x - a) / a;
     const double ia = 1.0 / a, ia2 = ia * ia;
     const double corr = ia * (1.0 / 12.0 + ia2 * (-1.0 / 360.0 + ia2 * (1.0 / 1260.0 + ia2 *
                         (-1.0 / 1680.0 + ia2 * (1.0 / 1188.0 + ia2 * (-691.0 / 360360.0))))));
-    return a * (log1p(u) - u) - 0.5 * log(6.28318530717958647693 * a) - corr;
+    return 0.5 * log(6.28318530717958647693 * a) + corr;
+}
+__device__ inline double igam_log_prefactor(double a, double x, double lg1) {
+    if (a < 20.0) return a * log(x) - x - lg1;
+    const double u = (x - a) / a;
+    return a * (log1p(u) - u) - lg1;
 }
 
 __device__ inline double igam_series(double a, double x) {        // P(a, x)
@@ -57,7 +63,7 @@ __device__ inline double igam_series(double a, double x) {        // P(a, x)
         sum += term;
         if (term < 1e-17 * sum) break;
     }
-    return sum * exp(igam_log_prefactor(a, x));
+    return sum * exp(igam_log_prefactor(a, x, igam_lgamma_term(a)));
 }
 
 // kappa = gammaincinv(a, 1/2), a = 2n > 0
@@ -71,11 +77,12 @@ __device__ inline double gamma_median(double a) {
         x = a - 1.0 / 3.0 + i * (4.0 / 405.0 + i * (46.0 / 25515.0 + i * (131.0 / 1148175.0 -
             i * (2194697.0 / 30690717750.0))));
     }
+    const double lg1 = igam_lgamma_term(a);
     // Halley on P(a, x) = 1/2: cubic convergence, so a step below 1e-6 x leaves an
     // error of order 1e-18 x and the iteration stops there (the starting values are
     // good to 1e-3 ... 1e-9, i.e. one or two steps)
     for (int it = 0; it < 12; ++it) {
-        const double pre = exp(igam_log_prefactor(a, x));         // x^a e^-x / Gamma(a+1)
+        const double pre = exp(igam_log_prefactor(a, x, lg1));    // x^a e^-x / Gamma(a+1)
         double term = 1.0, sum = 1.0, ap = a;
         for (int k = 0; k < 2000; ++k) {
             ap += 1.0;
@@ -126,19 +133,23 @@ __device__ inline double prior_logp(int fam, double x, double a, double b, doubl
     }
 }
 
-// One thread per walker: joint log-prior (device families + the host's extra),
-// non-finite -> skip; otherwise derive the caller row and expand it to the prep
-// record.  `row` is scratch of row_len doubles for this walker.
-__device__ inline void theta_to_prep(const ThetaLayout& L, const double* __restrict__ theta,
-                                     double extra, double* __restrict__ row, double* __restrict__ prep,
-                                     double* lnprior_out, uint8_t* skip_out, int ny, int nx,
-                                     const double* __restrict__ rho) {
+// The work of one walker is split into independent TASKS that run on different waves
+// of the workgroup (blockDim = (64 walkers, n tasks)): one walker per thread left the
+// whole GPU with two waves crawling through ~9000 dependent fp64 instructions (35 us
+// for a 128-walker half-ensemble, a sixth of an MCMC half-step).
+//   task 0              joint log-prior (device families + the host's extra), support
+//                       and axis-ratio checks -> lnprior, skip; sky and PSF index
+//   task 1 + k          PointSource k: flux, Lanczos / bilinear window -> prep block
+//   task 1 + n_ps + k   Sersic k: ellipse matrix, kappa, Sigma_e -> prep block
+// then task 0 writes the head of the prep record from the largest peak estimate.
+// Walkers outside the prior support get skip = 1; their prep record is scratch.
+__device__ inline double theta_slot(const ThetaLayout& L, const double* __restrict__ theta, int s) {
+    const int col = L.slot_col[s];
+    return col >= 0 ? theta[col] : L.slot_const[s];
+}
+
+__device__ inline double theta_log_prior(const ThetaLayout& L, const double* __restrict__ theta, double extra) {
     double lp = extra;
-    const int ns = n_slots(L.n_sky, L.n_ps, L.n_sersic);
-    auto slot = [&](int s) -> double {
-        const int col = L.slot_col[s];
-        return col >= 0 ? theta[col] : L.slot_const[s];
-    };
     for (int p = 0; p < L.n_params; ++p) {
         const int fam = L.family[p];
         if (fam == PRIOR_HOST) continue;
@@ -148,161 +159,233 @@ __device__ inline void theta_to_prep(const ThetaLayout& L, const double* __restr
     // Sersic axis-ratio constraint (Sersic.py:41-45)
     for (int k = 0; k < L.n_sersic; ++k) {
         const int s0 = L.n_sky + 3 * L.n_ps + 7 * k;
-        if (slot(s0 + 4) > slot(s0 + 3)) lp = -INFINITY;
+        if (theta_slot(L, theta, s0 + 4) > theta_slot(L, theta, s0 + 3)) lp = -INFINITY;
     }
-    *lnprior_out = lp;
-    const bool ok = lp == lp && fabs(lp) != INFINITY;        // finite
-    *skip_out = ok ? 0 : 1;
-    if (!ok) return;
-    double sky = 0.0;
-    for (int k = 0; k < L.n_sky; ++k) sky += slot(k);
-    row[0] = sky;
-    double* r = row + kRowSky;
-    for (int k = 0; k < L.n_ps; ++k, r += kRowPs) {
-        const int s0 = L.n_sky + 3 * k;
-        r[0] = pow(10.0, -0.4 * (slot(s0) - L.mag_zp));
-        r[1] = slot(s0 + 1);
-        r[2] = slot(s0 + 2);
-        r[3] = (double)L.ps_method[k];
-    }
-    for (int k = 0; k < L.n_sersic; ++k, r += kRowSersic) {
-        const int s0 = L.n_sky + 3 * L.n_ps + 7 * k;
-        const double ang = slot(s0), n = slot(s0 + 1), mag = slot(s0 + 2);
-        const double re = slot(s0 + 3), rb = slot(s0 + 4);
-        const double th = (L.sersic_deg[k] ? ang * (M_PI / 180.0) : ang) + 0.5 * M_PI;
-        const double sn = sin(th), cs = cos(th);
-        const double kappa = gamma_median(2.0 * n);
-        r[0] = slot(s0 + 5);
-        r[1] = slot(s0 + 6);
-        r[2] = cs / re;
-        r[3] = sn / re;
-        r[4] = -sn / rb;
-        r[5] = cs / rb;
-        r[6] = kappa;
-        r[7] = 0.5 / n;
-        r[8] = sersic_sb_eff(pow(10.0, -0.4 * (mag - L.mag_zp)), n, re, rb, kappa);
-    }
-    double psf = rint(slot(ns - 1));
-    psf = psf < 0.0 ? 0.0 : (psf > (double)(L.n_psf - 1) ? (double)(L.n_psf - 1) : psf);
-    r[0] = psf;
-    build_prep(row, prep, L.n_ps, L.n_sersic, ny, nx, rho);
+    return lp;
 }
 
-// LDS bytes of k_theta_prep: the layout tables, and per thread its parameter vector
-// and its derived row (the walk through the slots is a long chain of dependent small
-// loads: from global memory it cost 45 us per call, from LDS it is a few us)
-constexpr int kThetaThreads = 64;
+// row pieces (the caller-row layout of include/psfmc_hip.h)
+__device__ inline void theta_ps_row(const ThetaLayout& L, const double* __restrict__ theta, int k,
+                                    double* __restrict__ r) {
+    const int s0 = L.n_sky + 3 * k;
+    r[0] = pow(10.0, -0.4 * (theta_slot(L, theta, s0) - L.mag_zp));
+    r[1] = theta_slot(L, theta, s0 + 1);
+    r[2] = theta_slot(L, theta, s0 + 2);
+    r[3] = (double)L.ps_method[k];
+}
+
+__device__ inline void theta_sersic_row(const ThetaLayout& L, const double* __restrict__ theta, int k,
+                                        double* __restrict__ r) {
+    const int s0 = L.n_sky + 3 * L.n_ps + 7 * k;
+    const double ang = theta_slot(L, theta, s0), n = theta_slot(L, theta, s0 + 1);
+    const double mag = theta_slot(L, theta, s0 + 2);
+    const double re = theta_slot(L, theta, s0 + 3), rb = theta_slot(L, theta, s0 + 4);
+    const double th = (L.sersic_deg[k] ? ang * (M_PI / 180.0) : ang) + 0.5 * M_PI;
+    const double sn = sin(th), cs = cos(th);
+    const double kappa = gamma_median(2.0 * n);
+    r[0] = theta_slot(L, theta, s0 + 5);
+    r[1] = theta_slot(L, theta, s0 + 6);
+    r[2] = cs / re;
+    r[3] = sn / re;
+    r[4] = -sn / rb;
+    r[5] = cs / rb;
+    r[6] = kappa;
+    r[7] = 0.5 / n;
+    r[8] = sersic_sb_eff(pow(10.0, -0.4 * (mag - L.mag_zp)), n, re, rb, kappa);
+}
+
+// Stretch-move proposal formed while the parameter tile is loaded (pos != nullptr):
+// q[i] = c[j_i] - z_i (c[j_i] - s_i), s = half `h` of pos, c = the other half
+// (Goodman & Weare 2010; emcee 2.2.1 `_propose_stretch`).  No FMA contraction: the
+// same three roundings as the numpy expression emcee uses.  The iteration number
+// comes from *d_iter when a captured hipGraph of one iteration is replayed, else `it`.
+struct StretchIn {
+    const double* pos;      // [2 half][P] current positions, or nullptr: theta is given
+    double* q;              // [half][P] proposals (kept for the accept step)
+    const double* z;        // [n_iter][2][half]
+    const int* partner;     // [n_iter][2][half]
+    const int* d_iter;
+    int it, half, h;
+};
+
+__device__ inline double stretch_point(double s, double c, double z) {
+#pragma clang fp contract(off)
+    const double diff = c - s;
+    const double step = z * diff;
+    return c - step;
+}
+
+// LDS bytes of k_theta_prep: the layout tables, per walker its parameter vector and
+// its derived row (the walk through the slots is a long chain of dependent small
+// loads: from global memory it cost 45 us per call, from LDS it is a few us), and
+// the components' peak estimates
+constexpr int kThetaThreads = 64;       // walkers per workgroup
+constexpr int kThetaMaxTasks = 4;       // waves per workgroup; further tasks loop
+__host__ inline int theta_task_waves(int n_ps, int n_sersic) {
+    const int t = 1 + n_ps + n_sersic;
+    return t > kThetaMaxTasks ? kThetaMaxTasks : t;
+}
 __host__ inline size_t theta_prep_lds_bytes(int n_sky, int n_ps, int n_sersic, int n_params) {
     const size_t ns = n_slots(n_sky, n_ps, n_sersic);
     const size_t n_int = ((ns + n_ps + n_sersic + n_params + 1) / 2) * 2;           // 8-byte multiple
     const size_t n_dbl = ns + 3 * (size_t)n_params;
-    return n_int * sizeof(int) + (n_dbl + (size_t)kThetaThreads * (n_params + row_len(n_ps, n_sersic))) *
-                                     sizeof(double);
+    return n_int * sizeof(int) +
+           (n_dbl + (size_t)kThetaThreads * (n_params + row_len(n_ps, n_sersic) + n_ps + n_sersic)) *
+               sizeof(double);
 }
 
-__global__ void __launch_bounds__(kThetaThreads)
+__global__ void __launch_bounds__(kThetaThreads * kThetaMaxTasks)
 k_theta_prep(ThetaLayout G, const double* __restrict__ theta,
              const double* __restrict__ extra, double* __restrict__ rows,
              double* __restrict__ prep, double* __restrict__ lnprior,
              uint8_t* __restrict__ skip, int W, int ny, int nx,
-             const double* __restrict__ rho) {
+             const double* __restrict__ rho, StretchIn sp) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int ns = n_slots(G.n_sky, G.n_ps, G.n_sersic);
     const int n_int = ((ns + G.n_ps + G.n_sersic + G.n_params + 1) / 2) * 2;
     const int n_dbl = ns + 3 * G.n_params;
     const int rlen = row_len(G.n_ps, G.n_sersic);
+    const int P = G.n_params;
     int* li = reinterpret_cast<int*>(lds_raw);
     double* ld = reinterpret_cast<double*>(lds_raw + (size_t)n_int * sizeof(int));
     double* th_tile = ld + n_dbl;
-    double* row_tile = th_tile + (size_t)kThetaThreads * G.n_params;
+    double* row_tile = th_tile + (size_t)kThetaThreads * P;
+    double* peak_tile = row_tile + (size_t)kThetaThreads * rlen;       // [component][walker]
+    const int tid = threadIdx.y * kThetaThreads + threadIdx.x, nthr = kThetaThreads * blockDim.y;
     // the four int tables and the four double tables are contiguous in the blob
-    for (int i = threadIdx.x; i < ns + G.n_ps + G.n_sersic + G.n_params; i += kThetaThreads) li[i] = G.slot_col[i];
-    for (int i = threadIdx.x; i < n_dbl; i += kThetaThreads) ld[i] = G.slot_const[i];
+    for (int i = tid; i < ns + G.n_ps + G.n_sersic + P; i += nthr) li[i] = G.slot_col[i];
+    for (int i = tid; i < n_dbl; i += nthr) ld[i] = G.slot_const[i];
     const int w0 = blockIdx.x * kThetaThreads;
     const int n_here = W - w0 < kThetaThreads ? W - w0 : kThetaThreads;
-    for (int i = threadIdx.x; i < n_here * G.n_params; i += kThetaThreads)      // coalesced tile load
-        th_tile[i] = theta[(size_t)w0 * G.n_params + i];
+    if (sp.pos) {                                                   // propose into the tile
+        const int it = sp.d_iter ? *sp.d_iter : sp.it;
+        const size_t off = ((size_t)it * 2 + sp.h) * sp.half;
+        for (int i = tid; i < n_here * P; i += nthr) {
+            const int lw = i / P, d = i - lw * P, w = w0 + lw;
+            const double s = sp.pos[(size_t)(sp.h * sp.half + w) * P + d];
+            const double c = sp.pos[(size_t)((1 - sp.h) * sp.half + sp.partner[off + w]) * P + d];
+            const double q = stretch_point(s, c, sp.z[off + w]);
+            th_tile[i] = q;
+            sp.q[(size_t)w0 * P + i] = q;
+        }
+    } else {
+        for (int i = tid; i < n_here * P; i += nthr)                // coalesced tile load
+            th_tile[i] = theta[(size_t)w0 * P + i];
+    }
     __syncthreads();
     ThetaLayout L = G;
     L.slot_col = li; L.ps_method = li + ns; L.sersic_deg = li + ns + G.n_ps;
     L.family = li + ns + G.n_ps + G.n_sersic;
-    L.slot_const = ld; L.pa = ld + ns; L.pb = ld + ns + G.n_params; L.pc = ld + ns + 2 * G.n_params;
-    const int w = w0 + threadIdx.x;
-    if (w >= W) return;
-    double* row = row_tile + (size_t)threadIdx.x * rlen;
-    theta_to_prep(L, th_tile + (size_t)threadIdx.x * G.n_params, extra ? extra[w] : 0.0, row,
-                  prep + (size_t)w * prep_len(G.n_ps, G.n_sersic), lnprior + w, skip + w, ny, nx, rho);
-    if (rows) {
+    L.slot_const = ld; L.pa = ld + ns; L.pb = ld + ns + P; L.pc = ld + ns + 2 * P;
+    const int lw = threadIdx.x, w = w0 + lw;
+    const bool active = w < W;
+    const double* th = th_tile + (size_t)lw * P;
+    double* row = row_tile + (size_t)lw * rlen;
+    double* my_prep = prep + (size_t)(active ? w : 0) * prep_len(G.n_ps, G.n_sersic);
+    const int n_tasks = 1 + G.n_ps + G.n_sersic;
+    bool ok = false;
+    for (int task = threadIdx.y; task < n_tasks; task += blockDim.y) {      // wave-uniform
+        if (!active) continue;
+        if (task == 0) {
+            const double lp = theta_log_prior(L, th, extra ? extra[w] : 0.0);
+            ok = lp == lp && fabs(lp) != INFINITY;                          // finite
+            lnprior[w] = lp;
+            skip[w] = ok ? 0 : 1;
+            double sky = 0.0;
+            for (int k = 0; k < L.n_sky; ++k) sky += theta_slot(L, th, k);
+            row[0] = sky;
+            double psf = rint(theta_slot(L, th, ns - 1));
+            psf = psf < 0.0 ? 0.0 : (psf > (double)(L.n_psf - 1) ? (double)(L.n_psf - 1) : psf);
+            row[rlen - 1] = psf;
+        } else if (task <= G.n_ps) {
+            const int k = task - 1;
+            double* r = row + kRowSky + kRowPs * k;
+            theta_ps_row(L, th, k, r);
+            peak_tile[k * kThetaThreads + lw] = prep_ps_block(r, my_prep + kPrepHead + kPrepPs * k, ny, nx);
+        } else {
+            const int k = task - 1 - G.n_ps;
+            double* r = row + kRowSky + kRowPs * G.n_ps + kRowSersic * k;
+            theta_sersic_row(L, th, k, r);
+            peak_tile[(G.n_ps + k) * kThetaThreads + lw] =
+                prep_sersic_block(r, my_prep + kPrepHead + kPrepPs * G.n_ps + kPrepSersic * k);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.y != 0 || !active) return;
+    double peak = fabs(row[0]);
+    for (int k = 0; k < G.n_ps + G.n_sersic; ++k) peak = fmax(peak, peak_tile[k * kThetaThreads + lw]);
+    prep_head(my_prep, row[0], (int)row[rlen - 1], peak, rho);
+    if (rows && ok) {
         double* out = rows + (size_t)w * rlen;
         for (int i = 0; i < rlen; ++i) out[i] = row[i];
     }
 }
 
-// lnprob[w] = loglike + lnprior, non-finite likelihood -> -inf (models.py:238-243)
+// lnprob = loglike + lnprior, non-finite likelihood -> -inf (models.py:238-243); all
+// lanes of the walker's wave get the value
+__device__ inline double walker_lnprob(const double* __restrict__ partial, const uint8_t* __restrict__ skip,
+                                       const double* __restrict__ lnprior, int nblk, int w, int lane) {
+    if (skip[w]) return -INFINITY;
+    const double ll = -0.5 * wave_sum_partials(partial + (size_t)w * nblk, nblk, lane);
+    const bool fin = ll == ll && fabs(ll) != INFINITY;
+    return fin ? ll + lnprior[w] : -INFINITY;
+}
+
+// one wave per walker (launch: finish_blocks(W) x kFinishThreads)
 __global__ void k_finish_posterior(const double* __restrict__ partial, const uint8_t* __restrict__ skip,
                                    const double* __restrict__ lnprior, double* __restrict__ lnprob,
                                    int W, int nblk) {
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * (kFinishThreads / 64) + (threadIdx.x >> 6);
     if (w >= W) return;
-    if (skip[w]) { lnprob[w] = -INFINITY; return; }
-    double s = 0.0;
-    for (int i = 0; i < nblk; ++i) s += partial[(size_t)w * nblk + i];
-    const double ll = -0.5 * s;
-    const bool fin = ll == ll && fabs(ll) != INFINITY;
-    lnprob[w] = fin ? ll + lnprior[w] : -INFINITY;
+    const double lp = walker_lnprob(partial, skip, lnprior, nblk, w, lane);
+    if (lane == 0) lnprob[w] = lp;
 }
 
 // ---------------------------------------------------------------------------
-// stretch move (Goodman & Weare 2010; emcee 2.2.1 `_propose_stretch`)
+// stretch move, second half of a half-step: the proposals' log-posteriors
+// (k_finish_posterior's sum), acceptance where lz + newlnp - lnp > ln u (emcee 2.2.1
+// `_propose_stretch`), the move, and the chain entry of this half's walkers -- the
+// other half's positions do not change during this half-step, so iteration `it` of
+// walker g is final after the half-step that owns g.  One wave per walker (launch:
+// finish_blocks(half) x kFinishThreads).
 // ---------------------------------------------------------------------------
-// q[i] = c[j_i] - z_i (c[j_i] - s_i), s = half `h` of pos, c = the other half.
-// No FMA contraction: the same three roundings as the numpy expression emcee uses.
-// The iteration number is read from device memory (*d_iter) so that one captured
-// hipGraph of an iteration can be replayed for every iteration.
-__global__ void k_stretch_propose(const double* __restrict__ pos, double* __restrict__ q,
-                                  const double* __restrict__ z, const int* __restrict__ partner,
-                                  const int* __restrict__ d_iter, int half, int h, int P) {
+__global__ void k_stretch_finish(const double* __restrict__ partial, const uint8_t* __restrict__ skip,
+                                 const double* __restrict__ lnprior, int nblk,
+                                 double* __restrict__ pos, double* __restrict__ lnprob,
+                                 const double* __restrict__ q, const double* __restrict__ lz,
+                                 const double* __restrict__ log_u, long long* __restrict__ nacc,
+                                 double* __restrict__ chain, double* __restrict__ lnchain,
+                                 const int* __restrict__ d_iter, int it_val, int n_iter, int half, int h,
+                                 int P) {
 #pragma clang fp contract(off)
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= half * P) return;
-    const size_t off = ((size_t)*d_iter * 2 + h) * half;
-    const int w = i / P, d = i - w * P;
-    const double s = pos[(size_t)(h * half + w) * P + d];
-    const double c = pos[(size_t)((1 - h) * half + partner[off + w]) * P + d];
-    const double diff = c - s;
-    const double step = z[off + w] * diff;
-    q[i] = c - step;
-}
-
-// accept where lz + newlnp - lnp > ln u; move the walker, count it
-__global__ void k_stretch_accept(double* __restrict__ pos, double* __restrict__ lnprob,
-                                 const double* __restrict__ q, const double* __restrict__ newlnp,
-                                 const double* __restrict__ lz, const double* __restrict__ log_u,
-                                 long long* __restrict__ nacc, const int* __restrict__ d_iter, int half,
-                                 int h, int P) {
-#pragma clang fp contract(off)
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= half) return;
-    const size_t off = ((size_t)*d_iter * 2 + h) * half;
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * (kFinishThreads / 64) + (threadIdx.x >> 6);
+    if (w >= half) return;                                   // wave-uniform
+    const int it = d_iter ? *d_iter : it_val;
+    const double newlnp = walker_lnprob(partial, skip, lnprior, nblk, w, lane);
+    const size_t off = ((size_t)it * 2 + h) * half;
     const int g = h * half + w;
-    const double diff = (lz[off + w] + newlnp[w]) - lnprob[g];
-    if (diff > log_u[off + w]) {
-        for (int d = 0; d < P; ++d) pos[(size_t)g * P + d] = q[(size_t)w * P + d];
-        lnprob[g] = newlnp[w];
-        nacc[g] += 1;
+    double lp = lnprob[g];
+    const double diff = (lz[off + w] + newlnp) - lp;
+    const bool accept = diff > log_u[off + w];               // the same in every lane
+    if (accept) lp = newlnp;
+    for (int d = lane; d < P; d += 64) {                     // lane d moves coordinate d
+        double v;
+        if (accept) {
+            v = q[(size_t)w * P + d];
+            pos[(size_t)g * P + d] = v;
+        } else {
+            v = pos[(size_t)g * P + d];
+        }
+        if (chain) chain[((size_t)g * n_iter + it) * P + d] = v;
     }
-}
-
-// chain[w][it][:] = pos[w][:], lnchain[w][it] = lnprob[w]; the last thread advances *d_iter
-__global__ void k_stretch_store(const double* __restrict__ pos, const double* __restrict__ lnprob,
-                                double* __restrict__ chain, double* __restrict__ lnchain, int W, int P,
-                                int* __restrict__ d_iter, int n_iter) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int it = *d_iter;
-    if (i < W * P && chain) {
-        const int w = i / P, d = i - w * P;
-        chain[((size_t)w * n_iter + it) * P + d] = pos[i];
-        if (d == 0) lnchain[(size_t)w * n_iter + it] = lnprob[w];
+    if (lane == 0) {
+        if (accept) {
+            lnprob[g] = lp;
+            nacc[g] += 1;
+        }
+        if (chain) lnchain[(size_t)g * n_iter + it] = lp;
     }
 }
 

@@ -20,6 +20,8 @@ What is new: every half-step evaluates its walkers in ONE call --
 batch) or `pool.map` (e.g. `BatchLogPosterior.as_pool()`), instead of one Python
 call per walker.
 """
+import threading
+
 import numpy as np
 
 __all__ = ['EnsembleSampler', 'DeviceEnsembleSampler', 'AutocorrError', 'integrated_time']
@@ -239,6 +241,28 @@ class EnsembleSampler(object):
         return results
 
 
+def _run_async(fn, *args, **kwargs):
+    """Start fn(*args, **kwargs) on a thread; the returned callable joins and gives its result
+    (or raises what it raised)."""
+    box = {}
+
+    def work():
+        try:
+            box['value'] = fn(*args, **kwargs)
+        except BaseException as exc:            # re-raised by the caller
+            box['error'] = exc
+
+    th = threading.Thread(target=work)
+    th.start()
+
+    def join():
+        th.join()
+        if 'error' in box:
+            raise box['error']
+        return box['value']
+    return join
+
+
 class DeviceEnsembleSampler(EnsembleSampler):
     """The same sampler with the walkers resident on the GPU: proposal, log-posterior
     (priors included), acceptance and chain storage all run on the device
@@ -301,21 +325,35 @@ class DeviceEnsembleSampler(EnsembleSampler):
             self._lnprob = np.concatenate((self._lnprob, np.zeros((self.k, n_keep))), axis=1)
         nacc = self.naccepted.astype(np.int64)
         done = 0
+        # The next block's random numbers are drawn while the GPU works on the current one
+        # (the library call releases the GIL).  The draws stay in emcee's order because the
+        # stream is sequential: block k+1 is drawn right after block k, only earlier in time.
+        draws = self._draw(min(self.block, iterations)) if iterations > 0 else None
         while done < iterations:
             n = min(self.block, iterations - done)
-            z, lz, partner, log_u = self._draw(n)
-            p, lnprob, chain, lnchain = self.model.engine.stretch_run(
-                p, lnprob, z, lz, partner, log_u, nacc, store=True, accumulate=self.accumulate)
+            n_next = min(self.block, iterations - done - n)
+            job = _run_async(self.model.engine.stretch_run, p, lnprob, *draws, nacc, store=True,
+                             accumulate=self.accumulate)
+            try:
+                draws = self._draw(n_next) if n_next > 0 else None
+            finally:
+                result = job()
+            p, lnprob, chain, lnchain = result
             if self.accumulate:
                 self.model._device_samples += n * self.k
                 self.model.accumulated_samples += n * self.k
+            # per-block bookkeeping in whole-array operations: at a few hundred microseconds
+            # per iteration on the GPU, per-iteration numpy calls here were 10 % of the run
+            if storechain:
+                kept = np.arange(done, done + n)
+                kept = kept[kept % thin == 0]
+                if len(kept):
+                    ind = i0 + kept // thin
+                    self._chain[:, ind, :] = chain[:, kept - done, :]
+                    self._lnprob[:, ind] = lnchain[:, kept - done]
+            self.naccepted = nacc.astype(np.float64)
+            state = self.random_state
             for j in range(n):
-                i = done + j
                 self.iterations += 1
-                if storechain and i % thin == 0:
-                    ind = i0 + int(i // thin)
-                    self._chain[:, ind, :] = chain[:, j, :]
-                    self._lnprob[:, ind] = lnchain[:, j]
-                self.naccepted = nacc.astype(np.float64)
-                yield chain[:, j, :].copy(), lnchain[:, j].copy(), self.random_state
+                yield chain[:, j, :].copy(), lnchain[:, j].copy(), state
             done += n

@@ -119,6 +119,17 @@ def test_skip_chunking_and_order_invariance(models, backend):
     # internal chunking changes nothing
     model.engine.set_option('chunk_walkers', 16)
     assert np.array_equal(model.log_posterior_batch(theta), base)
+    # pass sizes that are not multiples of the library's rounding (4 / 8) must stay within
+    # the T buffers (regression: 95-walker passes over 4085 walkers ran one walker past them),
+    # with one or two passes in flight and with single-pass batches split over both streams
+    for chunk, streams, min_split in ((5, 1, 0), (7, 2, 0), (13, 2, 1), (89, 2, 1), (90, 2, 1)):
+        model.engine.set_option('chunk_walkers', chunk)
+        model.engine.set_option('streams', streams)
+        if min_split:
+            model.engine.set_option('min_split', min_split)
+        assert np.array_equal(model.log_posterior_batch(theta), base), (chunk, streams, min_split)
+    model.engine.set_option('min_split', 1 << 30)
+    model.engine.set_option('streams', 2)
     model.engine.set_option('chunk_walkers', 256)
     # walkers outside the prior support are skipped and come back -inf
     bad = theta.copy()
