@@ -869,7 +869,7 @@ extern "C" int psfmc_set_layout(psfmc_ctx* c, int n_sky, int n_params, const int
     HIP_TRY(hipDeviceSynchronize());
     // pack everything into one device allocation (8-byte units)
     const size_t n_int = (size_t)ns + c->n_ps + c->n_sersic + n_params;
-    const size_t n_dbl = (size_t)ns + 3 * (size_t)n_params;
+    const size_t n_dbl = (size_t)ns + 4 * (size_t)n_params;
     const size_t int_bytes = (n_int * sizeof(int) + 7) / 8 * 8;
     std::vector<unsigned char> blob(int_bytes + n_dbl * sizeof(double));
     int* ip = reinterpret_cast<int*>(blob.data());
@@ -883,6 +883,7 @@ extern "C" int psfmc_set_layout(psfmc_ctx* c, int n_sky, int n_params, const int
         memcpy(dp + ns, p0, n_params * sizeof(double));
         memcpy(dp + ns + n_params, p1, n_params * sizeof(double));
         memcpy(dp + ns + 2 * n_params, p2, n_params * sizeof(double));
+        for (int i = 0; i < n_params; ++i) dp[ns + 3 * n_params + i] = prior_log_norm(family[i], p0[i], p1[i], p2[i]);
     }
     if (c->d_layout_blob) { (void)hipFree(c->d_layout_blob); c->d_layout_blob = nullptr; }
     HIP_TRY(hipMalloc(&c->d_layout_blob, blob.size()));
@@ -895,6 +896,7 @@ extern "C" int psfmc_set_layout(psfmc_ctx* c, int n_sky, int n_params, const int
     L.slot_col = dip; L.ps_method = dip + ns; L.sersic_deg = dip + ns + c->n_ps;
     L.family = dip + ns + c->n_ps + c->n_sersic;
     L.slot_const = ddp; L.pa = ddp + ns; L.pb = ddp + ns + n_params; L.pc = ddp + ns + 2 * n_params;
+    L.pk = ddp + ns + 3 * n_params;
     for (double** p : {&c->d_theta, &c->d_extra, &c->d_lnprior})
         if (*p) { (void)hipFree(*p); *p = nullptr; }
     HIP_TRY(hipMalloc(&c->d_theta, (size_t)c->max_walkers * (n_params > 0 ? n_params : 1) * sizeof(double)));

@@ -31,58 +31,51 @@ struct ThetaLayout {
     const double* pa;           // [n_params] loc / c / low
     const double* pb;           // [n_params] scale / loc / high
     const double* pc;           // [n_params] - / scale / -
+    const double* pk;           // [n_params] the family's constant log term (prior_log_norm),
+                                //            filled by psfmc_set_layout
 };
 
 // ---------------------------------------------------------------------------
 // regularised lower incomplete gamma P(a, x), series form (valid and fast for
 // x < a + 1, which brackets the median), and its inverse at 1/2
 // ---------------------------------------------------------------------------
-// log of x^a e^-x / Gamma(a+1).  `lg1` = lgamma(a + 1) (a < 20) or the Stirling
-// tail of ln Gamma(a + 1) (a >= 20), from igam_lgamma_term: it depends on a only, so
-// an iteration over x computes it once.
-__device__ inline double igam_lgamma_term(double a) {
-    if (a < 20.0) return lgamma(a + 1.0);
-    // Gamma(a+1) = sqrt(2 pi a) (a/e)^a exp(corr(a)):  avoids the cancellation of
-    // a ln x - x against lgamma for large a
+// x^a e^-x / Gamma(a+1), the prefactor of the series.  Below a = 20 it is formed
+// directly from Gamma(a) (`tg`, which the caller needs for Sigma_e anyway: one OCML
+// tgamma instead of lgamma + tgamma); from a = 20 on, Gamma(a+1) = sqrt(2 pi a) (a/e)^a
+// exp(corr(a)) avoids the cancellation of a ln x - x against ln Gamma, and `stirling`
+// = ln sqrt(2 pi a) + corr(a) depends on a only.
+__device__ inline double igam_stirling_term(double a) {
     const double ia = 1.0 / a, ia2 = ia * ia;
     const double corr = ia * (1.0 / 12.0 + ia2 * (-1.0 / 360.0 + ia2 * (1.0 / 1260.0 + ia2 *
                         (-1.0 / 1680.0 + ia2 * (1.0 / 1188.0 + ia2 * (-691.0 / 360360.0))))));
     return 0.5 * log(6.28318530717958647693 * a) + corr;
 }
-__device__ inline double igam_log_prefactor(double a, double x, double lg1) {
-    if (a < 20.0) return a * log(x) - x - lg1;
+__device__ inline double igam_prefactor(double a, double x, double tg, double stirling) {
+    if (a < 20.0) return exp(a * log(x) - x) / (a * tg);
     const double u = (x - a) / a;
-    return a * (log1p(u) - u) - lg1;
+    return exp(a * (log1p(u) - u) - stirling);
 }
 
-__device__ inline double igam_series(double a, double x) {        // P(a, x)
-    double term = 1.0, sum = 1.0, ap = a;
-    for (int k = 0; k < 2000; ++k) {
-        ap += 1.0;
-        term *= x / ap;
-        sum += term;
-        if (term < 1e-17 * sum) break;
-    }
-    return sum * exp(igam_log_prefactor(a, x, igam_lgamma_term(a)));
-}
-
-// kappa = gammaincinv(a, 1/2), a = 2n > 0
-__device__ inline double gamma_median(double a) {
+// kappa = gammaincinv(a, 1/2), a = 2n > 0.  `tg` = tgamma(a) (used for a < 20 only).
+__device__ inline double gamma_median(double a, double tg) {
     if (!(a > 0.0) || !(a < 1e6)) return __builtin_nan("");
     double x;
     if (a < 1.0) {
-        x = exp((log(0.5) + lgamma(a + 1.0)) / a);            // P ~ x^a / Gamma(a+1)
+        x = exp(log(0.5 * a * tg) / a);                         // P ~ x^a / Gamma(a+1)
     } else {
-        const double n = 0.5 * a, i = 1.0 / n;                  // Ciotti & Bertin (1999) eq. 18
+        // Ciotti & Bertin (1999) eq. 18, plus a fitted remainder i^3 (c0 + c1 i + c2 i^2)
+        // (least squares against gammaincinv over n in [0.5, 40]): relative error of the
+        // start <= 1.1e-7 instead of 3.6e-4 at n = 0.5, so ONE Halley step is enough
+        const double n = 0.5 * a, i = 1.0 / n;
         x = a - 1.0 / 3.0 + i * (4.0 / 405.0 + i * (46.0 / 25515.0 + i * (131.0 / 1148175.0 -
             i * (2194697.0 / 30690717750.0))));
+        x -= i * i * i * (2.47501670e-05 + i * (3.05002372e-05 - i * 1.35458779e-05));
     }
-    const double lg1 = igam_lgamma_term(a);
+    const double stirling = a < 20.0 ? 0.0 : igam_stirling_term(a);
     // Halley on P(a, x) = 1/2: cubic convergence, so a step below 1e-6 x leaves an
-    // error of order 1e-18 x and the iteration stops there (the starting values are
-    // good to 1e-3 ... 1e-9, i.e. one or two steps)
+    // error of order 1e-18 x and the iteration stops there
     for (int it = 0; it < 12; ++it) {
-        const double pre = exp(igam_log_prefactor(a, x, lg1));    // x^a e^-x / Gamma(a+1)
+        const double pre = igam_prefactor(a, x, tg, stirling);    // x^a e^-x / Gamma(a+1)
         double term = 1.0, sum = 1.0, ap = a;
         for (int k = 0; k < 2000; ++k) {
             ap += 1.0;
@@ -101,32 +94,46 @@ __device__ inline double gamma_median(double a) {
     return x;
 }
 
-__device__ inline double sersic_sb_eff(double flux, double n, double reff, double reff_b, double kappa) {
-    return flux / (M_PI * reff * reff_b * 2.0 * n * exp(kappa + log(kappa) * -2.0 * n) * tgamma(2.0 * n));
+// Sigma_e (Sersic.py:55-71); tg = tgamma(2n)
+__device__ inline double sersic_sb_eff(double flux, double n, double reff, double reff_b, double kappa,
+                                       double tg) {
+    return flux / (M_PI * reff * reff_b * 2.0 * n * exp(kappa + log(kappa) * -2.0 * n) * tg);
 }
 
 // ---------------------------------------------------------------------------
 // priors
 // ---------------------------------------------------------------------------
-__device__ inline double prior_logp(int fam, double x, double a, double b, double c) {
+// The x-independent term of each family's log-density, computed once on the host
+// (ten log() calls per walker otherwise).
+__host__ inline double prior_log_norm(int fam, double a, double b, double c) {
+    switch (fam) {
+        case PRIOR_UNIFORM: return -log(b);
+        case PRIOR_NORMAL: return -0.91893853320467274178 - log(b);
+        case PRIOR_WEIBULL_MIN: return log(a) - log(c);
+        case PRIOR_RANDINT: return -log(b - a);
+        default: return 0.0;
+    }
+}
+
+__device__ inline double prior_logp(int fam, double x, double a, double b, double c, double k) {
     const double ninf = -INFINITY;
     switch (fam) {
         case PRIOR_UNIFORM: {                                 // loc a, scale b
             const double y = (x - a) / b;
-            return (y >= 0.0 && y <= 1.0) ? -log(b) : (y == y ? ninf : y);
+            return (y >= 0.0 && y <= 1.0) ? k : (y == y ? ninf : y);
         }
         case PRIOR_NORMAL: {                                  // loc a, scale b
             const double z = (x - a) / b;
-            return -0.5 * z * z - 0.91893853320467274178 - log(b);
+            return -0.5 * z * z + k;
         }
         case PRIOR_WEIBULL_MIN: {                             // c a, loc b, scale c
             const double y = (x - b) / c;
             if (!(y >= 0.0)) return y == y ? ninf : y;
-            if (y == 0.0) return a == 1.0 ? -log(c) : (a < 1.0 ? INFINITY : ninf);
-            return log(a) + (a - 1.0) * log(y) - pow(y, a) - log(c);
+            if (y == 0.0) return a == 1.0 ? k : (a < 1.0 ? INFINITY : ninf);
+            return k + (a - 1.0) * log(y) - pow(y, a);
         }
         case PRIOR_RANDINT: {                                 // low a, high b (exclusive); x already rounded
-            return (x >= a && x <= b - 1.0) ? -log(b - a) : ninf;
+            return (x >= a && x <= b - 1.0) ? k : ninf;
         }
         default:
             return 0.0;
@@ -154,7 +161,7 @@ __device__ inline double theta_log_prior(const ThetaLayout& L, const double* __r
         const int fam = L.family[p];
         if (fam == PRIOR_HOST) continue;
         const double x = fam == PRIOR_RANDINT ? rint(theta[p]) : theta[p];
-        lp += prior_logp(fam, x, L.pa[p], L.pb[p], L.pc[p]);
+        lp += prior_logp(fam, x, L.pa[p], L.pb[p], L.pc[p], L.pk[p]);
     }
     // Sersic axis-ratio constraint (Sersic.py:41-45)
     for (int k = 0; k < L.n_sersic; ++k) {
@@ -182,7 +189,8 @@ __device__ inline void theta_sersic_row(const ThetaLayout& L, const double* __re
     const double re = theta_slot(L, theta, s0 + 3), rb = theta_slot(L, theta, s0 + 4);
     const double th = (L.sersic_deg[k] ? ang * (M_PI / 180.0) : ang) + 0.5 * M_PI;
     const double sn = sin(th), cs = cos(th);
-    const double kappa = gamma_median(2.0 * n);
+    const double tg = tgamma(2.0 * n);
+    const double kappa = gamma_median(2.0 * n, tg);
     r[0] = theta_slot(L, theta, s0 + 5);
     r[1] = theta_slot(L, theta, s0 + 6);
     r[2] = cs / re;
@@ -191,7 +199,7 @@ __device__ inline void theta_sersic_row(const ThetaLayout& L, const double* __re
     r[5] = cs / rb;
     r[6] = kappa;
     r[7] = 0.5 / n;
-    r[8] = sersic_sb_eff(pow(10.0, -0.4 * (mag - L.mag_zp)), n, re, rb, kappa);
+    r[8] = sersic_sb_eff(pow(10.0, -0.4 * (mag - L.mag_zp)), n, re, rb, kappa, tg);
 }
 
 // Stretch-move proposal formed while the parameter tile is loaded (pos != nullptr):
@@ -228,7 +236,7 @@ __host__ inline int theta_task_waves(int n_ps, int n_sersic) {
 __host__ inline size_t theta_prep_lds_bytes(int n_sky, int n_ps, int n_sersic, int n_params) {
     const size_t ns = n_slots(n_sky, n_ps, n_sersic);
     const size_t n_int = ((ns + n_ps + n_sersic + n_params + 1) / 2) * 2;           // 8-byte multiple
-    const size_t n_dbl = ns + 3 * (size_t)n_params;
+    const size_t n_dbl = ns + 4 * (size_t)n_params;
     return n_int * sizeof(int) +
            (n_dbl + (size_t)kThetaThreads * (n_params + row_len(n_ps, n_sersic) + n_ps + n_sersic)) *
                sizeof(double);
@@ -243,7 +251,7 @@ k_theta_prep(ThetaLayout G, const double* __restrict__ theta,
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int ns = n_slots(G.n_sky, G.n_ps, G.n_sersic);
     const int n_int = ((ns + G.n_ps + G.n_sersic + G.n_params + 1) / 2) * 2;
-    const int n_dbl = ns + 3 * G.n_params;
+    const int n_dbl = ns + 4 * G.n_params;
     const int rlen = row_len(G.n_ps, G.n_sersic);
     const int P = G.n_params;
     int* li = reinterpret_cast<int*>(lds_raw);
@@ -276,7 +284,7 @@ k_theta_prep(ThetaLayout G, const double* __restrict__ theta,
     ThetaLayout L = G;
     L.slot_col = li; L.ps_method = li + ns; L.sersic_deg = li + ns + G.n_ps;
     L.family = li + ns + G.n_ps + G.n_sersic;
-    L.slot_const = ld; L.pa = ld + ns; L.pb = ld + ns + P; L.pc = ld + ns + 2 * P;
+    L.slot_const = ld; L.pa = ld + ns; L.pb = ld + ns + P; L.pc = ld + ns + 2 * P; L.pk = ld + ns + 3 * P;
     const int lw = threadIdx.x, w = w0 + lw;
     const bool active = w < W;
     const double* th = th_tile + (size_t)lw * P;

@@ -27,3 +27,18 @@ cp $OUT/pmc_traffic.json profiles/pmc_traffic.json
 # (5) the plain bench line (traffic now comes from the PMC table just written)
 python3 bench.py > $OUT/${TAG}_bench.json 2>/dev/null
 tail -c 400 $OUT/${TAG}_bench.json
+# (6) device-resident sampler, 256 walkers: kernel stats and the timeline of one iteration
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_sampler -o s256 -- python3 $R/tests/profile_sampler.py 256 300 > $OUT/${TAG}_sampler_256.txt 2>/dev/null
+cp $R/gpurun_out/${TAG}_sampler/s256_kernel_stats.csv $OUT/${TAG}_sampler_256_kernel_stats.csv
+python3 - $R/gpurun_out/${TAG}_sampler/s256_kernel_trace.csv > $OUT/${TAG}_sampler_256_trace.txt <<'PY'
+import csv, sys
+tr = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r['Start_Timestamp']))
+mid = tr[len(tr) // 2:len(tr) // 2 + 16]
+t0 = int(mid[0]['Start_Timestamp'])
+print('start_us  duration_us  kernel   (16 consecutive launches from the middle of the run)')
+for r in mid:
+    print('%8.1f %8.1f  %s' % ((int(r['Start_Timestamp']) - t0) / 1e3,
+                               (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3, r['Kernel_Name'][:60]))
+PY
+cd $R
