@@ -149,27 +149,35 @@ __device__ __forceinline__ void wave_lds_sync() {
 //      once per wave: a few extra ds_read_b128 per transform, 60 VGPRs back
 //   2  re-read from the global table at every use (always for P = 32)
 // Measured at 256^2 (bench.py, MI355X): mode 0 1.085 M evals/s at 2-3 waves/SIMD, mode 1
-// 1.06 M at 4 waves/SIMD -- the row kernels are not occupancy-limited, so the default is 0.
+// 1.06 M at 4 waves/SIMD -- the row kernels are not occupancy-limited, so their default is 0.
+// The column kernel (PSFMC_TW_MODE_COLS) uses mode 1: alone it is neutral (47.3 vs 46.6 us),
+// but the 60 VGPRs pay for a second register set that pipelines its loads (43.3 us).
 #ifndef PSFMC_TW_MODE
 #define PSFMC_TW_MODE 0
 #endif
-template <int N> constexpr int fft_tw_mode() { return FftShape<N>::P > 16 ? 2 : PSFMC_TW_MODE; }
-template <int N> constexpr bool fft_tw_in_regs() { return fft_tw_mode<N>() == 0; }
-template <int N> constexpr int fft_tw_regs() { return fft_tw_in_regs<N>() ? FftShape<N>::P : 1; }
+#ifndef PSFMC_TW_MODE_COLS
+#define PSFMC_TW_MODE_COLS 1     /* the column kernel: LDS table, the registers go to its load pipeline */
+#endif
+template <int N, int TWM = PSFMC_TW_MODE> constexpr int fft_tw_mode() { return FftShape<N>::P > 16 ? 2 : TWM; }
+template <int N, int TWM = PSFMC_TW_MODE> constexpr bool fft_tw_in_regs() { return fft_tw_mode<N, TWM>() == 0; }
+template <int N, int TWM = PSFMC_TW_MODE> struct TwRegs { static constexpr int value = (FftShape<N>::P > 16 ? 2 : TWM) == 0 ? FftShape<N>::P : 1; };
+template <int N, int TWM = PSFMC_TW_MODE> constexpr int fft_tw_regs() { return TwRegs<N, TWM>::value; }
 // LDS complex elements of the per-wave twiddle table (mode 1)
-template <int N> constexpr int fft_tw_lds_elems() { return fft_tw_mode<N>() == 1 ? FftShape<N>::P * FftShape<N>::T : 0; }
+template <int N, int TWM = PSFMC_TW_MODE> constexpr int fft_tw_lds_elems() {
+    return fft_tw_mode<N, TWM>() == 1 ? FftShape<N>::P * FftShape<N>::T : 0;
+}
 
 // `twl`: this wave's LDS table (mode 1) -- every lane of the wave must call.
-template <int N>
-__device__ __forceinline__ void load_twiddles(cd (&w)[fft_tw_regs<N>()], const cd* __restrict__ table, int t,
+template <int N, int TWM = PSFMC_TW_MODE>
+__device__ __forceinline__ void load_twiddles(cd* w /* [TwRegs<N, TWM>::value] */, const cd* __restrict__ table, int t,
                                               cd* __restrict__ twl, int lane) {
     constexpr int P = FftShape<N>::P, T = FftShape<N>::T;
-    if constexpr (fft_tw_mode<N>() == 0) {
+    if constexpr (fft_tw_mode<N, TWM>() == 0) {
 #pragma unroll
         for (int c = 0; c < P; ++c) w[c] = table[t * c];
     } else {
         w[0] = cd{1.0, 0.0};
-        if constexpr (fft_tw_mode<N>() == 1) {
+        if constexpr (fft_tw_mode<N, TWM>() == 1) {
 #pragma unroll
             for (int i = lane; i < P * T; i += 64) twl[i] = table[(i / T) * (i % T)];   // twl[c][t] = W^(t c)
             wave_lds_sync();
@@ -183,8 +191,8 @@ __device__ __forceinline__ void load_twiddles(cd (&w)[fft_tw_regs<N>()], const c
 // The exchange goes through LDS one component at a time (real parts, then
 // imaginary parts): half the LDS footprint per wave, which is what bounds how many
 // waves a CU can hold, for the same number of LDS bytes moved.
-template <int N, int SIGN>
-__device__ __forceinline__ void fft_wave(cd (&v)[FftShape<N>::P], const cd (&w)[fft_tw_regs<N>()],
+template <int N, int SIGN, int TWM = PSFMC_TW_MODE>
+__device__ __forceinline__ void fft_wave(cd (&v)[FftShape<N>::P], const cd* w /* [TwRegs<N, TWM>::value] */,
                                          const cd* __restrict__ table, int t, double* __restrict__ xbuf,
                                          const cd* __restrict__ twl) {
     constexpr int P = FftShape<N>::P, T = FftShape<N>::T;
@@ -192,8 +200,8 @@ __device__ __forceinline__ void fft_wave(cd (&v)[FftShape<N>::P], const cd (&w)[
 #pragma unroll
     for (int c = 1; c < P; ++c) {
         cd wc;
-        if constexpr (fft_tw_mode<N>() == 0) wc = w[c];
-        else if constexpr (fft_tw_mode<N>() == 1) wc = twl[c * T + t];
+        if constexpr (fft_tw_mode<N, TWM>() == 0) wc = w[c];
+        else if constexpr (fft_tw_mode<N, TWM>() == 1) wc = twl[c * T + t];
         else wc = table[t * c];
         v[c] = cmul(v[c], SIGN < 0 ? wc : cconj(wc));
     }

@@ -41,6 +41,9 @@ namespace psfmc {
 #define PSFMC_ROW_WAVES 0          /* 0 = choose per shape */
 #endif
 constexpr int kColThreads = 256;     // column kernel: 4 waves, persistent
+#ifndef PSFMC_COLS_PREFETCH
+#define PSFMC_COLS_PREFETCH 1         /* register double-buffering of the column loads */
+#endif
 
 template <int NX> constexpr int row_group() { return 64 / FftShape<NX>::T; }      // rows per wave
 template <int NX> constexpr int row_waves() {
@@ -56,7 +59,7 @@ template <int NX> constexpr size_t fused_row_lds_bytes() {
 }
 template <int NY> constexpr int col_ffts_per_block() { return kColThreads / FftShape<NY>::T; }
 template <int NY> constexpr size_t fused_col_wave_lds_doubles() {
-    return (size_t)(64 / FftShape<NY>::T) * fft_lds_elems<NY>() + 2 * (size_t)fft_tw_lds_elems<NY>();
+    return (size_t)(64 / FftShape<NY>::T) * fft_lds_elems<NY>() + 2 * (size_t)fft_tw_lds_elems<NY, PSFMC_TW_MODE_COLS>();
 }
 template <int NY> constexpr size_t fused_col_lds_bytes() {
     return (size_t)(kColThreads / 64) * fused_col_wave_lds_doubles<NY>() * sizeof(double);
@@ -189,35 +192,72 @@ k_cols(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restric
     double* wave_lds = smem + (size_t)wave * fused_col_wave_lds_doubles<NY>();
     double* xbuf = wave_lds + (size_t)(lane / T) * fft_lds_elems<NY>();
     cd* twl = reinterpret_cast<cd*>(wave_lds + (size_t)(64 / T) * fft_lds_elems<NY>());
-    cd tw[fft_tw_regs<NY>()];
-    load_twiddles<NY>(tw, twy, t, twl, lane);
+    constexpr int TM = PSFMC_TW_MODE_COLS;
+    cd tw[TwRegs<NY, TM>::value];
+    load_twiddles<NY, TM>(tw, twy, t, twl, lane);
     const int n_groups = (n_cols + FPB - 1) / FPB;
-    for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    // slot s of group grp: its column, whether it is live, and the lane's first element
+    auto locate = [&](int grp, int& pr, int& c, bool& active) -> cd* {
         const int col = grp * FPB + s;
-        bool active = col < n_cols;
-        const int pr = col >> 1, c = col & 1;     // (walker, kx) pair, component
-        int w = 0, kx = 0;
-        if (active) {
-            w = pr / nxh;
-            kx = pr - w * nxh;
-            if (skip && skip[w]) active = false;
-        }
-        cd* base = Tbuf + (size_t)pr * 2 * NY + (c << rg_log2) + t_elem(t, 0, rg_log2);
-        cd v[P];
+        active = col < n_cols;
+        pr = col >> 1;                            // (walker, kx) pair
+        c = col & 1;                              // component
+        if (active && skip && skip[pr / nxh]) active = false;
+        return Tbuf + (size_t)pr * 2 * NY + (c << rg_log2) + t_elem(t, 0, rg_log2);
+    };
+    // Software pipeline (P <= 16): the next group's column is loaded into a second register
+    // set while this one is transformed.  Loads return in order, so they are issued AFTER the
+    // kernel-spectrum loads were consumed and fly during the inverse transform and the
+    // stores (issued before the forward transform they made the multiply wait for them:
+    // 56 us instead of 46; here 43 us).  The twiddles live in LDS to make room.
+    constexpr bool PF = PSFMC_COLS_PREFETCH && P <= 16;
+    int pr = 0, c = 0;
+    bool active = false;
+    cd* base = Tbuf;
+    cd nxt[PF ? P : 1];
+    if constexpr (PF) {
+        if ((int)blockIdx.x < n_groups) {
+            base = locate(blockIdx.x, pr, c, active);
 #pragma unroll
-        for (int a = 0; a < P; ++a) v[a] = active ? load_stream(base + 2 * T * a) : cd{0.0, 0.0};
-        fft_wave<NY, -1>(v, tw, twy, t, xbuf, twl);
+            for (int a = 0; a < P; ++a) nxt[a] = active ? load_stream(base + 2 * T * a) : cd{0.0, 0.0};
+        }
+    }
+    for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        cd v[P];
+        if constexpr (PF) {
+#pragma unroll
+            for (int a = 0; a < P; ++a) v[a] = nxt[a];
+        } else {
+            base = locate(grp, pr, c, active);
+#pragma unroll
+            for (int a = 0; a < P; ++a) v[a] = active ? load_stream(base + 2 * T * a) : cd{0.0, 0.0};
+        }
+        fft_wave<NY, -1, TM>(v, tw, twy, t, xbuf, twl);
         if constexpr (CONVOLVE) {
+            const int w = pr / nxh, kx = pr - w * nxh;
             const int psf = active ? (int)prep[(size_t)w * plen + kPrepPsfIdx] : 0;
-            const cd* k = Kt + (((size_t)psf * nxh + kx) * 2 + c) * NY;
+            const cd* k = Kt + (((size_t)psf * nxh + (active ? kx : 0)) * 2 + c) * NY;
 #pragma unroll
             for (int e = 0; e < P; ++e) v[e] = cmul(v[e], k[t + T * e]);
-            fft_wave<NY, +1>(v, tw, twy, t, xbuf, twl);
         }
+        int pr_n = 0, c_n = 0;
+        bool active_n = false;
+        cd* base_n = base;
+        if constexpr (PF) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (grp + (int)gridDim.x < n_groups) {
+                base_n = locate(grp + gridDim.x, pr_n, c_n, active_n);
+#pragma unroll
+                for (int a = 0; a < P; ++a) nxt[a] = active_n ? load_stream(base_n + 2 * T * a) : cd{0.0, 0.0};
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (CONVOLVE) fft_wave<NY, +1, TM>(v, tw, twy, t, xbuf, twl);
         if (active) {
 #pragma unroll
             for (int e = 0; e < P; ++e) base[2 * T * e] = v[e];
         }
+        if constexpr (PF) { base = base_n; pr = pr_n; c = c_n; active = active_n; }
     }
 }
 
