@@ -253,8 +253,8 @@ template <int N> constexpr int fft3_lds_doubles() {
 }
 
 // per-lane twiddles: w1[k1] = W_N^(t k1) (k1 < R1), w2[k2] = W_N^(R1 n3 k2) (k2 < 8).
-// For R1 = 16 the stage-1 set would cost 64 VGPRs: it is re-read from the (cache
-// resident) table at each use instead.
+// For R1 = 16 the stage-1 set would cost 64 VGPRs: it comes from a table the workgroup
+// shares in LDS (fft_wave3's w1_lds) or is re-read from the global table at each use.
 template <int N> constexpr int fft3_w1_regs() { return Fft3Shape<N>::R1 <= 8 ? Fft3Shape<N>::R1 : 1; }
 template <int N>
 __device__ __forceinline__ void load_twiddles3(cd (&w1)[fft3_w1_regs<N>()], cd (&w2)[8],
@@ -270,10 +270,12 @@ __device__ __forceinline__ void load_twiddles3(cd (&w1)[fft3_w1_regs<N>()], cd (
     for (int k = 0; k < 8; ++k) w2[k] = table[R1 * (t & 7) * k];
 }
 
+// `w1_lds` (R1 = 16): the workgroup's shared stage-1 table [k1][t] = W_N^(t k1) in LDS,
+// or nullptr to re-read the global table.
 template <int N, int SIGN>
 __device__ __forceinline__ void fft_wave3(cd (&v)[Fft3Shape<N>::R1], const cd (&w1)[fft3_w1_regs<N>()],
                                           const cd (&w2)[8], const cd* __restrict__ table, int t,
-                                          double* __restrict__ lds) {
+                                          double* __restrict__ lds, const cd* __restrict__ w1_lds = nullptr) {
     constexpr int R1 = Fft3Shape<N>::R1, NB = R1 / 8, S1 = 72, S2 = R1 + 1;
     const int n3 = t & 7, g = t >> 3;
     // stage 1
@@ -281,7 +283,8 @@ __device__ __forceinline__ void fft_wave3(cd (&v)[Fft3Shape<N>::R1], const cd (&
 #pragma unroll
     for (int k = 1; k < R1; ++k) {
         cd wk;
-        if constexpr (R1 <= 8) wk = w1[k]; else wk = table[t * k];
+        if constexpr (R1 <= 8) wk = w1[k];
+        else wk = w1_lds ? w1_lds[k * 64 + t] : table[t * k];
         v[k] = cmul(v[k], SIGN < 0 ? wk : cconj(wk));
     }
     // exchange 1 + stage 2

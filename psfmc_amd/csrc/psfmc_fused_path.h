@@ -265,12 +265,17 @@ k_cols(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restric
 // cols3: the column kernel for ny = 512, 1024 on the wave-wide three-stage engine
 // (psfmc_fft.h fft_wave3): one wave per column, 4 waves per workgroup, persistent.
 // ---------------------------------------------------------------------------
+// the waves' exchange regions, then (R1 = 16) the shared stage-1 twiddle table [16][64]
 template <int NY> constexpr size_t fused_col3_lds_bytes() {
-    return (size_t)(kColThreads / 64) * fft3_lds_doubles<NY>() * sizeof(double);
+    return (size_t)(kColThreads / 64) * fft3_lds_doubles<NY>() * sizeof(double) +
+           (Fft3Shape<NY>::R1 > 8 ? (size_t)Fft3Shape<NY>::R1 * 64 * sizeof(cd) : 0);
 }
 
+#ifndef PSFMC_COLS3_BAR
+#define PSFMC_COLS3_BAR 7           /* which of the three scheduling barriers of k_cols3 are in */
+#endif
 #ifndef PSFMC_COLS3_WAVES
-#define PSFMC_COLS3_WAVES 2     /* measured at 1024: 1 or 2 -> 178 us, 3 -> 273 us, 4 -> 374 us (spills) */
+#define PSFMC_COLS3_WAVES 2     /* measured at 1024 (before the shared LDS twiddle table: 150 us now): 1 or 2 -> 178 us, 3 -> 273 us, 4 -> 374 us (spills) */
 #endif
 template <int NY, bool CONVOLVE>
 __global__ void __launch_bounds__(kColThreads, Fft3Shape<NY>::R1 > 8 ? PSFMC_COLS3_WAVES : 2)
@@ -284,6 +289,13 @@ k_cols3(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restri
     double* lds = smem + (size_t)wave * fft3_lds_doubles<NY>();
     cd w1[fft3_w1_regs<NY>()], w2[8];
     load_twiddles3<NY>(w1, w2, twy, t);
+    const cd* w1s = nullptr;
+    if constexpr (R1 > 8) {
+        cd* tab = reinterpret_cast<cd*>(smem + (size_t)WPB * fft3_lds_doubles<NY>());
+        for (int i = threadIdx.x; i < R1 * 64; i += kColThreads) tab[i] = twy[(i & 63) * (i >> 6)];
+        __syncthreads();                                   // once, before any wave can leave
+        w1s = tab;
+    }
     const int rg = 1 << rg_log2;
     const int e0 = t_elem(t, 0, rg_log2);              // offset of y = t; y = 64 a + t adds 128 a
     for (int col = blockIdx.x * WPB + wave; col < n_cols; col += gridDim.x * WPB) {
@@ -294,18 +306,24 @@ k_cols3(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restri
         cd v[R1];
 #pragma unroll
         for (int a = 0; a < R1; ++a) v[a] = base[128 * a];
-        fft_wave3<NY, -1>(v, w1, w2, twy, t, lds);
+        fft_wave3<NY, -1>(v, w1, w2, twy, t, lds, w1s);
         if constexpr (CONVOLVE) {
             // keep the kernel-spectrum loads (and the next column's) out of the transform's
             // register budget: occupancy, not load hoisting, hides their latency here
+#if PSFMC_COLS3_BAR & 1
             __builtin_amdgcn_sched_barrier(0);
+#endif
             const int psf = (int)prep[(size_t)w * plen + kPrepPsfIdx];
             const cd* k = Kt + (((size_t)psf * nxh + kx) * 2 + c) * NY;
 #pragma unroll
             for (int e = 0; e < R1; ++e) v[e] = cmul(v[e], k[t + 64 * e]);
+#if PSFMC_COLS3_BAR & 2
             __builtin_amdgcn_sched_barrier(0);
-            fft_wave3<NY, +1>(v, w1, w2, twy, t, lds);
+#endif
+            fft_wave3<NY, +1>(v, w1, w2, twy, t, lds, w1s);
+#if PSFMC_COLS3_BAR & 4
             __builtin_amdgcn_sched_barrier(0);
+#endif
         }
 #pragma unroll
         for (int e = 0; e < R1; ++e) base[128 * e] = v[e];
