@@ -188,12 +188,16 @@ def test_device_math():
     assert np.max(np.abs(got[normal] - ref[normal]) / ref[normal]) <= 6e-16
     assert np.all(np.abs(got[~normal] - ref[~normal]) <= 5e-324 + 1e-15 * ref[~normal])
     assert np.isnan(engine.debug_math('exp2', np.array([np.nan]))[0])
+    got = engine.debug_math('exp2_minmax', y)          # same values; only NaN handling differs
+    assert np.array_equal(got, engine.debug_math('exp2', y))
     assert engine.debug_math('exp2', np.array([2000.0, np.inf])).tolist() == [np.inf, np.inf]
 
     z = 10.0 ** rng.uniform(-200, 200, 20000)
     assert np.max(np.abs(engine.debug_math('rcp', z) * z - 1.0)) <= 4e-16
     assert np.max(np.abs(engine.debug_math('rsqrt', z) * np.sqrt(z) - 1.0)) <= 6e-16
     assert np.isnan(engine.debug_math('rcp', np.array([0.0]))[0] * 0.0)
+    assert np.max(np.abs(engine.debug_math('rcp1', z) * z - 1.0)) <= 2e-15
+    assert np.isnan(engine.debug_math('rcp1', np.array([0.0]))[0])
 
 
 @pytest.mark.parametrize('name', CASES)
