@@ -402,14 +402,33 @@ k_rows_inv(const cd* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
             var_out[rowoff + T * e + t] = v[e].y;
         }
     }
+    // sum over the lane's good pixels of r^2 / d + ln(2 pi d), d = model_var + obs_var
+    // (= r^2 ivm - ln(ivm / 2 pi), models.py:233-236).  The P logarithms of a lane are
+    // taken as ONE: ln prod d = ln2 (log2 prod mant(d) + sum exp(d)), with the mantissas in
+    // [1/2, 1) so that the product of P <= 32 of them cannot underflow -- a log2 is 27
+    // instructions, frexp + multiply + integer add are 4.  d <= 0 or NaN gives NaN like the
+    // reference's log of a non-positive weight.
     const FieldPx* fp = field + (size_t)yg * P * 64 + lane;
-    double acc = 0.0;
+    double acc = 0.0, mant = 1.0;
+    int expo = 0, n_good = 0;
+    bool invalid = false;
 #pragma unroll
     for (int e = 0; e < P; ++e) {
         const FieldPx px = fp[e * 64];
-        const double term = chi2_term_fast(px.sci, px.var, v[e].x, v[e].y);
-        acc += (px.sci == px.sci) ? term : 0.0;             // NaN sci marks an excluded pixel
+        const bool good = px.sci == px.sci;                  // NaN sci marks an excluded pixel
+        const double d = v[e].y + px.var;
+        const double r = px.sci - v[e].x;
+        const double q = r * r * fast_rcp(d);
+        acc += good ? q : 0.0;
+        const double dd = good ? d : 1.0;                    // neutral factor
+        invalid |= !(dd > 0.0);
+        mant *= __builtin_amdgcn_frexp_mant(dd);
+        expo += __builtin_amdgcn_frexp_exp(dd);
+        n_good += good ? 1 : 0;
     }
+    acc += 0.69314718055994530942 * (fast_log2(mant) + (double)expo) +
+           1.83787706640934548356 * (double)n_good;           // ln(2 pi) per good pixel
+    acc = invalid ? __builtin_nan("") : acc;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
     if (lane == 0) partial[(size_t)w * gridDim.x * row_waves<NX>() + yg] = acc;
