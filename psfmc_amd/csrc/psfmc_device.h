@@ -320,8 +320,8 @@ __device__ __forceinline__ void raster_row(const double* __restrict__ prep, int 
         const double dy = y - y0;
         const double uy = m01 * dy, vy = m11 * dy, dy2 = dy * dy;
         const double nkl = -kappa * kLog2e;                // sb = 2^(nkl (t - 1))
-        const double gk = -2.0 * kappa * pw;               // g  = gk t / sqrt(rho2)
-        (void)0;
+        // g = gk t / sqrt(rho2); the 1/12 of the centroid term rides on gk
+        const double gk = -2.0 * kappa * pw * 0.28867513459481288225;   // sqrt(1/12)
 #pragma unroll
         for (int k = 0; k < P; ++k) {
             const double dx = (double)(T * k + t) - x0;
@@ -330,10 +330,10 @@ __device__ __forceinline__ void raster_row(const double* __restrict__ prep, int 
             const double rho2 = __builtin_fma(u, u, v * v);
             const double d2 = __builtin_fma(dx, dx, dy2);
             const double tt = fast_exp2_noclamp(pw * fast_log2(rho2));
-            const double sb = fast_exp2_minmax(nkl * (tt - 1.0));
-            // g^2 q = (gk t)^2 / rho2 * rho2 / d2: the elliptical radius cancels
+            const double sb = fast_exp2_minmax(__builtin_fma(nkl, tt, -nkl));
+            // g^2 q / 12 = (gk t)^2 / rho2 * rho2 / d2: the elliptical radius cancels
             const double gt = gk * tt;
-            r[k] += sbeff * sb * __builtin_fma(gt * gt, fast_rcp1(d2) * (1.0 / 12.0), 1.0);
+            r[k] = __builtin_fma(sbeff * sb, __builtin_fma(gt * gt, fast_rcp1(d2), 1.0), r[k]);
         }
     }
 }

@@ -391,15 +391,13 @@ k_rows_inv(const cd* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
     fft_wave<NX, +1>(v, tw, twx, t, wave_lds + (size_t)f * fft_lds_elems<NX>(), twl);
     // imaginary part is lambda * model variance (see build_prep)
     const double inv_lambda = prep[(size_t)w * plen + kPrepInvLambda];
-#pragma unroll
-    for (int e = 0; e < P; ++e) v[e].y *= inv_lambda;
 
     if (conv_out) {
         const size_t rowoff = (size_t)w * ny * NX + (size_t)iy * NX;
 #pragma unroll
         for (int e = 0; e < P; ++e) {
             conv_out[rowoff + T * e + t] = v[e].x;
-            var_out[rowoff + T * e + t] = v[e].y;
+            var_out[rowoff + T * e + t] = v[e].y * inv_lambda;
         }
     }
     // sum over the lane's good pixels of r^2 / d + ln(2 pi d), d = model_var + obs_var
@@ -408,23 +406,43 @@ k_rows_inv(const cd* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
     // [1/2, 1) so that the product of P <= 32 of them cannot underflow -- a log2 is 27
     // instructions, frexp + multiply + integer add are 4.  d <= 0 or NaN gives NaN like the
     // reference's log of a non-positive weight.
+    // Waves whose pixels are all good (NaN sci marks an excluded pixel) skip the selects.
     const FieldPx* fp = field + (size_t)yg * P * 64 + lane;
-    double acc = 0.0, mant = 1.0;
-    int expo = 0, n_good = 0;
-    bool invalid = false;
+    FieldPx px[P];
+    bool any_bad = false;
 #pragma unroll
     for (int e = 0; e < P; ++e) {
-        const FieldPx px = fp[e * 64];
-        const bool good = px.sci == px.sci;                  // NaN sci marks an excluded pixel
-        const double d = v[e].y + px.var;
-        const double r = px.sci - v[e].x;
-        const double q = r * r * fast_rcp(d);
-        acc += good ? q : 0.0;
-        const double dd = good ? d : 1.0;                    // neutral factor
-        invalid |= !(dd > 0.0);
-        mant *= __builtin_amdgcn_frexp_mant(dd);
-        expo += __builtin_amdgcn_frexp_exp(dd);
-        n_good += good ? 1 : 0;
+        px[e] = fp[e * 64];
+        any_bad |= px[e].sci != px[e].sci;
+    }
+    double acc = 0.0, mant = 1.0;
+    int expo = 0, n_good = P;
+    bool invalid = false;
+    if (!__any(any_bad)) {
+#pragma unroll
+        for (int e = 0; e < P; ++e) {
+            const double d = __builtin_fma(v[e].y, inv_lambda, px[e].var);
+            const double r = px[e].sci - v[e].x;
+            acc = __builtin_fma(r * r, fast_rcp(d), acc);
+            invalid |= !(d > 0.0);
+            mant *= __builtin_amdgcn_frexp_mant(d);
+            expo += __builtin_amdgcn_frexp_exp(d);
+        }
+    } else {
+        n_good = 0;
+#pragma unroll
+        for (int e = 0; e < P; ++e) {
+            const bool good = px[e].sci == px[e].sci;
+            const double d = __builtin_fma(v[e].y, inv_lambda, px[e].var);
+            const double r = px[e].sci - v[e].x;
+            const double q = r * r * fast_rcp(d);
+            acc += good ? q : 0.0;
+            const double dd = good ? d : 1.0;                // neutral factor
+            invalid |= !(dd > 0.0);
+            mant *= __builtin_amdgcn_frexp_mant(dd);
+            expo += __builtin_amdgcn_frexp_exp(dd);
+            n_good += good ? 1 : 0;
+        }
     }
     acc += 0.69314718055994530942 * (fast_log2(mant) + (double)expo) +
            1.83787706640934548356 * (double)n_good;           // ln(2 pi) per good pixel
