@@ -67,6 +67,20 @@ template <int NY> constexpr size_t fused_col_lds_bytes() {
 // waves per SIMD the register allocator must leave room for
 template <int N> constexpr int fused_min_waves() { return FftShape<N>::P > 16 ? 1 : 2; }
 
+// Address = wave-uniform base (scalar registers) + 32-bit byte offset per lane: the form
+// global_load/store take directly (saddr + voffset).  64-bit per-lane pointer arithmetic was
+// ~100 VALU instructions per wave across the three kernels.  Offsets stay far below 4 GB:
+// they index one walker's T (<= 17 MB at 1024^2) or the kernel spectra.
+template <typename Tp>
+__device__ __forceinline__ Tp* at_bytes(Tp* base, unsigned byte_off) {
+    return reinterpret_cast<Tp*>(reinterpret_cast<char*>(base) + byte_off);
+}
+template <typename Tp>
+__device__ __forceinline__ const Tp* at_bytes(const Tp* base, unsigned byte_off) {
+    return reinterpret_cast<const Tp*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+constexpr unsigned kCd = sizeof(double) * 2;          // bytes of a T element
+
 // element offset of (y, c) inside one (walker, kx) run of 2*ny complex.
 // Sides are >= 64, so RG <= 8 <= T(ny): for y = T a + t the offset is affine in a,
 // t_elem(T a + t) = t_elem(t) + 2 T a  (used by the column kernel).
@@ -154,20 +168,21 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
     wave_lds_sync();
     const int tm = (T - t) % T;
     const int shift = t ? P - 1 : P;
-    cd* dst = Tbuf + (size_t)w * 2 * NXH * ny + t_elem(iy, 0, __builtin_ctz(RG));
-    const size_t kstride = (size_t)2 * ny;
+    cd* wbase = Tbuf + (size_t)w * 2 * NXH * ny;                    // wave-uniform
+    const unsigned kstride = 2u * (unsigned)ny * kCd;                // bytes between kx columns
+    const unsigned off0 = (unsigned)t_elem(iy, 0, __builtin_ctz(RG)) * kCd + (unsigned)t * kstride;
 #pragma unroll
     for (int e = 0; e < P / 2; ++e) {
         const cd zk = v[e];
         cd zm = (e == 0 && t == 0) ? zk                       // k = 0 is its own mirror
                                    : ubuf[(shift - e - P / 2) * T + tm];
-        cd* o = dst + (size_t)(t + T * e) * kstride;
+        cd* o = at_bytes(wbase, off0 + (unsigned)(T * e) * kstride);
         o[0] = cd{0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y)};        // spectrum of raw
         o[RG] = cd{0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x)};      // spectrum of mu raw^2
     }
     if (t == 0) {                                           // Nyquist column, its own mirror
         const cd z = v[P / 2];
-        cd* o = dst + (size_t)(NX / 2) * kstride;
+        cd* o = at_bytes(wbase, off0 + (unsigned)(NX / 2) * kstride);
         o[0] = cd{z.x, 0.0};
         o[RG] = cd{z.y, 0.0};
     }
@@ -351,8 +366,9 @@ k_rows_inv(const cd* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
     const int f = lane / T, t = lane % T;
     const int yg = blockIdx.x * row_waves<NX>() + wave;
     const int iy = yg * RG + f;
-    const cd* src = Tbuf + (size_t)w * 2 * NXH * ny + t_elem(iy, 0, __builtin_ctz(RG));
-    const size_t kstride = (size_t)2 * ny;
+    const cd* wbase = Tbuf + (size_t)w * 2 * NXH * ny;              // wave-uniform
+    const unsigned kstride = 2u * (unsigned)ny * kCd;                // bytes between kx columns
+    const unsigned off0 = (unsigned)t_elem(iy, 0, __builtin_ctz(RG)) * kCd + (unsigned)t * kstride;
 
     // Y[k], k = T a + t:  k <= NX/2: G[k] + i H[k];  else conj(G[NX-k]) + i conj(H[NX-k]).
     // Every (G, H) pair is loaded once, by the lane that owns k <= NX/2; that lane also
@@ -363,13 +379,13 @@ k_rows_inv(const cd* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
     cd v[P];
 #pragma unroll
     for (int a = 0; a < P / 2; ++a) {
-        const cd* p = src + (size_t)(T * a + t) * kstride;
+        const cd* p = at_bytes(wbase, off0 + (unsigned)(T * a) * kstride);
         const cd g = load_stream(p), h = load_stream(p + RG);
         v[a] = cd{g.x - h.y, g.y + h.x};
         mbuf[a * T + t] = cd{g.x + h.y, h.x - g.y};
     }
     {   // Nyquist column k = NX/2 (lane 0 only); the other lanes take a mirror for a = P/2
-        const cd* p = src + (size_t)(NX / 2) * kstride;
+        const cd* p = at_bytes(wbase, off0 + (unsigned)(NX / 2) * kstride);   // t == 0: kx = NX/2
         cd g = cd{0.0, 0.0}, h = cd{0.0, 0.0};
         if (t == 0) { g = load_stream(p); h = load_stream(p + RG); }
         v[P / 2] = cd{g.x - h.y, g.y + h.x};
@@ -407,12 +423,13 @@ k_rows_inv(const cd* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
     // instructions, frexp + multiply + integer add are 4.  d <= 0 or NaN gives NaN like the
     // reference's log of a non-positive weight.
     // Waves whose pixels are all good (NaN sci marks an excluded pixel) skip the selects.
-    const FieldPx* fp = field + (size_t)yg * P * 64 + lane;
+    const FieldPx* fbase = field + (size_t)yg * P * 64;              // wave-uniform
+    const unsigned foff = (unsigned)lane * (unsigned)sizeof(FieldPx);
     FieldPx px[P];
     bool any_bad = false;
 #pragma unroll
     for (int e = 0; e < P; ++e) {
-        px[e] = fp[e * 64];
+        px[e] = *at_bytes(fbase, foff + (unsigned)(e * 64 * sizeof(FieldPx)));
         any_bad |= px[e].sci != px[e].sci;
     }
     double acc = 0.0, mant = 1.0;
