@@ -177,14 +177,16 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
         cd zm = (e == 0 && t == 0) ? zk                       // k = 0 is its own mirror
                                    : ubuf[(shift - e - P / 2) * T + tm];
         cd* o = at_bytes(wbase, off0 + (unsigned)(T * e) * kstride);
-        o[0] = cd{0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y)};        // spectrum of raw
-        o[RG] = cd{0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x)};      // spectrum of mu raw^2
+        // TWICE the spectra of raw and of mu raw^2: the 1/2 of the untangling is a power of
+        // two and rides on the kernel spectra (k_scale_kernel_spectrum), bit for bit the same
+        o[0] = cd{zk.x + zm.x, zk.y - zm.y};
+        o[RG] = cd{zk.y + zm.y, zm.x - zk.x};
     }
     if (t == 0) {                                           // Nyquist column, its own mirror
         const cd z = v[P / 2];
         cd* o = at_bytes(wbase, off0 + (unsigned)(NX / 2) * kstride);
-        o[0] = cd{z.x, 0.0};
-        o[RG] = cd{z.y, 0.0};
+        o[0] = cd{z.x + z.x, 0.0};
+        o[RG] = cd{z.y + z.y, 0.0};
     }
 }
 
@@ -471,7 +473,9 @@ k_rows_inv(const cd* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
 
 // Kt[psf][kx][c][ky] = spec_c[psf][ky][kx] * (-1)^(kx+ky) / S from the
 // column-transformed PSF buffer (T layout with ky in place of y; its c = 1 half
-// already carries the channel scale rho[psf], which stays in Kt)
+// already carries the channel scale rho[psf], which stays in Kt).  k_rows_fwd leaves
+// every spectrum doubled: `inv_s` carries 1/2 for the PSF's own doubling and 1/2 for
+// the doubling of the model spectra it will multiply.
 __global__ void k_scale_kernel_spectrum(const cd* __restrict__ raw, cd* __restrict__ Kt, int n_total,
                                         int ny, int nxh, int rg_log2, double inv_s) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_total; i += gridDim.x * blockDim.x) {
@@ -494,7 +498,7 @@ __global__ void k_untranspose_spectrum(const cd* __restrict__ raw, cd* __restric
         const int kx = i % nxh;
         const int ky = (i / nxh) % ny;
         const int p = i / (nxh * ny);
-        const double sc = c ? 1.0 / rho[p] : 1.0;
+        const double sc = 0.5 * (c ? 1.0 / rho[p] : 1.0);      // k_rows_fwd doubles
         const cd v = raw[((size_t)p * nxh + kx) * 2 * ny + t_elem(ky, c, rg_log2)];
         out[i] = cd{v.x * sc, v.y * sc};
     }

@@ -361,7 +361,7 @@ static int spectra_fused(psfmc_ctx* c, const double* d_canvas) {
     DISPATCH_LEN(c->ny, RC_TRY((launch_cols<N_, false>(c, c->d_Kraw, c->n_psf * 2 * c->nxh, nullptr,
                                                        nullptr, c->stream))));
     hipLaunchKernelGGL(k_scale_kernel_spectrum, dim3(256), dim3(256), 0, c->stream, c->d_Kraw, c->d_Kt,
-                       (int)n_el, c->ny, c->nxh, c->rg_log2, 1.0 / (double)c->S);
+                       (int)n_el, c->ny, c->nxh, c->rg_log2, 0.25 / (double)c->S);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     return PSFMC_OK;
