@@ -188,15 +188,6 @@ __device__ __forceinline__ double fast_rcp(double x) {
     return __builtin_fma(r, e, r);
 }
 
-__device__ __forceinline__ double fast_rsqrt(double x) {
-    double y = __builtin_amdgcn_rsq(x);
-    double h = 0.5 * x;
-    double e = __builtin_fma(-h * y, y, 0.5);       // 0.5 - 0.5 x y^2
-    y = __builtin_fma(y, e, y);
-    e = __builtin_fma(-h * y, y, 0.5);
-    return __builtin_fma(y, e, y);
-}
-
 // One Newton step on v_rcp_f64: ~2^-50 relative, for terms that are themselves small
 // corrections (the rasteriser's centroid term).
 __device__ __forceinline__ double fast_rcp1(double x) {
@@ -238,18 +229,11 @@ __device__ __forceinline__ double fast_exp2_noclamp(double y) {
     return __builtin_amdgcn_ldexp(fast_exp2_poly(y - n), (int)n);
 }
 
-// 2^y.  y is clamped to [-1100, 1100] (so -inf / +inf give 0 / inf); NaN stays NaN
-// (compare-and-select, not fmax/fmin, which would swallow it).
+// 2^y with y clamped to [-1100, 1100] (so -inf / +inf give 0 / inf).  The clamp is a
+// v_max / v_min pair, which returns the bound for a NaN argument: NaN comes back as 0.  In
+// the rasteriser a NaN also reaches the result through the centroid term, so the
+// brightness factor need not carry it.
 __device__ __forceinline__ double fast_exp2(double y) {
-    y = y < -1100.0 ? -1100.0 : y;
-    y = y > 1100.0 ? 1100.0 : y;
-    const double n = __builtin_rint(y);
-    return __builtin_amdgcn_ldexp(fast_exp2_poly(y - n), (int)n);
-}
-
-// 2^y where a NaN argument may come back as 0 (the rasteriser: a NaN there also reaches
-// the result through the centroid term, so the brightness factor need not carry it)
-__device__ __forceinline__ double fast_exp2_minmax(double y) {
     y = __builtin_fmin(__builtin_fmax(y, -1100.0), 1100.0);
     const double n = __builtin_rint(y);
     return __builtin_amdgcn_ldexp(fast_exp2_poly(y - n), (int)n);
@@ -330,7 +314,7 @@ __device__ __forceinline__ void raster_row(const double* __restrict__ prep, int 
             const double rho2 = __builtin_fma(u, u, v * v);
             const double d2 = __builtin_fma(dx, dx, dy2);
             const double tt = fast_exp2_noclamp(pw * fast_log2(rho2));
-            const double sb = fast_exp2_minmax(__builtin_fma(nkl, tt, -nkl));
+            const double sb = fast_exp2(__builtin_fma(nkl, tt, -nkl));
             // g^2 q / 12 = (gk t)^2 / rho2 * rho2 / d2: the elliptical radius cancels
             const double gt = gk * tt;
             r[k] = __builtin_fma(sbeff * sb, __builtin_fma(gt * gt, fast_rcp1(d2), 1.0), r[k]);
@@ -346,17 +330,6 @@ __device__ inline double chi2_term(double sci, double obs_var, double conv, doub
     const double ivm = 1.0 / (mvar + obs_var);
     const double r = sci - conv;
     return r * r * ivm - log(0.5 / M_PI * ivm);
-}
-
-// The same term with the rasteriser's elementary functions (fused path):
-//   r^2 / d + ln(2 pi d),  d = model_var + obs_var  (= r^2 ivm - ln(ivm / 2 pi)).
-// d <= 0 gives NaN like the reference's log of a negative weight.
-__device__ __forceinline__ double chi2_term_fast(double sci, double obs_var, double conv, double mvar) {
-    const double d = mvar + obs_var;
-    const double r = sci - conv;
-    const double lg = 0.69314718055994530942 * fast_log2(6.28318530717958647693 * d);
-    const double term = __builtin_fma(r * r, fast_rcp(d), lg);
-    return d > 0.0 ? term : __builtin_nan("");
 }
 
 // wave64 + LDS block sum; result valid in thread 0.  blockDim.x multiple of 64.

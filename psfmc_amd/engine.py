@@ -118,11 +118,10 @@ def _f64(arr):
 
 
 def debug_math(op, values, device=0):
-    """Evaluate a device elementary function ('log2', 'exp2', 'rcp', 'rsqrt',
-    'rcp1', 'exp2_minmax') on an array (test hook for the rasteriser's
-    hand-written fp64 math)."""
+    """Evaluate a device elementary function ('log2', 'exp2', 'rcp', 'rcp1',
+    'exp2_noclamp') on an array (test hook for the rasteriser's hand-written fp64 math)."""
     lib = load_library()
-    code = {'log2': 0, 'exp2': 1, 'rcp': 2, 'rsqrt': 3, 'rcp1': 4, 'exp2_minmax': 5}[op]
+    code = {'log2': 0, 'exp2': 1, 'rcp': 2, 'rcp1': 3, 'exp2_noclamp': 4}[op]
     x = _f64(np.ravel(values))
     out = np.empty_like(x)
     rc = lib.psfmc_debug_math(int(device), code, x.size, _dp(x), _dp(out))
