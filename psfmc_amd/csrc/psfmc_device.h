@@ -308,7 +308,7 @@ __device__ __forceinline__ void raster_row(const double* __restrict__ prep, int 
         const double gk = -2.0 * kappa * pw * 0.28867513459481288225;   // sqrt(1/12)
 #pragma unroll
         for (int k = 0; k < P; ++k) {
-            const double dx = (double)(T * k + t) - x0;
+            const double dx = (double)(T * k + t) - x0;      // exact pixel coordinate, one rounding
             const double u = __builtin_fma(m00, dx, uy);
             const double v = __builtin_fma(m10, dx, vy);
             const double rho2 = __builtin_fma(u, u, v * v);

@@ -228,53 +228,61 @@ k_cols(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restric
     // stores (issued before the forward transform they made the multiply wait for them:
     // 56 us instead of 46; here 43 us).  The twiddles live in LDS to make room.
     constexpr bool PF = PSFMC_COLS_PREFETCH && P <= 16;
-    int pr = 0, c = 0;
-    bool active = false;
-    cd* base = Tbuf;
-    cd nxt[PF ? P : 1];
-    if constexpr (PF) {
-        if ((int)blockIdx.x < n_groups) {
-            base = locate(blockIdx.x, pr, c, active);
+    struct Slot {
+        cd* base;
+        int pr, c;
+        bool active;
+    };
+    auto load_group = [&](int grp, cd (&dst)[P], Slot& sl) {
+        sl.base = locate(grp, sl.pr, sl.c, sl.active);
 #pragma unroll
-            for (int a = 0; a < P; ++a) nxt[a] = active ? load_stream(base + 2 * T * a) : cd{0.0, 0.0};
-        }
-    }
-    for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
-        cd v[P];
-        if constexpr (PF) {
-#pragma unroll
-            for (int a = 0; a < P; ++a) v[a] = nxt[a];
-        } else {
-            base = locate(grp, pr, c, active);
-#pragma unroll
-            for (int a = 0; a < P; ++a) v[a] = active ? load_stream(base + 2 * T * a) : cd{0.0, 0.0};
-        }
+        for (int a = 0; a < P; ++a) dst[a] = sl.active ? load_stream(sl.base + 2 * T * a) : cd{0.0, 0.0};
+    };
+    // one column per slot: forward, * kernel spectrum, `between()`, inverse, store in place
+    auto transform = [&](cd (&v)[P], const Slot& sl, auto&& between) {
         fft_wave<NY, -1, TM>(v, tw, twy, t, xbuf, twl);
         if constexpr (CONVOLVE) {
-            const int w = pr / nxh, kx = pr - w * nxh;
-            const int psf = active ? (int)prep[(size_t)w * plen + kPrepPsfIdx] : 0;
-            const cd* k = Kt + (((size_t)psf * nxh + (active ? kx : 0)) * 2 + c) * NY;
+            const int w = sl.pr / nxh, kx = sl.pr - w * nxh;
+            const int psf = sl.active ? (int)prep[(size_t)w * plen + kPrepPsfIdx] : 0;
+            const cd* k = Kt + (((size_t)psf * nxh + (sl.active ? kx : 0)) * 2 + sl.c) * NY;
 #pragma unroll
             for (int e = 0; e < P; ++e) v[e] = cmul(v[e], k[t + T * e]);
         }
-        int pr_n = 0, c_n = 0;
-        bool active_n = false;
-        cd* base_n = base;
-        if constexpr (PF) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (grp + (int)gridDim.x < n_groups) {
-                base_n = locate(grp + gridDim.x, pr_n, c_n, active_n);
-#pragma unroll
-                for (int a = 0; a < P; ++a) nxt[a] = active_n ? load_stream(base_n + 2 * T * a) : cd{0.0, 0.0};
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        between();
         if constexpr (CONVOLVE) fft_wave<NY, +1, TM>(v, tw, twy, t, xbuf, twl);
-        if (active) {
+        if (sl.active) {
 #pragma unroll
-            for (int e = 0; e < P; ++e) base[2 * T * e] = v[e];
+            for (int e = 0; e < P; ++e) sl.base[2 * T * e] = v[e];
         }
-        if constexpr (PF) { base = base_n; pr = pr_n; c = c_n; active = active_n; }
+    };
+    if constexpr (PF) {
+        // two register sets take turns (no copies): while one is transformed the other
+        // receives the next group
+        cd A[P], B[P];
+        Slot sa{Tbuf, 0, 0, false}, sb{Tbuf, 0, 0, false};
+        const int step = (int)gridDim.x;
+        if ((int)blockIdx.x < n_groups) load_group(blockIdx.x, A, sa);
+        for (int grp = blockIdx.x; grp < n_groups; grp += 2 * step) {
+            const int g1 = grp + step, g2 = g1 + step;
+            transform(A, sa, [&] {
+                __builtin_amdgcn_sched_barrier(0);
+                if (g1 < n_groups) load_group(g1, B, sb);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if (g1 < n_groups)
+                transform(B, sb, [&] {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (g2 < n_groups) load_group(g2, A, sa);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+        }
+    } else {
+        for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+            cd v[P];
+            Slot sl{Tbuf, 0, 0, false};
+            load_group(grp, v, sl);
+            transform(v, sl, [] {});
+        }
     }
 }
 
