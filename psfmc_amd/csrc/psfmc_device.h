@@ -72,18 +72,26 @@ __device__ inline void ps_window(double c, int n, int method, int* lo, int* cnt)
 // The three pieces of a prep record.  Each component block is independent of the
 // others (k_theta_prep builds them on different waves); the head needs the largest
 // of the components' peak estimates.
-__device__ inline double prep_ps_block(const double* __restrict__ r, double* __restrict__ p, int ny, int nx) {
-    const double flux = r[0], x0 = r[1], y0 = r[2];
+// one axis of a point source's window: axis 0 = y (weights p[4..]), axis 1 = x (weights
+// p[4 + kTaps..], flux folded in)
+__device__ inline void prep_ps_axis(const double* __restrict__ r, double* __restrict__ p, int axis, int n) {
+    const double flux = r[0], c0 = axis ? r[1] : r[2];
     const int method = (int)r[3];
-    int ylo, yn, xlo, xn;
-    ps_window(y0, ny, method, &ylo, &yn);
-    ps_window(x0, nx, method, &xlo, &xn);
-    p[0] = ylo; p[1] = yn; p[2] = xlo; p[3] = xn;
+    int lo, cnt;
+    ps_window(c0, n, method, &lo, &cnt);
+    p[2 * axis] = lo;
+    p[2 * axis + 1] = cnt;
+    double* wgt = p + 4 + kTaps * axis;
     for (int t = 0; t < kTaps; ++t) {
-        p[4 + t] = t < yn ? ps_weight((double)(ylo + t) - y0, method) : 0.0;
-        p[4 + kTaps + t] = t < xn ? ps_weight((double)(xlo + t) - x0, method) * flux : 0.0;
+        const double wv = t < cnt ? ps_weight((double)(lo + t) - c0, method) : 0.0;
+        wgt[t] = axis ? wv * flux : wv;
     }
-    return fabs(flux);
+}
+
+__device__ inline double prep_ps_block(const double* __restrict__ r, double* __restrict__ p, int ny, int nx) {
+    prep_ps_axis(r, p, 0, ny);
+    prep_ps_axis(r, p, 1, nx);
+    return fabs(r[0]);
 }
 
 __device__ inline double prep_sersic_block(const double* __restrict__ r, double* __restrict__ p) {

@@ -141,14 +141,15 @@ __device__ inline double prior_logp(int fam, double x, double a, double b, doubl
 }
 
 // The work of one walker is split into independent TASKS that run on different waves
-// of the workgroup (blockDim = (64 walkers, n tasks)): one walker per thread left the
+// of the workgroup (blockDim = (64 walkers, n waves)): one walker per thread left the
 // whole GPU with two waves crawling through ~9000 dependent fp64 instructions (35 us
 // for a 128-walker half-ensemble, a sixth of an MCMC half-step).
-//   task 0              joint log-prior (device families + the host's extra), support
-//                       and axis-ratio checks -> lnprior, skip; sky and PSF index
-//   task 1 + k          PointSource k: flux, Lanczos / bilinear window -> prep block
-//   task 1 + n_ps + k   Sersic k: ellipse matrix, kappa, Sigma_e -> prep block
-// then task 0 writes the head of the prep record from the largest peak estimate.
+//   task 0                       joint log-prior (device families + the host's extra),
+//                                support and axis-ratio checks -> lnprior, skip; sky, PSF index
+//   tasks 1 + 2k, 2 + 2k         PointSource k: flux and the y / the x axis of its window
+//   then 2 per Sersic            the ellipse + flux, and Gamma(2n) + kappa
+// after a barrier one wave per Sersic forms Sigma_e and its prep block, and after another
+// task 0's wave writes the head of the prep record from the largest peak estimate.
 // Walkers outside the prior support get skip = 1; their prep record is scratch.
 __device__ inline double theta_slot(const ThetaLayout& L, const double* __restrict__ theta, int s) {
     const int col = L.slot_col[s];
@@ -181,25 +182,38 @@ __device__ inline void theta_ps_row(const ThetaLayout& L, const double* __restri
     r[3] = (double)L.ps_method[k];
 }
 
-__device__ inline void theta_sersic_row(const ThetaLayout& L, const double* __restrict__ theta, int k,
-                                        double* __restrict__ r) {
+// Sersic row in three independent pieces: the ellipse (sincos), kappa (tgamma + the
+// incomplete-gamma inversion), and Sigma_e, which needs both.  scratch = {Gamma(2n), flux}.
+__device__ inline void theta_sersic_geometry(const ThetaLayout& L, const double* __restrict__ theta, int k,
+                                             double* __restrict__ r, double* __restrict__ scratch) {
     const int s0 = L.n_sky + 3 * L.n_ps + 7 * k;
-    const double ang = theta_slot(L, theta, s0), n = theta_slot(L, theta, s0 + 1);
-    const double mag = theta_slot(L, theta, s0 + 2);
+    const double ang = theta_slot(L, theta, s0), mag = theta_slot(L, theta, s0 + 2);
     const double re = theta_slot(L, theta, s0 + 3), rb = theta_slot(L, theta, s0 + 4);
     const double th = (L.sersic_deg[k] ? ang * (M_PI / 180.0) : ang) + 0.5 * M_PI;
     const double sn = sin(th), cs = cos(th);
-    const double tg = tgamma(2.0 * n);
-    const double kappa = gamma_median(2.0 * n, tg);
     r[0] = theta_slot(L, theta, s0 + 5);
     r[1] = theta_slot(L, theta, s0 + 6);
     r[2] = cs / re;
     r[3] = sn / re;
     r[4] = -sn / rb;
     r[5] = cs / rb;
-    r[6] = kappa;
+    scratch[1] = pow(10.0, -0.4 * (mag - L.mag_zp));
+}
+
+__device__ inline void theta_sersic_kappa(const ThetaLayout& L, const double* __restrict__ theta, int k,
+                                          double* __restrict__ r, double* __restrict__ scratch) {
+    const double n = theta_slot(L, theta, L.n_sky + 3 * L.n_ps + 7 * k + 1);
+    const double tg = tgamma(2.0 * n);
+    r[6] = gamma_median(2.0 * n, tg);
     r[7] = 0.5 / n;
-    r[8] = sersic_sb_eff(pow(10.0, -0.4 * (mag - L.mag_zp)), n, re, rb, kappa, tg);
+    scratch[0] = tg;
+}
+
+__device__ inline void theta_sersic_sigma(const ThetaLayout& L, const double* __restrict__ theta, int k,
+                                          double* __restrict__ r, const double* __restrict__ scratch) {
+    const int s0 = L.n_sky + 3 * L.n_ps + 7 * k;
+    r[8] = sersic_sb_eff(scratch[1], theta_slot(L, theta, s0 + 1), theta_slot(L, theta, s0 + 3),
+                         theta_slot(L, theta, s0 + 4), r[6], scratch[0]);
 }
 
 // Stretch-move proposal formed while the parameter tile is loaded (pos != nullptr):
@@ -228,9 +242,9 @@ __device__ inline double stretch_point(double s, double c, double z) {
 // loads: from global memory it cost 45 us per call, from LDS it is a few us), and
 // the components' peak estimates
 constexpr int kThetaThreads = 64;       // walkers per workgroup
-constexpr int kThetaMaxTasks = 4;       // waves per workgroup; further tasks loop
+constexpr int kThetaMaxTasks = 8;       // waves per workgroup; further tasks loop
 __host__ inline int theta_task_waves(int n_ps, int n_sersic) {
-    const int t = 1 + n_ps + n_sersic;
+    const int t = 1 + 2 * n_ps + 2 * n_sersic;
     return t > kThetaMaxTasks ? kThetaMaxTasks : t;
 }
 __host__ inline size_t theta_prep_lds_bytes(int n_sky, int n_ps, int n_sersic, int n_params) {
@@ -238,7 +252,7 @@ __host__ inline size_t theta_prep_lds_bytes(int n_sky, int n_ps, int n_sersic, i
     const size_t n_int = ((ns + n_ps + n_sersic + n_params + 1) / 2) * 2;           // 8-byte multiple
     const size_t n_dbl = ns + 4 * (size_t)n_params;
     return n_int * sizeof(int) +
-           (n_dbl + (size_t)kThetaThreads * (n_params + row_len(n_ps, n_sersic) + n_ps + n_sersic)) *
+           (n_dbl + (size_t)kThetaThreads * (n_params + row_len(n_ps, n_sersic) + n_ps + 3 * n_sersic)) *
                sizeof(double);
 }
 
@@ -290,7 +304,8 @@ k_theta_prep(ThetaLayout G, const double* __restrict__ theta,
     const double* th = th_tile + (size_t)lw * P;
     double* row = row_tile + (size_t)lw * rlen;
     double* my_prep = prep + (size_t)(active ? w : 0) * prep_len(G.n_ps, G.n_sersic);
-    const int n_tasks = 1 + G.n_ps + G.n_sersic;
+    double* sersic_scratch = peak_tile + (size_t)(G.n_ps + G.n_sersic) * kThetaThreads;   // [sersic][2][walker]
+    const int n_tasks = 1 + 2 * G.n_ps + 2 * G.n_sersic;
     bool ok = false;
     for (int task = threadIdx.y; task < n_tasks; task += blockDim.y) {      // wave-uniform
         if (!active) continue;
@@ -305,18 +320,40 @@ k_theta_prep(ThetaLayout G, const double* __restrict__ theta,
             double psf = rint(theta_slot(L, th, ns - 1));
             psf = psf < 0.0 ? 0.0 : (psf > (double)(L.n_psf - 1) ? (double)(L.n_psf - 1) : psf);
             row[rlen - 1] = psf;
-        } else if (task <= G.n_ps) {
-            const int k = task - 1;
-            double* r = row + kRowSky + kRowPs * k;
-            theta_ps_row(L, th, k, r);
-            peak_tile[k * kThetaThreads + lw] = prep_ps_block(r, my_prep + kPrepHead + kPrepPs * k, ny, nx);
+        } else if (task <= 2 * G.n_ps) {
+            // both axis tasks derive the (identical) row piece; each writes its own half of
+            // the prep block, the y task also the row and the peak estimate
+            const int k = (task - 1) >> 1, axis = (task - 1) & 1;
+            double rr[kRowPs];
+            theta_ps_row(L, th, k, rr);
+            prep_ps_axis(rr, my_prep + kPrepHead + kPrepPs * k, axis, axis ? nx : ny);
+            if (axis == 0) {
+                double* r = row + kRowSky + kRowPs * k;
+                for (int j = 0; j < kRowPs; ++j) r[j] = rr[j];
+                peak_tile[k * kThetaThreads + lw] = fabs(rr[0]);
+            }
         } else {
-            const int k = task - 1 - G.n_ps;
+            const int j = task - 1 - 2 * G.n_ps, k = j >> 1;
             double* r = row + kRowSky + kRowPs * G.n_ps + kRowSersic * k;
-            theta_sersic_row(L, th, k, r);
-            peak_tile[(G.n_ps + k) * kThetaThreads + lw] =
-                prep_sersic_block(r, my_prep + kPrepHead + kPrepPs * G.n_ps + kPrepSersic * k);
+            double scr[2];
+            if (j & 1) {
+                theta_sersic_kappa(L, th, k, r, scr);
+                sersic_scratch[(k * 2 + 0) * kThetaThreads + lw] = scr[0];
+            } else {
+                theta_sersic_geometry(L, th, k, r, scr);
+                sersic_scratch[(k * 2 + 1) * kThetaThreads + lw] = scr[1];
+            }
         }
+    }
+    __syncthreads();
+    for (int k = threadIdx.y; k < G.n_sersic; k += blockDim.y) {            // wave-uniform
+        if (!active) continue;
+        double* r = row + kRowSky + kRowPs * G.n_ps + kRowSersic * k;
+        const double scr[2] = {sersic_scratch[(k * 2 + 0) * kThetaThreads + lw],
+                               sersic_scratch[(k * 2 + 1) * kThetaThreads + lw]};
+        theta_sersic_sigma(L, th, k, r, scr);
+        peak_tile[(G.n_ps + k) * kThetaThreads + lw] =
+            prep_sersic_block(r, my_prep + kPrepHead + kPrepPs * G.n_ps + kPrepSersic * k);
     }
     __syncthreads();
     if (threadIdx.y != 0 || !active) return;
