@@ -123,6 +123,15 @@ def test_device_sampler_reproduces_host_sampler(tmp_path):
     more_h = list(host.sample(out_h[-1][0], lnprob0=out_h[-1][1], iterations=6, thin=2))
     more_d = list(dev.sample(out_d[-1][0], lnprob0=out_d[-1][1], iterations=6, thin=2))
     assert dev.chain.shape == (40, 28, model.num_params) and np.array_equal(dev.chain, host.chain)
+    # replaying one captured iteration as a hipGraph (option "graph") gives the same chain
+    model.engine.set_option('graph', 1)
+    launches = model.engine.get_option('graph_launches')
+    gdev = DeviceEnsembleSampler(40, model, block=9)
+    gdev.random_state = np.random.RandomState(11).get_state()
+    list(gdev.sample(p0, iterations=25))
+    assert model.engine.get_option('graph_launches') > launches
+    assert np.array_equal(gdev.chain, host.chain[:, :25])
+    model.engine.set_option('graph', 0)
     # accumulation inside the device loop == accumulating every iteration's positions
     model.reset_images()
     acc = DeviceEnsembleSampler(40, model, block=4, accumulate=True)
