@@ -21,6 +21,8 @@ np.random.seed(1)
 p0 = m.init_params_from_priors(n_w)
 if os.environ.get('PSFMC_CHUNK'):
     m.engine.set_option('chunk_walkers', int(os.environ['PSFMC_CHUNK']))
+if os.environ.get('PSFMC_GRAPH'):
+    m.engine.set_option('graph', int(os.environ['PSFMC_GRAPH']))
 s = DeviceEnsembleSampler(n_w, m, block=100)
 s.random_state = np.random.RandomState(5).get_state()
 list(s.sample(p0, iterations=100))
