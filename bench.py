@@ -3,10 +3,12 @@
 bench.py -- walker log-posterior evaluations per second (BASELINE.json metric).
 
 A *step* is one pass of the hot path over one batch of synthetic walkers: the
-256x256 field with 1 PointSource + 1 Sersic (BASELINE.json configs[1] shape /
-SURVEY.md section 8(d) headline), W walkers per GPU, derived-parameter rows already
-resident in HBM; the step ends with the all-gather of the log-likelihoods
-across ranks (N > 1).  One process per GPU (`python -m torch.distributed.run`
+256x256 field with 1 PointSource + 1 Sersic that BASELINE.json's `metric` is quoted on
+(BASELINE.md / SURVEY.md section 8(d) headline), W walkers per GPU, derived-parameter
+rows already resident in HBM; the step ends with the all-gather of the log-likelihoods
+across ranks (N > 1).  BASELINE.json configs[1] (the reference's J0005-0006 example
+model, 256 walkers in one batch) is a parity case (tests/golden/example); its throughput
+is reported next to the headline as `example_model_256_walkers` (N = 1 only).  One process per GPU (`python -m torch.distributed.run`
 for N > 1); weak scaling (per-GPU batch fixed).
 
 Prints ONE JSON line on rank 0 (contract in the task description), including
@@ -105,6 +107,30 @@ def kernel_profile(eng, args, step, torch, dev, steps):
     eng.set_option('streams', streams)
     out.sort(key=lambda d: -d['total_ms'])
     return out, chunk
+
+
+def example_model_rate(walkers=256, reps=40):
+    """BASELINE.json configs[1]: the reference's example field (128^2 HST data, Sky +
+    PointSource + 2 Sersic, 18 parameters; data files under tests/golden/example), 256
+    walkers drawn from the priors, one batch per call through the Python entry point
+    (`MultiComponentModel.log_posterior_batch`: host vectors in, log-posteriors out)."""
+    mfile = os.path.join(ROOT, 'tests', 'golden', 'example', 'model_example.py')
+    if not os.path.exists(mfile):
+        return None
+    from psfmc_amd import MultiComponentModel
+    m = MultiComponentModel(mfile, max_walkers=walkers)
+    np.random.seed(7)
+    theta = m.init_params_from_priors(walkers)
+    out = m.log_posterior_batch(theta)                     # warm-up (context, layout)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = m.log_posterior_batch(theta)
+    dt = time.perf_counter() - t0
+    m.close()
+    return {'evals_per_s': walkers * reps / dt, 'ms_per_batch': dt / reps * 1e3, 'walkers': walkers,
+            'finite': int(np.isfinite(out).sum()),
+            'workload': 'J0005-0006 example model (128x128, Sky + PointSource + 2 Sersic), 256 walkers '
+                        'per batch, host vectors in / log-posteriors out, fp64'}
 
 
 def cpu_baseline(args, fld, theta, budget_s):
@@ -242,6 +268,7 @@ def main():
                     help="'nccl' (RCCL over xGMI; the real thing) or 'gloo' (rehearsal of the "
                          "multi-rank path on a box with fewer GPUs than ranks: ranks share devices)")
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--no-example', action='store_true', help='skip the configs[1] (example model) rate')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--cpu-procs', type=int, default=min(16, os.cpu_count() or 1),
                     help='processes of the all-cores CPU baseline (0 = skip)')
@@ -386,6 +413,10 @@ def main():
         for _ in range(reps):
             model.log_posterior_batch(theta)
         line['host_path_evals_per_s'] = args.walkers * reps / (time.perf_counter() - t0)
+        if world == 1 and not args.no_example:
+            ex = example_model_rate()
+            if ex:
+                line['example_model_256_walkers'] = ex
         if not args.no_cpu and world == 1:      # CPU baseline: rank 0 at N = 1 only
             base, vals = cpu_baseline(args, fld, theta, args.cpu_seconds)
             line['cpu_baseline'] = base
