@@ -214,9 +214,13 @@ k_cols(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restric
     load_twiddles<NY, TM>(tw, twy, t, twl, lane);
     const int n_groups = (n_cols + FPB - 1) / FPB;
     // slot s of group grp: its column, whether it is live, and the lane's first element
+    // Slots past the last column (final group only) and skipped walkers still LOAD -- from
+    // the last valid column / the walker's stale data -- and transform; only their stores are
+    // masked.  Zero-filling their registers instead cost 32 moves per group in every lane.
     auto locate = [&](int grp, int& pr, int& c, bool& active) -> cd* {
-        const int col = grp * FPB + s;
+        int col = grp * FPB + s;
         active = col < n_cols;
+        col = active ? col : n_cols - 1;
         pr = col >> 1;                            // (walker, kx) pair
         c = col & 1;                              // component
         if (active && skip && skip[pr / nxh]) active = false;
@@ -236,15 +240,16 @@ k_cols(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restric
     auto load_group = [&](int grp, cd (&dst)[P], Slot& sl) {
         sl.base = locate(grp, sl.pr, sl.c, sl.active);
 #pragma unroll
-        for (int a = 0; a < P; ++a) dst[a] = sl.active ? load_stream(sl.base + 2 * T * a) : cd{0.0, 0.0};
+        for (int a = 0; a < P; ++a) dst[a] = load_stream(sl.base + 2 * T * a);
     };
     // one column per slot: forward, * kernel spectrum, `between()`, inverse, store in place
     auto transform = [&](cd (&v)[P], const Slot& sl, auto&& between) {
         fft_wave<NY, -1, TM>(v, tw, twy, t, xbuf, twl);
         if constexpr (CONVOLVE) {
             const int w = sl.pr / nxh, kx = sl.pr - w * nxh;
+            // a skipped walker's record may hold anything: its (masked) lanes use PSF 0
             const int psf = sl.active ? (int)prep[(size_t)w * plen + kPrepPsfIdx] : 0;
-            const cd* k = Kt + (((size_t)psf * nxh + (sl.active ? kx : 0)) * 2 + sl.c) * NY;
+            const cd* k = Kt + (((size_t)psf * nxh + kx) * 2 + sl.c) * NY;
 #pragma unroll
             for (int e = 0; e < P; ++e) v[e] = cmul(v[e], k[t + T * e]);
         }
