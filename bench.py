@@ -2,24 +2,37 @@
 """
 bench.py -- walker log-posterior evaluations per second (BASELINE.json metric).
 
-A *step* is one pass of the hot path over one batch of synthetic walkers: the
-256x256 field with 1 PointSource + 1 Sersic that BASELINE.json's `metric` is quoted on
-(BASELINE.md / SURVEY.md section 8(d) headline), W walkers per GPU, derived-parameter
-rows already resident in HBM; the step ends with the all-gather of the log-likelihoods
-across ranks (N > 1).  BASELINE.json configs[1] (the reference's J0005-0006 example
-model, 256 walkers in one batch) is a parity case (tests/golden/example); its throughput
-is reported next to the headline as `example_model_256_walkers` (N = 1 only).  One process per GPU (`python -m torch.distributed.run`
-for N > 1); weak scaling (per-GPU batch fixed).
+A *step* is --batches passes of the hot path, each over one batch of --walkers
+synthetic walkers on the 256x256 field with 1 PointSource + 1 Sersic that
+BASELINE.json's `metric` is quoted on (SURVEY.md section 8(d) headline: W = 4096).
+The timed call is the WHOLE log-posterior: raw emcee parameter vectors resident in
+HBM -> unpacking, priors, early-out, Sersic constants, rasteriser, both convolutions,
+composite variance, masked Gaussian likelihood, NaN guard -> one double per walker
+(`psfmc_eval_theta_device`, psfMC/models.py:193-243 for every walker of the batch).
+With N > 1 every batch ends with the all-gather of the log-posteriors across ranks.
+
+`python bench.py --gpus N` with N > 1 starts `python -m torch.distributed.run` with N
+ranks as a CHILD process (before this process touches the GPU) and relays its output;
+the driver's own `torch.distributed.run ... bench.py --gpus N` form runs the ranks
+directly.  One process per GPU; weak scaling (per-GPU batch fixed).
 
 Prints ONE JSON line on rank 0 (contract in the task description), including
-  roofline      algorithmic bytes (96 N^2 + 64 N per evaluation)
-                over the live-measured device time of the evaluation pipeline
-  cpu_baseline  the numpy oracle (a port of the reference algorithm) timed on
-                this host, one walker per call like the reference
+  roofline       the dominant kernel (k_cols): its algorithmic bytes per launch (read +
+                 write of the transposed half-spectra, = the column pass's share of SURVEY
+                 section 8(d)'s per-evaluation figure) over its live HIP-event-timed launch
+                 duration; `traffic` from the committed rocprofv3 PMC passes
+  roofline_step  the whole step by MEASURED bytes (PMC bytes per walker of the three
+                 pipeline kernels x evals/s) against the 8 TB/s peak;
+                 `algorithmic_equiv_GBps` is SURVEY section 8(d)'s 96 N^2 + 64 N bytes x
+                 evals/s -- an equivalent rate of an unfused design, not a fraction of peak
+  cpu_baseline   the numpy oracle (a port of the reference algorithm) timed on this host,
+                 one walker per call like the reference
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,27 +44,66 @@ for p in (ROOT, os.path.join(ROOT, 'tools')):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBPS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md, chip-level table
+BYTES_NOTE = ('FETCH_SIZE/WRITE_SIZE count requests at the L2 memory side (fabric); the pass size keeps '
+              'the transposed half-spectra inside the 256 MiB Infinity Cache, so part of these bytes '
+              'is served on-die, not from DRAM')
 
 
 def algorithmic_bytes_per_eval(n):
     return 96 * n * n + 64 * n
 
 
-def pmc_traffic(args, kernel):
-    """HBM bytes per walker of `kernel` from the committed rocprofv3 PMC passes
-    (profiles/pmc_traffic.json; FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM,
-    plus WRITE_SIZE), or None when that shape was not profiled."""
+def pmc_table(args):
+    """HBM-side bytes per walker of each pipeline kernel from the committed rocprofv3 PMC
+    passes (profiles/pmc_traffic.json; FETCH_SIZE doubled per MI355X_MICROARCH.md section
+    HBM, plus WRITE_SIZE), or {} when that shape was not profiled."""
     path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     try:
         with open(path) as f:
-            table = json.load(f)
-        return table['%dx%d' % (args.size, args.size)][kernel]['hbm_bytes_per_walker']
+            return json.load(f)['%dx%d' % (args.size, args.size)]
     except (IOError, OSError, KeyError, ValueError):
-        return None
+        return {}
+
+
+def pmc_lookup(table, prefix):
+    for name, rec in table.items():
+        if name.startswith(prefix):
+            return rec['hbm_bytes_per_walker']
+    return None
+
+
+def physical_cores():
+    """(cores this process may use, logical CPUs of the machine): one entry per distinct
+    (package, core) among the CPUs of the affinity mask."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = list(range(os.cpu_count() or 1))
+    seen = set()
+    for cpu in allowed:
+        base = '/sys/devices/system/cpu/cpu%d/topology/' % cpu
+        try:
+            with open(base + 'physical_package_id') as f:
+                pkg = f.read().strip()
+            with open(base + 'core_id') as f:
+                core = f.read().strip()
+            seen.add((pkg, core))
+        except (IOError, OSError):
+            seen.add(('cpu', cpu))
+    return max(len(seen), 1), os.cpu_count() or 1
+
+
+def draw_theta(args, fld, n, seed=1):
+    import synth_field
+    half = n // 2
+    return np.vstack([
+        synth_field.draw_walkers(args.size, args.sersic, half, seed=seed),
+        synth_field.draw_walkers(args.size, args.sersic, n - half, seed=seed + 1,
+                                 near_truth=fld['truth'])])
 
 
 def build_problem(args, device, seed=0):
-    """Synthetic field + walker rows.  Returns (model, theta[W,P])."""
+    """Synthetic field + walker vectors.  Returns (model, theta[W,P], field dict)."""
     import tempfile
     import synth_field
     from psfmc_amd import MultiComponentModel, fits_io
@@ -65,15 +117,10 @@ def build_problem(args, device, seed=0):
         f.write(synth_field.model_file_text(args.size, args.sersic))
     model = MultiComponentModel(path, device=device, backend=args.backend,
                                 max_walkers=args.walkers)
-    half = args.walkers // 2
-    theta = np.vstack([
-        synth_field.draw_walkers(args.size, args.sersic, half, seed=1),
-        synth_field.draw_walkers(args.size, args.sersic, args.walkers - half, seed=2,
-                                 near_truth=fld['truth'])])
-    return model, theta, fld
+    return model, draw_theta(args, fld, args.walkers), fld
 
 
-def kernel_profile(eng, args, step, torch, dev, steps):
+def kernel_profile(eng, args, one_batch, torch, dev, reps):
     """Per-kernel device time from HIP events recorded inside the library around
     every launch (set_option 'profile').  Run with ONE pass in flight so that a
     kernel's events bracket that kernel alone -- the same quantity rocprofv3
@@ -82,15 +129,14 @@ def kernel_profile(eng, args, step, torch, dev, steps):
     nxh = n // 2 + 1
     t_bytes = 2 * nxh * n * 16                  # transposed half-spectra of one walker
     designed = {'rows_fwd': t_bytes, 'cols': 2 * t_bytes, 'rows_inv': t_bytes}
-    names = {'rows_fwd': 'k_rows_fwd<%d, false>' % n, 'cols': 'k_cols<%d, true>' % n,
-             'rows_inv': 'k_rows_inv<%d>' % n}
+    names = {'rows_fwd': 'k_rows_fwd<%d, false>' % n, 'rows_inv': 'k_rows_inv<%d>' % n,
+             'cols': ('k_cols3<%d, true>' if n >= 512 else 'k_cols<%d, true>') % n}
     streams = eng.get_option('streams')
     eng.set_option('streams', 1)
     eng.set_option('profile', 1)
-    for _ in range(steps):
-        step()
+    for _ in range(reps):
+        one_batch()
     torch.cuda.synchronize(dev)
-    chunk = int(eng.get_option('chunk_walkers'))
     out = []
     for key in ('rows_fwd', 'cols', 'rows_inv'):
         ms = eng.get_option('prof_ms_' + key)
@@ -98,7 +144,7 @@ def kernel_profile(eng, args, step, torch, dev, steps):
         if not cnt:
             continue
         avg_s = ms * 1e-3 / cnt
-        walkers = args.walkers * steps / cnt          # walkers one launch processes (avg)
+        walkers = args.walkers * reps / cnt          # walkers one launch processes (avg)
         out.append({'kernel': names[key], 'launches': int(cnt), 'avg_ms': avg_s * 1e3,
                     'total_ms': ms, 'walkers_per_launch': walkers,
                     'bytes_per_walker': designed[key],
@@ -106,7 +152,28 @@ def kernel_profile(eng, args, step, torch, dev, steps):
     eng.set_option('profile', 0)
     eng.set_option('streams', streams)
     out.sort(key=lambda d: -d['total_ms'])
-    return out, chunk
+    return out
+
+
+def small_ensembles(eng, args, torch, dev, theta_dev, out_dev, stream):
+    """Half-steps of the reference's default ensembles (chains = 2 P + 2, psfMC/fitting.py:
+    52-53 -> 11 and 19 walkers per half-step for 10 / 18 parameters) and a few more: device
+    time per call of the whole log-posterior, back to back on one stream."""
+    res = {}
+    for w in (11, 19, 32, 64, 128, 256):
+        if w > args.walkers:
+            continue
+        for _ in range(5):
+            eng.logpost_theta_device(w, theta_dev.data_ptr(), 0, out_dev.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        reps = 200
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            eng.logpost_theta_device(w, theta_dev.data_ptr(), 0, out_dev.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / reps
+        res[str(w)] = {'us_per_call': dt * 1e6, 'evals_per_s': w / dt}
+    return res
 
 
 def example_model_rate(walkers=256, reps=40):
@@ -152,7 +219,8 @@ def cpu_baseline(args, fld, theta, budget_s):
         if el >= budget_s:
             break
     return {'value': done / el, 'unit': 'evals/s', 'cores': 1, 'kind': 'port',
-            'sample': '%d walkers of the same batch, one per call, %.1f s' % (done, el)}, vals
+            'sample': '%d walkers of the same batch, one per call, %.1f s (log-likelihood; the '
+                      'reference adds ~15 scipy.stats prior calls per walker on top)' % (done, el)}, vals
 
 
 def cpu_worker(args):
@@ -160,19 +228,14 @@ def cpu_worker(args):
     --cpu-seconds and print how many were done (no GPU, no torch)."""
     import synth_field
     fld = synth_field.make_field(args.size, args.sersic, seed=0)
-    half = args.walkers // 2
-    theta = np.vstack([
-        synth_field.draw_walkers(args.size, args.sersic, half, seed=1),
-        synth_field.draw_walkers(args.size, args.sersic, args.walkers - half, seed=2,
-                                 near_truth=fld['truth'])])
+    theta = draw_theta(args, fld, args.walkers)
     _, vals = cpu_baseline(args, fld, theta[args.cpu_worker::7], args.cpu_seconds)
     print('CPU_WORKER_DONE %d' % len(vals))
 
 
-def cpu_baseline_multi(args, n_procs):
+def cpu_baseline_multi(args, n_procs, n_logical):
     """The best the reference could do had `threads=n` worked: one
-    single-threaded process per core, walkers split between them."""
-    import subprocess
+    single-threaded process per physical core, walkers split between them."""
     env = dict(os.environ, OMP_NUM_THREADS='1', MKL_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1')
     cmd = [sys.executable, os.path.abspath(__file__), '--size', str(args.size), '--sersic',
            str(args.sersic), '--walkers', str(args.walkers), '--cpu-seconds', str(args.cpu_seconds)]
@@ -187,25 +250,28 @@ def cpu_baseline_multi(args, n_procs):
                 done += int(line.split()[1])
     el = time.perf_counter() - t0
     return {'value': done / args.cpu_seconds, 'unit': 'evals/s', 'cores': n_procs, 'kind': 'port',
-            'sample': '%d single-threaded processes x %.0f s of walkers of the same batch '
-                      '(wall %.1f s incl. start-up)' % (n_procs, args.cpu_seconds, el)}
+            'host_logical_cpus': n_logical,
+            'sample': '%d single-threaded processes (one per physical core available to this job; the '
+                      'host reports %d logical CPUs) x %.0f s of walkers of the same batch (wall %.1f s '
+                      'incl. start-up)' % (n_procs, n_logical, args.cpu_seconds, el)}
 
 
-def many_fields(args, torch, dist, world, rank, local, dev):
-    """BASELINE config 5: every rank owns --fields independent fields (own context,
-    own streams, own walkers); a step evaluates all of them.  Fields shard across
-    ranks with no data-path collective."""
-    probs = [build_problem(args, local, seed=rank * args.fields + f) for f in range(args.fields)]
-    engs, rows, outs = [], [], []
-    for model, theta, _ in probs:
-        engs.append(model.engine)
-        rows.append(torch.from_numpy(model.derived_rows(theta)).to(dev))
-        outs.append(torch.empty(args.walkers, dtype=torch.float64, device=dev))
+def spawn_ranks(args, argv):
+    """`bench.py --gpus N` outside a torch.distributed launch: start the N ranks as a child
+    process (this process has not touched the GPU), relay the output, return its exit code."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'),
+               OMP_NUM_THREADS=os.environ.get('OMP_NUM_THREADS', '1'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
 
-    def step():
-        for eng, r, o in zip(engs, rows, outs):       # each context enqueues on its own stream
-            eng.loglike_device(args.walkers, r.data_ptr(), 0, o.data_ptr(), None)
 
+def timed_region(args, torch, dist, world, dev, step, gloo):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides;
+    returns the MAX over ranks of the wall time."""
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
@@ -219,31 +285,56 @@ def many_fields(args, torch, dist, world, rank, local, dev):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if gloo else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    return elapsed
+
+
+def many_fields(args, torch, dist, world, rank, local, dev, gloo):
+    """BASELINE config 5: every rank owns --fields independent fields (own context,
+    own streams, own walkers); a step evaluates all of them (raw vectors -> log-posterior).
+    Fields shard across ranks with no data-path collective."""
+    probs = [build_problem(args, local, seed=rank * args.fields + f) for f in range(args.fields)]
+    engs, thetas, outs = [], [], []
+    for model, theta, _ in probs:
+        engs.append(model.engine)
+        thetas.append(torch.from_numpy(theta).to(dev))
+        outs.append(torch.empty(args.walkers, dtype=torch.float64, device=dev))
+
+    def step():
+        for _ in range(args.batches):
+            for eng, t, o in zip(engs, thetas, outs):       # each context enqueues on its own stream
+                eng.logpost_theta_device(args.walkers, t.data_ptr(), 0, o.data_ptr(), None)
+
+    elapsed = timed_region(args, torch, dist, world, dev, step, gloo)
     finite = int(sum(int(torch.isfinite(o).sum().item()) for o in outs))
     if rank == 0:
-        total = args.walkers * args.fields * world * args.steps
+        total = args.walkers * args.fields * args.batches * world * args.steps
         b_eval = algorithmic_bytes_per_eval(args.size)
-        achieved = b_eval * total / elapsed / world / 1e9
+        table = pmc_table(args)
+        per_walker = [pmc_lookup(table, k) for k in ('k_rows_fwd<', 'k_cols', 'k_rows_inv<')]
+        measured = sum(per_walker) if all(per_walker) else None
+        rate_gpu = total / elapsed / world
         print(json.dumps({
             'metric': 'walker log-posterior evals/sec, 256x256 image, 1 PSF+1 Sersic',
             'value': total / elapsed, 'unit': 'evals/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
             'data': 'synthetic',
-            'config': {'workload': '%d independent synthetic %dx%d fields per GPU x %d walkers each, '
-                                   '1 PointSource + %d Sersic, fp64' % (args.fields, args.size,
-                                                                       args.size, args.walkers,
-                                                                       args.sersic),
+            'config': {'workload': '%d independent synthetic %dx%d fields per GPU x %d walkers each x %d '
+                                   'batches per step, 1 PointSource + %d Sersic, raw vectors resident in '
+                                   'HBM -> log-posterior, fp64' % (args.fields, args.size, args.size,
+                                                                   args.walkers, args.batches, args.sersic),
                        'fields_per_gpu': args.fields, 'walkers_per_field': args.walkers,
                        'backend': args.backend, 'parallelism': 'fields sharded x%d' % world},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
-                         'kernel': 'evaluation pipelines of all fields (per GPU)',
-                         'bytes_per_eval': b_eval},
-            'finite_loglikes': finite}))
+            'roofline': {'bound': 'hbm', 'achieved': measured * rate_gpu / 1e9 if measured else None,
+                         'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                         'frac': measured * rate_gpu / 1e9 / HBM_PEAK_GBPS if measured else None,
+                         'traffic': measured * args.walkers * args.fields * args.batches if measured else None,
+                         'kernel': 'evaluation pipelines of all fields (per GPU), measured PMC bytes per walker',
+                         'algorithmic_equiv_GBps': b_eval * rate_gpu / 1e9, 'bytes_note': BYTES_NOTE},
+            'finite_logposts': finite}))
     for model, _, _ in probs:
         model.close()
     if world > 1:
@@ -255,7 +346,10 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--walkers', type=int, default=4096, help='walkers per GPU per step')
+    ap.add_argument('--walkers', type=int, default=4096, help='walkers per batch (per GPU)')
+    ap.add_argument('--batches', type=int, default=0,
+                    help='batches per step (0: enough for ~26 ms per step, so that the default 20 '
+                         'steps time >= 0.5 s: 8 at 256^2 x 4096 walkers)')
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--sersic', type=int, default=1)
     ap.add_argument('--backend', default=os.environ.get('PSFMC_BACKEND', 'fused'))
@@ -270,31 +364,47 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-example', action='store_true', help='skip the configs[1] (example model) rate')
     ap.add_argument('--no-cpu', action='store_true')
-    ap.add_argument('--cpu-procs', type=int, default=min(16, os.cpu_count() or 1),
-                    help='processes of the all-cores CPU baseline (0 = skip)')
+    ap.add_argument('--no-extras', action='store_true',
+                    help='skip the side figures (small ensembles, likelihood-only, host path)')
+    ap.add_argument('--cpu-procs', type=int, default=-1,
+                    help='processes of the all-cores CPU baseline (-1 = one per physical core, 0 = skip)')
     ap.add_argument('--cpu-worker', type=int, default=-1, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker >= 0:
         return cpu_worker(args)
+    env_world = os.environ.get('WORLD_SIZE')
+    if env_world is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
+    world = int(env_world or '1')
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d, or '
+                         'run plain `python bench.py --gpus N`)' % (args.gpus, world, args.gpus))
+    if args.batches <= 0:
+        # ~3.3 ms per 4096-walker batch at 256^2 on one MI355X; scale by the bytes of a walker
+        per_batch_ms = 3.3 * (args.walkers / 4096.0) * (args.size / 256.0) ** 2 * max(args.fields, 1)
+        args.batches = max(1, min(64, int(np.ceil(26.0 / per_batch_ms))))
     # the all-cores CPU baseline runs first, in child processes, before this process
     # touches the GPU (rank 0, N = 1 only)
     multi = None
-    if (not args.no_cpu and args.cpu_procs > 1 and int(os.environ.get('WORLD_SIZE', '1')) == 1):
-        multi = cpu_baseline_multi(args, args.cpu_procs)
+    n_phys, n_logical = physical_cores()
+    if args.cpu_procs < 0:
+        args.cpu_procs = n_phys
+    if not args.no_cpu and args.cpu_procs > 1 and world == 1 and args.fields == 1:
+        multi = cpu_baseline_multi(args, args.cpu_procs, n_logical)
 
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (there is no CPU fallback)')
-    if args.dist_backend == 'gloo':          # rehearsal: several ranks may share one device
+    gloo = world > 1 and args.dist_backend == 'gloo'
+    if gloo:                                 # rehearsal: several ranks may share one device
         local = local % torch.cuda.device_count()
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        if args.dist_backend == 'gloo':
+        if gloo:
             dist.init_process_group('gloo')
         else:
             dist.init_process_group('nccl', device_id=torch.device('cuda', local))
@@ -302,7 +412,7 @@ def main():
     dev = torch.device('cuda', local)
 
     if args.fields > 1:
-        return many_fields(args, torch, dist, world, rank, local, dev)
+        return many_fields(args, torch, dist, world, rank, local, dev, gloo)
     model, theta, fld = build_problem(args, local)
     eng = model.engine
     if args.chunk:
@@ -310,109 +420,112 @@ def main():
     for kv in args.opt:
         key, val = kv.split('=')
         eng.set_option(key, float(val))
-    rows = torch.from_numpy(model.derived_rows(theta)).to(dev)
-    out = torch.empty(args.walkers, dtype=torch.float64, device=dev)
-    gathered = torch.empty(args.walkers * world, dtype=torch.float64, device=dev)
+    # every batch of a step has its own walkers (same field); all resident in HBM
+    thetas = [theta] + [draw_theta(args, fld, args.walkers, seed=11 + 2 * b) for b in range(1, args.batches)]
+    theta_dev = torch.from_numpy(np.ascontiguousarray(np.stack(thetas))).to(dev)      # [B, W, P]
+    out = torch.empty((args.batches, args.walkers), dtype=torch.float64, device=dev)
+    gathered = torch.empty(args.walkers * world, dtype=torch.float64, device='cpu' if gloo else dev)
     # a real (non-NULL) stream: the library launches on the stream it is handed,
     # and the HIP events below must sit on that same stream
     stream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)
+    sptr = stream.cuda_stream
 
-    gloo = world > 1 and args.dist_backend == 'gloo'
-    if gloo:
-        gathered = gathered.cpu()
+    def one_batch(b=0):
+        eng.logpost_theta_device(args.walkers, theta_dev[b].data_ptr(), 0, out[b].data_ptr(), sptr)
 
     def step():
-        eng.loglike_device(args.walkers, rows.data_ptr(), 0, out.data_ptr(), stream.cuda_stream)
-        if gloo:                         # host staging only in the rehearsal back end
-            dist.all_gather_into_tensor(gathered, out.cpu())
-        elif world > 1:
-            dist.all_gather_into_tensor(gathered, out)
+        for b in range(args.batches):
+            one_batch(b)
+            if gloo:                         # host staging only in the rehearsal back end
+                dist.all_gather_into_tensor(gathered, out[b].cpu())
+            elif world > 1:
+                dist.all_gather_into_tensor(gathered, out[b])
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(dev)
+    elapsed = timed_region(args, torch, dist, world, dev, step, gloo)
     if world > 1:
-        dist.barrier()
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(args.steps):
-        step()
-    ev1.record(stream)
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if gloo else dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
         # every rank evaluated the same walkers of the same field: the gathered blocks agree
         blocks = gathered.reshape(world, args.walkers)
-        assert bool((blocks == blocks[0]).all()), 'ranks disagree on the gathered log-likelihoods'
+        assert bool((blocks == blocks[0]).all()), 'ranks disagree on the gathered log-posteriors'
 
     # sanity: the batch the timing ran on is numerically right
-    lnlike = out.cpu().numpy()
-    n_finite = int(np.isfinite(lnlike).sum())
+    lnpost = out[0].cpu().numpy()
+    n_finite = int(np.isfinite(out.cpu().numpy()).sum())
 
-    kernels, chunk = ([], 0)
+    kernels = []
     if rank == 0 and args.backend == 'fused':
-        kernels, chunk = kernel_profile(eng, args, step if world == 1 else
-                                        (lambda: eng.loglike_device(args.walkers, rows.data_ptr(), 0,
-                                                                    out.data_ptr(), stream.cuda_stream)),
-                                        torch, dev, max(2, min(args.steps, 5)))
+        kernels = kernel_profile(eng, args, one_batch, torch, dev, max(2, min(args.steps, 5)))
 
     if rank == 0:
-        total_evals = args.walkers * world * args.steps
+        evals_per_step = args.walkers * args.batches
+        total_evals = evals_per_step * world * args.steps
         value = total_evals / elapsed
+        rate_gpu = value / world
         b_eval = algorithmic_bytes_per_eval(args.size)
-        launch_s = dev_ms * 1e-3 / args.steps            # device time of one pipeline pass
-        achieved = b_eval * args.walkers / launch_s / 1e9
+        table = pmc_table(args)
         line = {
             'metric': 'walker log-posterior evals/sec, 256x256 image, 1 PSF+1 Sersic',
             'value': value, 'unit': 'evals/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'synthetic %dx%d field, 1 PointSource + %d Sersic, %d walkers '
-                                   'per GPU per step, fp64, rows resident in HBM'
-                                   % (args.size, args.size, args.sersic, args.walkers),
-                       'image': args.size, 'walkers_per_gpu': args.walkers,
+            'config': {'workload': 'synthetic %dx%d field, 1 PointSource + %d Sersic, %d batches x %d walkers '
+                                   'per GPU per step, raw emcee vectors resident in HBM -> full '
+                                   'log-posterior (priors, early-out, Sersic constants, likelihood), fp64'
+                                   % (args.size, args.size, args.sersic, args.batches, args.walkers),
+                       'image': args.size, 'walkers_per_batch': args.walkers, 'batches_per_step': args.batches,
+                       'evals_per_gpu_per_step': evals_per_step, 'entry_point': 'psfmc_eval_theta_device',
                        'backend': args.backend, 'parallelism': 'walkers sharded x%d' % world},
-            'finite_loglikes': n_finite,
+            'finite_logposts': n_finite,
         }
-        # whole pipeline against SURVEY.md section 8(d)'s algorithmic bytes per evaluation
-        pipe = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
-                'kernel': 'evaluation pipeline (k_rows_fwd + k_cols + k_rows_inv, one '
-                          'eval_batch_device call of %d walkers)' % args.walkers,
-                'bytes_per_eval': b_eval, 'launch_ms': launch_s * 1e3}
+        per_walker = [pmc_lookup(table, k) for k in ('k_rows_fwd<', 'k_cols', 'k_rows_inv<')]
+        measured = sum(per_walker) if all(per_walker) else None
+        step_roof = {'bound': 'hbm', 'achieved': measured * rate_gpu / 1e9 if measured else None,
+                     'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                     'frac': measured * rate_gpu / 1e9 / HBM_PEAK_GBPS if measured else None,
+                     'traffic': measured * evals_per_step if measured else None,
+                     'kernel': 'whole step per GPU: (k_rows_fwd + k_cols + k_rows_inv) PMC bytes per walker '
+                               'x evals/s; profiles/pmc_traffic.json',
+                     'measured_bytes_per_eval': measured,
+                     'algorithmic_equiv_GBps': b_eval * rate_gpu / 1e9,
+                     'algorithmic_bytes_per_eval': b_eval, 'bytes_note': BYTES_NOTE}
         if kernels:
-            # dominant kernel: its own algorithmic bytes (= the HBM bytes the design
-            # moves: it reads and writes the transposed half-spectra once) over its
-            # event-timed average launch duration
+            # dominant kernel: its own algorithmic bytes (= the bytes the design moves: it reads
+            # and writes the transposed half-spectra once; the column pass's 64 F of SURVEY section
+            # 8(d)'s figure) over its event-timed average launch duration
             k = kernels[0]
-            traffic = pmc_traffic(args, k['kernel'])
+            traffic = pmc_lookup(table, k['kernel'].split('<')[0])
             line['roofline'] = {
                 'bound': 'hbm', 'achieved': k['GBps'], 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                 'frac': k['GBps'] / HBM_PEAK_GBPS,
                 'traffic': traffic * k['walkers_per_launch'] if traffic else None,
                 'kernel': k['kernel'], 'launch_ms': k['avg_ms'], 'launches': k['launches'],
                 'bytes_per_launch': k['bytes_per_walker'] * k['walkers_per_launch'],
-                'walkers_per_launch': k['walkers_per_launch']}
-            line['roofline_pipeline'] = pipe
+                'walkers_per_launch': k['walkers_per_launch'],
+                'timing': 'HIP events around every launch on its own stream, one pass in flight',
+                'bytes_note': BYTES_NOTE}
+            line['roofline_step'] = step_roof
             line['kernels'] = kernels
         else:
-            line['roofline'] = pipe
-        # host-inclusive rate: the Python batch call (scipy priors, kappa, rows, H2D, D2H)
-        t0 = time.perf_counter()
-        reps = 3
-        for _ in range(reps):
-            model.log_posterior_batch(theta)
-        line['host_path_evals_per_s'] = args.walkers * reps / (time.perf_counter() - t0)
+            line['roofline'] = step_roof
+        if world == 1 and not args.no_extras:
+            # side figures: likelihood only from pre-derived rows (round 1's headline), the
+            # Python entry point with host vectors, small ensembles
+            rows = torch.from_numpy(model.derived_rows(theta)).to(dev)
+            like = torch.empty(args.walkers, dtype=torch.float64, device=dev)
+            for _ in range(2):
+                eng.loglike_device(args.walkers, rows.data_ptr(), 0, like.data_ptr(), sptr)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(10):
+                eng.loglike_device(args.walkers, rows.data_ptr(), 0, like.data_ptr(), sptr)
+            torch.cuda.synchronize(dev)
+            line['loglike_from_rows_evals_per_s'] = args.walkers * 10 / (time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                model.log_posterior_batch(theta)
+            line['host_path_evals_per_s'] = args.walkers * 5 / (time.perf_counter() - t0)
+            line['small_ensembles'] = small_ensembles(eng, args, torch, dev, theta_dev[0], out[0], stream)
         if world == 1 and not args.no_example:
             ex = example_model_rate()
             if ex:
@@ -422,9 +535,11 @@ def main():
             line['cpu_baseline'] = base
             if multi:
                 line['cpu_baseline_all_cores'] = multi
-            ref = np.array(vals)[:len(lnlike)]
-            got = lnlike[:len(ref)]
+            ref = np.array(vals)[:len(lnpost)]
+            ref = ref + model.log_priors_batch(theta[:len(ref)])
+            got = lnpost[:len(ref)]
             fin = np.isfinite(ref)
+            assert np.array_equal(np.isfinite(got), fin), 'GPU and oracle disagree on finiteness'
             line['check_vs_cpu_rel'] = float(np.max(np.abs(got[fin] - ref[fin]) / np.abs(ref[fin])))
         print(json.dumps(line))
     model.close()

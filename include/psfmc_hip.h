@@ -90,6 +90,14 @@ int psfmc_ctx_destroy(psfmc_ctx* ctx);
 int psfmc_row_len(const psfmc_ctx* ctx);
 
 /*
+ * Walkers per internal pass the library uses for a batch of W walkers (the batch is
+ * evaluated as ceil(W / pass) passes of at most this size; per-walker results do not depend
+ * on it).  For tests that place known vectors at pass boundaries and for profiling scripts
+ * that normalise per-launch counters; there is no reference counterpart.  < 0 on error.
+ */
+int psfmc_pass_size(const psfmc_ctx* ctx, int W);
+
+/*
  * Log-likelihood of W walkers (models.py:213-216, 233-236 for each):
  *   loglike[w] = -0.5 * sum_{good px} ( resid^2 * ivm - ln(ivm / 2pi) )
  * rows [W][row_len] and skip [W] (nonzero = prior was not finite: the walker is

@@ -26,6 +26,19 @@ def posterior_stats(model, database):
     return stats
 
 
+def posterior_psf_filename(model, database):
+    """The PSF file recorded as PSFIMG.  With several PSFs the reference takes the
+    `PSF_Index` of row `argmax(database['walker'])` -- the first row of the highest-numbered
+    walker, not the MAP row its comment announces (images.py:133-139); the same row is
+    used here so that the header matches the reference's for the same database."""
+    sel = model.config.psf_selector
+    if len(sel.filenames) > 1 and 'PSF_Index' in database.colnames:
+        row = int(np.argmax(database['walker']))
+        idx = int(np.rint(np.ravel(database['PSF_Index'][row])[0]))
+        return sel.filenames[min(max(idx, 0), len(sel.filenames) - 1)]
+    return sel.filenames[0]
+
+
 def save_posterior_images(model, database, output_name='out_{}', mode='weighted',
                           filetypes=default_filetypes, bad_px_value=0,
                           walker_min_percentile=10, batch=256):
@@ -40,7 +53,7 @@ def save_posterior_images(model, database, output_name='out_{}', mode='weighted'
     for key, (val, _) in annotate_metadata(database.meta).items():
         header[key] = val
     header.update(posterior_stats(model, database))
-    header['PSFIMG'] = str(model.config.psf_selector.filenames[0])[:60]
+    header['PSFIMG'] = str(posterior_psf_filename(model, database))[:60]
 
     unknown = [f for f in filetypes if f not in default_filetypes]
     if unknown:

@@ -117,16 +117,24 @@ __device__ inline void prep_head(double* __restrict__ prep, double sky, int psf,
     prep[kPrepInvLambda] = 1.0 / lambda;
 }
 
+// The PSF index of a caller row (public C ABI: anything may arrive) is rounded and clamped
+// to [0, n_psf): it indexes rho[] here and the kernel spectra in the column kernels.
+__device__ inline int clamp_psf_index(double v, int n_psf) {
+    const double r = rint(v);
+    if (!(r >= 0.0)) return 0;                          // negative or NaN
+    return r > (double)(n_psf - 1) ? n_psf - 1 : (int)r;
+}
+
 __device__ inline void build_prep(const double* __restrict__ row, double* __restrict__ prep,
                                   int n_ps, int n_sersic, int ny, int nx,
-                                  const double* __restrict__ rho) {
+                                  const double* __restrict__ rho, int n_psf) {
     double peak = fabs(row[0]);
     const double* r = row + kRowSky;
     double* p = prep + kPrepHead;
     for (int k = 0; k < n_ps; ++k, r += kRowPs, p += kPrepPs) peak = fmax(peak, prep_ps_block(r, p, ny, nx));
     for (int k = 0; k < n_sersic; ++k, r += kRowSersic, p += kPrepSersic)
         peak = fmax(peak, prep_sersic_block(r, p));
-    prep_head(prep, row[0], (int)r[0], peak, rho);
+    prep_head(prep, row[0], clamp_psf_index(r[0], n_psf), peak, rho);
 }
 
 // ---------------------------------------------------------------------------

@@ -113,9 +113,23 @@ template <int R, int SIGN> struct Dft {
     template <int K>
     static __device__ __forceinline__ void combine(cd (&v)[R], const cd (&ev)[R / 2], const cd (&od)[R / 2]) {
         if constexpr (K < R / 2) {
-            const cd t = tw_mul<R, K, SIGN>(od[K]);
-            v[K] = cadd(ev[K], t);
-            v[K + R / 2] = csub(ev[K], t);
+            if constexpr (K == 0 || 4 * K == R) {          // twiddle 1 or -+i: two adds per output
+                const cd t = tw_mul<R, K, SIGN>(od[K]);
+                v[K] = cadd(ev[K], t);
+                v[K + R / 2] = csub(ev[K], t);
+            } else {
+                // ev + od w in two FMAs per component, and ev - od w = 2 ev - (ev + od w) in
+                // one: 6 instructions per butterfly where twiddle-multiply-then-add/sub is 8
+                // (the (+-1 +- i)/sqrt2 twiddles included).  The second output inherits the
+                // first one's rounding: the error stays eps (|ev| + |od|) like the plain form.
+                constexpr double c = tw_cos<R, K>();
+                constexpr double s = SIGN * tw_sin<R, K>();
+                const cd e = ev[K], o = od[K];
+                const cd a = cd{__builtin_fma(o.x, c, __builtin_fma(-o.y, s, e.x)),
+                                __builtin_fma(o.x, s, __builtin_fma(o.y, c, e.y))};
+                v[K] = a;
+                v[K + R / 2] = cd{__builtin_fma(2.0, e.x, -a.x), __builtin_fma(2.0, e.y, -a.y)};
+            }
             combine<K + 1>(v, ev, od);
         }
     }

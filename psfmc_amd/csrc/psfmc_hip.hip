@@ -646,17 +646,15 @@ static int hipfft_convolve(psfmc_ctx* c, int n, const double* d_prep, const uint
     return PSFMC_OK;
 }
 
-// the likelihood pipeline over walkers whose prep records are in c->d_prep;
-// leaves the chi^2 partial sums in c->d_partial
-static int run_pipeline(psfmc_ctx* c, int W, const uint8_t* d_skip, hipStream_t st) {
+// Walkers per internal pass for a batch of W (fused path).  Pass i runs on stream
+// i % n_streams with its own T buffer, so the VALU-bound row kernels of one pass overlap the
+// HBM-bound column kernel of its neighbours; passes of equal size (no short tail), an even
+// number of them when two run at a time.
+// A batch of up to two chunks runs as ONE pass: with only two passes the fork/join
+// between the streams costs more than their overlap gains (256^2, MI355X: W = 128
+// 148 vs 157 us, W = 224 228 vs 237 us, W = 256 264 vs 269 us, W = 320 353 vs 338 us).
+static int pass_size(const psfmc_ctx* c, int W) {
     const bool fused = c->backend == PSFMC_BACKEND_FUSED;
-    // Fused path: pass i runs on stream i % n_streams with its own T buffer, so the
-    // VALU-bound row kernels of one pass overlap the HBM-bound column kernel of its
-    // neighbours.  Fork/join on events keeps the caller's stream semantics.
-    // passes of equal size (no short tail), an even number of them when two run at a time
-    // A batch of up to two chunks runs as ONE pass: with only two passes the fork/join
-    // between the streams costs more than their overlap gains (256^2, MI355X: W = 128
-    // 148 vs 157 us, W = 224 228 vs 237 us, W = 256 264 vs 269 us, W = 320 353 vs 338 us).
     int chunk = c->chunk;
     if (fused && c->n_streams > 1 && W <= chunk && W / 2 >= c->min_split) chunk = ((W + 1) / 2 + 7) & ~7;
     if (fused && W > chunk && W <= c->single_cap && c->min_split > W / 2) {
@@ -670,6 +668,21 @@ static int run_pipeline(psfmc_ctx* c, int W, const uint8_t* d_skip, hipStream_t 
     } else if (chunk > c->chunk) {
         chunk = c->chunk;
     }
+    return chunk;
+}
+
+extern "C" int psfmc_pass_size(const psfmc_ctx* c, int W) {
+    if (!c) return fail(PSFMC_EINVAL, "ctx is NULL");
+    if (W < 1 || W > c->max_walkers) return fail(PSFMC_EINVAL, "W=%d outside [1, max_walkers=%d]", W, c->max_walkers);
+    return pass_size(c, W);
+}
+
+// the likelihood pipeline over walkers whose prep records are in c->d_prep;
+// leaves the chi^2 partial sums in c->d_partial.  Fork/join on events keeps the caller's
+// stream semantics.
+static int run_pipeline(psfmc_ctx* c, int W, const uint8_t* d_skip, hipStream_t st) {
+    const bool fused = c->backend == PSFMC_BACKEND_FUSED;
+    const int chunk = pass_size(c, W);
     const int npass = (W + chunk - 1) / chunk;
     const int lanes = !fused ? 1 : (npass < c->n_streams ? npass : c->n_streams);
     if (lanes > 1) {
@@ -704,7 +717,7 @@ static int run_pipeline(psfmc_ctx* c, int W, const uint8_t* d_skip, hipStream_t 
 static int eval_device(psfmc_ctx* c, int W, const double* d_rows, const uint8_t* d_skip,
                        double* d_like, hipStream_t st) {
     hipLaunchKernelGGL(k_prep, dim3((W + 127) / 128), dim3(128), 0, st, d_rows, c->d_prep, W, c->n_ps,
-                       c->n_sersic, c->ny, c->nx, c->d_rho);
+                       c->n_sersic, c->ny, c->nx, c->d_rho, c->n_psf);
     RC_TRY(run_pipeline(c, W, d_skip, st));
     hipLaunchKernelGGL(k_finish, dim3(finish_blocks(W)), dim3(kFinishThreads), 0, st, c->d_partial, d_skip, d_like,
                        W, c->nblk);
@@ -789,7 +802,7 @@ extern "C" int psfmc_eval_images(psfmc_ctx* c, int W, const double* rows, double
     const size_t img = (size_t)c->S * sizeof(double);
     HIP_TRY(hipMemcpyAsync(c->d_rows, rows, (size_t)W * c->rlen * sizeof(double), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_prep, dim3((W + 127) / 128), dim3(128), 0, st, c->d_rows, c->d_prep, W, c->n_ps,
-                       c->n_sersic, c->ny, c->nx, c->d_rho);
+                       c->n_sersic, c->ny, c->nx, c->d_rho, c->n_psf);
     RC_TRY(ensure_image_staging(c));
     double* d_out = nullptr;     // [chunk][S] staging for derived images
     HIP_TRY(hipMalloc(&d_out, (size_t)c->chunk * img));
@@ -1021,7 +1034,7 @@ extern "C" int psfmc_accumulate_images(psfmc_ctx* c, int W, const double* rows) 
     hipStream_t st = c->stream;
     HIP_TRY(hipMemcpyAsync(c->d_rows, rows, (size_t)W * c->rlen * sizeof(double), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_prep, dim3((W + 127) / 128), dim3(128), 0, st, c->d_rows, c->d_prep, W, c->n_ps,
-                       c->n_sersic, c->ny, c->nx, c->d_rho);
+                       c->n_sersic, c->ny, c->nx, c->d_rho, c->n_psf);
     rc = accumulate_from_prep(c, W, st);
     (void)hipStreamSynchronize(st);
     if (rc == PSFMC_OK) HIP_TRY(hipGetLastError());

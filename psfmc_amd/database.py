@@ -59,9 +59,15 @@ def annotate_metadata(meta):
     return out
 
 
-def save_database(sampler, model, db_name, meta_dict=None):
+def save_database(sampler, model, db_name, meta_dict=None, sample_index='reference'):
     """Write chain + lnprobability + walker/sample indices; returns the table as
-    re-loaded from disk (database.py:6-46)."""
+    re-loaded from disk (database.py:6-46).
+
+    sample_index: 'reference' (default) writes the `sample` column exactly as the
+    reference does -- `repeat(arange(n_iter), n_walkers)` (database.py:27), which for row
+    (walker w, iteration i) holds (w * n_iter + i) // n_walkers, not i; its readers
+    (MAPSAMP in the header, analysis/images.py:52-66) then see the same file.
+    'iteration' writes i, the iteration of the row."""
     chain = sampler.chain
     n_w, n_it, _ = chain.shape
     flat = chain.reshape(n_w * n_it, chain.shape[2])
@@ -72,9 +78,12 @@ def save_database(sampler, model, db_name, meta_dict=None):
         pos += width
     cols['lnprobability'] = np.asarray(sampler.lnprobability).reshape(-1)
     cols['walker'] = np.repeat(np.arange(n_w, dtype=np.int64), n_it)
-    # the reference repeats arange(n_it) n_w times each (database.py:27); the sample
-    # index of row (w, i) is i, which is what is stored here
-    cols['sample'] = np.tile(np.arange(n_it, dtype=np.int64), n_w)
+    if sample_index == 'reference':
+        cols['sample'] = np.repeat(np.arange(n_it, dtype=np.int64), n_w)
+    elif sample_index == 'iteration':
+        cols['sample'] = np.tile(np.arange(n_it, dtype=np.int64), n_w)
+    else:
+        raise ValueError("sample_index must be 'reference' or 'iteration'")
     meta = OrderedDict(meta_dict or {})
     best = int(np.argmax(cols['lnprobability']))
     meta['MAPWLKR'] = int(cols['walker'][best])

@@ -69,6 +69,8 @@ def load_library():
     lib.psfmc_ctx_destroy.argtypes = [vp]
     lib.psfmc_row_len.restype = ci
     lib.psfmc_row_len.argtypes = [vp]
+    lib.psfmc_pass_size.restype = ci
+    lib.psfmc_pass_size.argtypes = [vp, ci]
     lib.psfmc_eval_batch.restype = ci
     lib.psfmc_eval_batch.argtypes = [vp, ci, _c_double_p, _c_u8_p, _c_double_p]
     lib.psfmc_eval_batch_device.restype = ci
@@ -194,6 +196,13 @@ class Context(object):
         if rows.shape[0] > self.max_walkers:
             raise ValueError('W={} exceeds max_walkers={}'.format(rows.shape[0], self.max_walkers))
         return rows
+
+    def pass_size(self, n_w):
+        """Walkers per internal pass for a batch of n_w (psfmc_pass_size)."""
+        rc = self._lib.psfmc_pass_size(self._ctx, int(n_w))
+        if rc < 0:
+            self._check(rc)
+        return rc
 
     def loglike(self, rows, skip=None):
         """[W, row_len] derived rows -> [W] log-likelihoods (NaN/inf preserved;

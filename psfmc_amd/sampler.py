@@ -58,6 +58,8 @@ def integrated_time(x, low=10, high=None, step=1, c=10, axis=0):
         tau = 1 + 2 * np.sum(f[tuple(idx)], axis=axis)
         if np.all(tau > 1.0) and m > c * tau.max():
             return tau
+        if c * tau.max() >= size:           # emcee 2.2.1 gives up here (recalled; parity unpinned)
+            break
     raise AutocorrError('The chain is too short to reliably estimate the '
                         'autocorrelation time')
 
@@ -269,7 +271,9 @@ class DeviceEnsembleSampler(EnsembleSampler):
     (`psfmc_stretch_run`); the host only draws the random numbers, from the same
     `RandomState` in the same order as the host loop, so both samplers produce the
     same chain.  `block` iterations are enqueued per library call (nothing is copied
-    back in between); `sample()` still yields once per iteration.
+    back in between); `sample()` still yields once per iteration, each time with the
+    generator state that follows that iteration's draws, while `iterations`, `naccepted`
+    and the stored chain advance a whole block at a time.
 
     Needs a `MultiComponentModel` whose priors all belong to the families the library
     evaluates (uniform, normal, weibull_min, discrete uniform); otherwise use
@@ -297,12 +301,14 @@ class DeviceEnsembleSampler(EnsembleSampler):
         z = np.empty((n_iter, 2, half))
         partner = np.empty((n_iter, 2, half), dtype=np.int32)
         log_u = np.empty((n_iter, 2, half))
+        states = []                     # generator state after each iteration's draws
         for it in range(n_iter):
             for h in range(2):
                 z[it, h] = ((self.a - 1.0) * self._random.rand(half) + 1) ** 2.0 / self.a
                 partner[it, h] = self._random.randint(half, size=(half,))
                 log_u[it, h] = np.log(self._random.rand(half))
-        return z, (self.dim - 1.0) * np.log(z), partner, log_u
+            states.append(self._random.get_state())
+        return (z, (self.dim - 1.0) * np.log(z), partner, log_u), states
 
     def sample(self, p0, lnprob0=None, rstate0=None, blobs0=None, iterations=1, thin=1,
                storechain=True):
@@ -328,14 +334,15 @@ class DeviceEnsembleSampler(EnsembleSampler):
         # The next block's random numbers are drawn while the GPU works on the current one
         # (the library call releases the GIL).  The draws stay in emcee's order because the
         # stream is sequential: block k+1 is drawn right after block k, only earlier in time.
-        draws = self._draw(min(self.block, iterations)) if iterations > 0 else None
+        draws, states = self._draw(min(self.block, iterations)) if iterations > 0 else (None, None)
         while done < iterations:
             n = min(self.block, iterations - done)
             n_next = min(self.block, iterations - done - n)
             job = _run_async(self.model.engine.stretch_run, p, lnprob, *draws, nacc, store=True,
                              accumulate=self.accumulate)
+            block_states = states
             try:
-                draws = self._draw(n_next) if n_next > 0 else None
+                draws, states = self._draw(n_next) if n_next > 0 else (None, None)
             finally:
                 result = job()
             p, lnprob, chain, lnchain = result
@@ -351,9 +358,12 @@ class DeviceEnsembleSampler(EnsembleSampler):
                     ind = i0 + kept // thin
                     self._chain[:, ind, :] = chain[:, kept - done, :]
                     self._lnprob[:, ind] = lnchain[:, kept - done]
+            # counters advance with the block (the device reports acceptances per block), so
+            # `acceptance_fraction` is consistent whenever the consumer looks; the yielded
+            # generator state is the one right after iteration j's draws, so that
+            # (pos, lnprob, rstate) of any yield resumes the same chain
             self.naccepted = nacc.astype(np.float64)
-            state = self.random_state
+            self.iterations += n
             for j in range(n):
-                self.iterations += 1
-                yield chain[:, j, :].copy(), lnchain[:, j].copy(), state
+                yield chain[:, j, :].copy(), lnchain[:, j].copy(), block_states[j]
             done += n

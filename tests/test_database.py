@@ -26,9 +26,14 @@ def test_save_load_roundtrip(tmp_path):
     theta = again.param_matrix(model.param_names)
     assert np.array_equal(theta, sampler.chain.reshape(42, -1))
     assert np.array_equal(again['lnprobability'], sampler.lnprobability.ravel())
-    assert again['walker'].tolist()[:8] == [0] * 7 + [1] and again['sample'].tolist()[:8] == list(range(7)) + [0]
+    # default: the reference's columns (psfMC/database.py:26-27), walker = repeat(arange(W), n_iter)
+    # and sample = repeat(arange(n_iter), W) -- NOT the iteration of the row
+    assert again['walker'].tolist() == np.repeat(np.arange(6), 7).tolist()
+    assert again['sample'].tolist() == np.repeat(np.arange(7), 6).tolist()
     best = np.argmax(sampler.lnprobability)
-    assert again.meta['MAPWLKR'] == best // 7 and again.meta['MAPSAMP'] == best % 7
+    assert again.meta['MAPWLKR'] == best // 7 and again.meta['MAPSAMP'] == best // 6
+    fixed = save_database(sampler, model, str(tmp_path / 'fixed_db.fits'), sample_index='iteration')
+    assert fixed['sample'].tolist()[:8] == list(range(7)) + [0] and fixed.meta['MAPSAMP'] == best % 7
     assert again.meta['MCBURN'] == 3 and again.meta['MCCONVRG'] is False and again.meta['MCACCEPT'] == 0.31
     kept = filter_lowp_walkers(again, percentile=20)
     assert sorted(set(kept['walker'].tolist())) == [0, 1, 2, 3, 5]

@@ -10,7 +10,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() {  # name counters...
   local name=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu $BENCH_ARGS > $OUT/$name.log 2>&1 || echo "pass $name failed"
+  rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 $BENCH_ARGS > $OUT/$name.log 2>&1 || echo "pass $name failed"
 }
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVES
 run sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS
@@ -27,7 +27,7 @@ for name in ['sq1','sq2','fetch','write']:
         agg[k][r['Counter_Name']] += float(r['Counter_Value'])
         cnt[(k, r['Counter_Name'])] += 1
     for k in sorted(agg):
-        if k.startswith(('k_rows_fwd<', 'k_cols<', 'k_rows_inv<')) and not k.endswith((', true>', 'false> ')) \
-                and 'k_cols' not in k or k.startswith('k_cols') and k.endswith('true>'):
+        if k.startswith(('k_rows_fwd<', 'k_rows_inv<', 'k_theta_prep', 'k_finish')) and 'true>' not in k \
+                or k.startswith('k_cols') and k.endswith('true>'):
             print(name, k, {c: '%.4g' % (v / cnt[(k, c)]) for c, v in agg[k].items()})
 PY
