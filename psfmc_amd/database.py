@@ -74,7 +74,7 @@ def save_database(sampler, model, db_name, meta_dict=None, sample_index='referen
     cols = OrderedDict()
     pos = 0
     for name, width in zip(model.param_names, model.param_lens):
-        cols[name] = flat[:, pos] if width == 1 else flat[:, pos:pos + width]
+        cols[name] = flat[:, pos:pos + width]      # [n, 1] for scalars, like np.split (database.py:24)
         pos += width
     cols['lnprobability'] = np.asarray(sampler.lnprobability).reshape(-1)
     cols['walker'] = np.repeat(np.arange(n_w, dtype=np.int64), n_it)
@@ -96,7 +96,7 @@ def load_database(db_name):
     cols, hdr = fits_io.read_table(db_name)
     structural = ('XTENSION', 'BITPIX', 'NAXIS', 'NAXIS1', 'NAXIS2', 'PCOUNT', 'GCOUNT', 'TFIELDS')
     meta = OrderedDict((k, v) for k, v in hdr.items()
-                       if k not in structural and not k.startswith(('TTYPE', 'TFORM')))
+                       if k not in structural and not k.startswith(('TTYPE', 'TFORM', 'TDIM')))
     return Table(cols, meta)
 
 

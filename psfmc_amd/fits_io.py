@@ -170,7 +170,7 @@ def write_table(path, columns, meta=None):
     names = list(columns)
     arrays = [np.asarray(columns[n]) for n in names]
     nrows = len(arrays[0]) if arrays else 0
-    fields, tforms = [], []
+    fields, tforms, tdims = [], [], []
     for n, a in zip(names, arrays):
         if len(a) != nrows:
             raise ValueError('column {} has {} rows, expected {}'.format(n, len(a), nrows))
@@ -182,6 +182,9 @@ def write_table(path, columns, meta=None):
         code, be = _TFORM[kind]
         fields.append((a.reshape(nrows, width), be, width))
         tforms.append(('%d%s' % (width, code)) if width > 1 else code)
+        # astropy.table records the per-row shape of every multidimensional column, [n, 1]
+        # ones included (the reference's scalar parameters are such columns, database.py:24)
+        tdims.append('(%s)' % ','.join(str(d) for d in reversed(a.shape[1:])) if a.ndim > 1 else None)
     rec = np.dtype([('c%d' % i, be, (w,)) for i, (_, be, w) in enumerate(fields)])
     table = np.zeros(nrows, dtype=rec)
     for i, (a, be, w) in enumerate(fields):
@@ -193,9 +196,11 @@ def write_table(path, columns, meta=None):
     cards = [_card('XTENSION', 'BINTABLE', 'binary table extension'), _card('BITPIX', 8),
              _card('NAXIS', 2), _card('NAXIS1', rec.itemsize), _card('NAXIS2', nrows),
              _card('PCOUNT', 0), _card('GCOUNT', 1), _card('TFIELDS', len(names))]
-    for i, (n, tf) in enumerate(zip(names, tforms)):
+    for i, (n, tf, td) in enumerate(zip(names, tforms, tdims)):
         cards.append(_card('TTYPE%d' % (i + 1), n))
         cards.append(_card('TFORM%d' % (i + 1), tf))
+        if td is not None:
+            cards.append(_card('TDIM%d' % (i + 1), td))
     for key, val in (meta or {}).items():
         comment = ''
         if isinstance(val, tuple):
@@ -231,12 +236,17 @@ def read_table(path):
         for i in range(int(hdr['TFIELDS'])):
             tform = str(hdr['TFORM%d' % (i + 1)]).strip()
             width = int(tform[:-1]) if tform[:-1] else 1
-            fields.append((str(hdr['TTYPE%d' % (i + 1)]).strip(), _TFORM_READ[tform[-1]], width))
-        rec = np.dtype([('c%d' % i, be, (w,)) for i, (_, be, w) in enumerate(fields)])
+            tdim = str(hdr.get('TDIM%d' % (i + 1), '')).strip().strip('()')
+            shape = tuple(int(d) for d in reversed(tdim.split(','))) if tdim else None
+            fields.append((str(hdr['TTYPE%d' % (i + 1)]).strip(), _TFORM_READ[tform[-1]], width, shape))
+        rec = np.dtype([('c%d' % i, be, (w,)) for i, (_, be, w, _) in enumerate(fields)])
         raw = np.frombuffer(f.read(n1 * n2), dtype=rec, count=n2)
     cols = OrderedDict()
-    for i, (name, be, w) in enumerate(fields):
+    for i, (name, be, w, shape) in enumerate(fields):
         a = raw['c%d' % i]
         a = a.astype(a.dtype.newbyteorder('='))
-        cols[name] = a[:, 0] if w == 1 else a
+        if shape is not None and int(np.prod(shape)) == w:      # TDIM: the per-row shape
+            cols[name] = a.reshape((len(a),) + shape)
+        else:
+            cols[name] = a[:, 0] if w == 1 else a
     return cols, hdr
