@@ -183,6 +183,37 @@ int psfmc_stretch_run(psfmc_ctx* ctx, int W, int n_iter, double* pos, double* ln
                       long long* naccepted, int accumulate);
 
 /*
+ * The same sampler one half-step at a time, for walkers sharded over several GPUs (one
+ * process per GPU).  Every rank opens the SAME ensemble with the SAME
+ * random numbers; per half-step each rank calls psfmc_stretch_half_eval for its contiguous
+ * block [lo, lo + n) of the half-ensemble's proposals (the proposals, priors and prep records
+ * of the whole half are formed on every rank; only the block's likelihood pipeline runs), the
+ * caller all-gathers the blocks' log-posteriors (torch.distributed / RCCL: the one collective
+ * of the path) and hands the gathered half-ensemble vector to psfmc_stretch_half_accept, which
+ * applies the identical accept / move / chain entry on every rank.  There is no reference
+ * counterpart (psfMC/fitting.py:55 gave up on parallel evaluation); the result equals
+ * psfmc_stretch_run's chain bit for bit.  d_* are device pointers, `stream` a hipStream_t
+ * (NULL = the context's stream); nothing is synchronised except in open / close.
+ *   psfmc_stretch_accumulate   add the images of walkers [lo, lo + n) of the current
+ *                              ensemble to this rank's posterior sums
+ *   psfmc_get/set_accumulated_sums   the raw sums [4][ny][nx] (raw, convolved, model
+ *                              variance, PS-only convolved) + sample count, so that ranks'
+ *                              shares can be added up (all-reduce) before
+ *                              psfmc_get_accumulated turns them into means
+ */
+int psfmc_stretch_open(psfmc_ctx* ctx, int W, int n_iter, const double* pos, const double* lnprob,
+                       const double* z, const double* lz, const int* partner, const double* log_u,
+                       const long long* naccepted, int store_chain);
+int psfmc_stretch_half_eval(psfmc_ctx* ctx, int it, int h, int lo, int n, double* d_newlnp_block,
+                            void* stream);
+int psfmc_stretch_half_accept(psfmc_ctx* ctx, int it, int h, const double* d_newlnp_half, void* stream);
+int psfmc_stretch_accumulate(psfmc_ctx* ctx, int lo, int n, void* stream);
+int psfmc_stretch_close(psfmc_ctx* ctx, double* pos, double* lnprob, double* chain,
+                        double* lnprob_chain, long long* naccepted, void* stream);
+int psfmc_get_accumulated_sums(psfmc_ctx* ctx, double* sums, long long* count);
+int psfmc_set_accumulated_sums(psfmc_ctx* ctx, const double* sums, long long count);
+
+/*
  * Posterior-image accumulation on the device (replaces the per-sample blob
  * hand-over and the running mean of MultiComponentModel.accumulate_images,
  * models.py:74-97, fed from fitting.py:83).  psfmc_accumulate_images adds the images

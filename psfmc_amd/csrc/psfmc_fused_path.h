@@ -191,15 +191,37 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
 }
 
 // ---------------------------------------------------------------------------
+// Work order of the column kernels.  Column items are numbered kx-major, then walker, then
+// component: item = (kx * n_w + w) * 2 + c, so that all walkers of a pass meet one kernel-
+// spectrum column Kt[psf][kx][c][.] while it is still in an L2 (walker-major order re-read every
+// Kt column from the Infinity Cache once per walker: +16 % fetch at 256^2 where Kt is 1 MB, +100 %
+// at 1024^2 where it is 17 MB -- profiles/r2_pmc_*).  The two components of a (kx, w) pair stay
+// adjacent: they are the interleaved halves of the same cache lines.
+// The list of workgroup-sized groups is cut into one contiguous share per XCD (workgroups are
+// dealt round-robin over the 8 XCDs, so b % 8 names the XCD a workgroup shares its L2 with;
+// MI355X_MICROARCH.md, Workgroup dispatch -- a speed assumption only: any placement covers
+// every group exactly once).
+// ---------------------------------------------------------------------------
+struct GroupRange { int first, end, step; };
+__device__ __forceinline__ GroupRange xcd_group_range(int n_groups) {
+    const int nb = (int)gridDim.x, b = (int)blockIdx.x;
+    const int nx = nb >= 8 ? 8 : 1;
+    const int x = b % nx, j = b / nx;
+    const int blocks_here = (nb - x + nx - 1) / nx;
+    const int lo = (int)((long long)x * n_groups / nx), hi = (int)((long long)(x + 1) * n_groups / nx);
+    return GroupRange{lo + j, hi, blocks_here};
+}
+
+// ---------------------------------------------------------------------------
 // cols.  persistent grid of 256-thread workgroups; slot s of a workgroup works
-// on column col = (walker*nxh + kx)*2 + c.
+// on column item (kx*n_w + walker)*2 + c.
 //   CONVOLVE = true : FFT_y, * Kt[psf][kx][c][.], IFFT_y (the hot path)
 //   CONVOLVE = false: FFT_y only (PSF spectra at setup)
 // ---------------------------------------------------------------------------
 template <int NY, bool CONVOLVE>
 __global__ void __launch_bounds__(kColThreads, fused_min_waves<NY>())
 k_cols(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restrict__ prep,
-       const uint8_t* __restrict__ skip, const cd* __restrict__ twy, int plen, int nxh, int n_cols,
+       const uint8_t* __restrict__ skip, const cd* __restrict__ twy, int plen, int nxh, int n_w,
        int rg_log2) {
     constexpr int P = FftShape<NY>::P, T = FftShape<NY>::T;
     constexpr int FPB = col_ffts_per_block<NY>();
@@ -212,19 +234,23 @@ k_cols(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restric
     constexpr int TM = PSFMC_TW_MODE_COLS;
     cd tw[TwRegs<NY, TM>::value];
     load_twiddles<NY, TM>(tw, twy, t, twl, lane);
+    const int n_cols = n_w * 2 * nxh;
     const int n_groups = (n_cols + FPB - 1) / FPB;
+    const GroupRange gr = xcd_group_range(n_groups);
     // slot s of group grp: its column, whether it is live, and the lane's first element
     // Slots past the last column (final group only) and skipped walkers still LOAD -- from
     // the last valid column / the walker's stale data -- and transform; only their stores are
     // masked.  Zero-filling their registers instead cost 32 moves per group in every lane.
-    auto locate = [&](int grp, int& pr, int& c, bool& active) -> cd* {
+    auto locate = [&](int grp, int& w, int& kx, int& c, bool& active) -> cd* {
         int col = grp * FPB + s;
         active = col < n_cols;
         col = active ? col : n_cols - 1;
-        pr = col >> 1;                            // (walker, kx) pair
         c = col & 1;                              // component
-        if (active && skip && skip[pr / nxh]) active = false;
-        return Tbuf + (size_t)pr * 2 * NY + (c << rg_log2) + t_elem(t, 0, rg_log2);
+        const int pr = col >> 1;                  // kx * n_w + walker
+        kx = pr / n_w;
+        w = pr - kx * n_w;
+        if (active && skip && skip[w]) active = false;
+        return Tbuf + ((size_t)w * nxh + kx) * 2 * NY + (c << rg_log2) + t_elem(t, 0, rg_log2);
     };
     // Software pipeline (P <= 16): the next group's column is loaded into a second register
     // set while this one is transformed.  Loads return in order, so they are issued AFTER the
@@ -234,11 +260,11 @@ k_cols(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restric
     constexpr bool PF = PSFMC_COLS_PREFETCH && P <= 16;
     struct Slot {
         cd* base;
-        int pr, c;
+        int w, kx, c;
         bool active;
     };
     auto load_group = [&](int grp, cd (&dst)[P], Slot& sl) {
-        sl.base = locate(grp, sl.pr, sl.c, sl.active);
+        sl.base = locate(grp, sl.w, sl.kx, sl.c, sl.active);
 #pragma unroll
         for (int a = 0; a < P; ++a) dst[a] = load_stream(sl.base + 2 * T * a);
     };
@@ -246,10 +272,9 @@ k_cols(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restric
     auto transform = [&](cd (&v)[P], const Slot& sl, auto&& between) {
         fft_wave<NY, -1, TM>(v, tw, twy, t, xbuf, twl);
         if constexpr (CONVOLVE) {
-            const int w = sl.pr / nxh, kx = sl.pr - w * nxh;
             // a skipped walker's record may hold anything: its (masked) lanes use PSF 0
-            const int psf = sl.active ? (int)prep[(size_t)w * plen + kPrepPsfIdx] : 0;
-            const cd* k = Kt + (((size_t)psf * nxh + kx) * 2 + sl.c) * NY;
+            const int psf = sl.active ? (int)prep[(size_t)sl.w * plen + kPrepPsfIdx] : 0;
+            const cd* k = Kt + (((size_t)psf * nxh + sl.kx) * 2 + sl.c) * NY;
 #pragma unroll
             for (int e = 0; e < P; ++e) v[e] = cmul(v[e], k[t + T * e]);
         }
@@ -264,27 +289,27 @@ k_cols(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restric
         // two register sets take turns (no copies): while one is transformed the other
         // receives the next group
         cd A[P], B[P];
-        Slot sa{Tbuf, 0, 0, false}, sb{Tbuf, 0, 0, false};
-        const int step = (int)gridDim.x;
-        if ((int)blockIdx.x < n_groups) load_group(blockIdx.x, A, sa);
-        for (int grp = blockIdx.x; grp < n_groups; grp += 2 * step) {
+        Slot sa{Tbuf, 0, 0, 0, false}, sb{Tbuf, 0, 0, 0, false};
+        const int step = gr.step;
+        if (gr.first < gr.end) load_group(gr.first, A, sa);
+        for (int grp = gr.first; grp < gr.end; grp += 2 * step) {
             const int g1 = grp + step, g2 = g1 + step;
             transform(A, sa, [&] {
                 __builtin_amdgcn_sched_barrier(0);
-                if (g1 < n_groups) load_group(g1, B, sb);
+                if (g1 < gr.end) load_group(g1, B, sb);
                 __builtin_amdgcn_sched_barrier(0);
             });
-            if (g1 < n_groups)
+            if (g1 < gr.end)
                 transform(B, sb, [&] {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (g2 < n_groups) load_group(g2, A, sa);
+                    if (g2 < gr.end) load_group(g2, A, sa);
                     __builtin_amdgcn_sched_barrier(0);
                 });
         }
     } else {
-        for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        for (int grp = gr.first; grp < gr.end; grp += gr.step) {
             cd v[P];
-            Slot sl{Tbuf, 0, 0, false};
+            Slot sl{Tbuf, 0, 0, 0, false};
             load_group(grp, v, sl);
             transform(v, sl, [] {});
         }
@@ -310,7 +335,7 @@ template <int NY> constexpr size_t fused_col3_lds_bytes() {
 template <int NY, bool CONVOLVE>
 __global__ void __launch_bounds__(kColThreads, Fft3Shape<NY>::R1 > 8 ? PSFMC_COLS3_WAVES : 2)
 k_cols3(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restrict__ prep,
-        const uint8_t* __restrict__ skip, const cd* __restrict__ twy, int plen, int nxh, int n_cols,
+        const uint8_t* __restrict__ skip, const cd* __restrict__ twy, int plen, int nxh, int n_w,
         int rg_log2) {
     constexpr int R1 = Fft3Shape<NY>::R1;
     constexpr int WPB = kColThreads / 64;
@@ -328,11 +353,15 @@ k_cols3(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restri
     }
     const int rg = 1 << rg_log2;
     const int e0 = t_elem(t, 0, rg_log2);              // offset of y = t; y = 64 a + t adds 128 a
-    for (int col = blockIdx.x * WPB + wave; col < n_cols; col += gridDim.x * WPB) {
-        const int pr = col >> 1, c = col & 1;           // (walker, kx) pair, component
-        const int w = pr / nxh, kx = pr - w * nxh;
+    const int n_cols = n_w * 2 * nxh;
+    const GroupRange gr = xcd_group_range((n_cols + WPB - 1) / WPB);
+    for (int grp = gr.first; grp < gr.end; grp += gr.step) {
+        const int col = grp * WPB + wave;
+        if (col >= n_cols) continue;                     // wave-uniform
+        const int pr = col >> 1, c = col & 1;           // kx * n_w + walker, component
+        const int kx = pr / n_w, w = pr - kx * n_w;
         if (skip && skip[w]) continue;                   // wave-uniform
-        cd* base = Tbuf + (size_t)pr * 2 * NY + c * rg + e0;
+        cd* base = Tbuf + ((size_t)w * nxh + kx) * 2 * NY + c * rg + e0;
         cd v[R1];
 #pragma unroll
         for (int a = 0; a < R1; ++a) v[a] = base[128 * a];

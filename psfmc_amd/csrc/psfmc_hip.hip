@@ -132,6 +132,17 @@ struct psfmc_ctx {
     double* d_rawstage = nullptr;   // [img_cap][S] raw-model staging for the sums
     long long acc_count = 0;
     int cols_grid = 0;
+    // device-resident sampler state (psfmc_stretch_*): grow-only buffers
+    struct Stretch {
+        double *pos = nullptr, *lnp = nullptr, *q = nullptr, *newlnp = nullptr, *rand = nullptr;
+        double *chain = nullptr, *lnchain = nullptr;
+        int *partner = nullptr, *iter = nullptr;
+        long long* nacc = nullptr;
+        size_t cap_pos = 0, cap_lnp = 0, cap_q = 0, cap_new = 0, cap_rand = 0, cap_chain = 0, cap_lnchain = 0,
+               cap_partner = 0, cap_iter = 0, cap_nacc = 0;
+        int W = 0, n_iter = 0;
+        bool store = false, open = false;
+    } stretch;
 };
 
 // ---------------------------------------------------------------------------
@@ -217,8 +228,9 @@ static int launch_rows_fwd(psfmc_ctx* c, int n, const double* prep, const uint8_
 }
 
 template <int NY, bool CONVOLVE>
-static int launch_cols(psfmc_ctx* c, cd* Tbuf, int n_cols, const double* prep, const uint8_t* skip,
+static int launch_cols(psfmc_ctx* c, cd* Tbuf, int n_w, const double* prep, const uint8_t* skip,
                        hipStream_t st) {
+    const int n_cols = n_w * 2 * c->nxh;
     if constexpr (NY >= 512) {          // long columns: wave-wide three-stage engine
         if (c->cols3) {
             constexpr size_t lds3 = fused_col3_lds_bytes<NY>();
@@ -226,7 +238,7 @@ static int launch_cols(psfmc_ctx* c, cd* Tbuf, int n_cols, const double* prep, c
             const int blocks = (n_cols + per_block - 1) / per_block;
             const int grid3 = blocks < 4 * c->cols_grid ? blocks : 4 * c->cols_grid;
             hipLaunchKernelGGL((k_cols3<NY, CONVOLVE>), dim3(grid3), dim3(kColThreads), lds3, st, Tbuf,
-                               c->d_Kt, prep, skip, c->d_twy, c->plen, c->nxh, n_cols, c->rg_log2);
+                               c->d_Kt, prep, skip, c->d_twy, c->plen, c->nxh, n_w, c->rg_log2);
             return PSFMC_OK;
         }
     }
@@ -240,7 +252,7 @@ static int launch_cols(psfmc_ctx* c, cd* Tbuf, int n_cols, const double* prep, c
     const int groups = (n_cols + col_ffts_per_block<NY>() - 1) / col_ffts_per_block<NY>();
     const int grid = groups < c->cols_grid ? groups : c->cols_grid;
     hipLaunchKernelGGL((k_cols<NY, CONVOLVE>), dim3(grid), dim3(kColThreads), lds, st, Tbuf, c->d_Kt,
-                       prep, skip, c->d_twy, c->plen, c->nxh, n_cols, c->rg_log2);
+                       prep, skip, c->d_twy, c->plen, c->nxh, n_w, c->rg_log2);
     return PSFMC_OK;
 }
 
@@ -307,7 +319,7 @@ static int fused_forward(psfmc_ctx* c, int n, cd* Tbuf, const double* prep, cons
                                                                nullptr, raw_out, st))));
     }
     ProfScope ps(c, PROF_COLS, st);
-    DISPATCH_LEN(c->ny, RC_TRY((launch_cols<N_, true>(c, Tbuf, n * 2 * c->nxh, prep, skip, st))));
+    DISPATCH_LEN(c->ny, RC_TRY((launch_cols<N_, true>(c, Tbuf, n, prep, skip, st))));
     return PSFMC_OK;
 }
 
@@ -358,7 +370,7 @@ static int spectra_fused(psfmc_ctx* c, const double* d_canvas) {
     HIP_TRY(hipMalloc(&c->d_Kt, n_el * sizeof(cd)));
     DISPATCH_LEN(c->nx, RC_TRY((launch_rows_fwd<N_, true>(c, c->n_psf, nullptr, nullptr, c->d_Kraw, 0,
                                                           d_canvas, c->d_rho, nullptr, c->stream))));
-    DISPATCH_LEN(c->ny, RC_TRY((launch_cols<N_, false>(c, c->d_Kraw, c->n_psf * 2 * c->nxh, nullptr,
+    DISPATCH_LEN(c->ny, RC_TRY((launch_cols<N_, false>(c, c->d_Kraw, c->n_psf, nullptr,
                                                        nullptr, c->stream))));
     hipLaunchKernelGGL(k_scale_kernel_spectrum, dim3(256), dim3(256), 0, c->stream, c->d_Kraw, c->d_Kt,
                        (int)n_el, c->ny, c->nxh, c->rg_log2, 0.25 / (double)c->S);
@@ -538,7 +550,9 @@ extern "C" int psfmc_ctx_destroy(psfmc_ctx* c) {
                     c->d_like, c->d_skip, c->d_partial, c->d_real,  c->d_spec,  c->d_Ts[0], c->d_Kraw,
                     c->d_Kt,   c->d_twx,  c->d_twy,     c->d_img0,  c->d_img1, c->d_rho,   c->d_field, c->d_Ts[1], c->d_acc,
                     c->d_layout_blob, c->d_theta, c->d_extra, c->d_lnprior, c->d_rawstage,
-                    c->d_Ts[2], c->d_Ts[3]};
+                    c->d_Ts[2], c->d_Ts[3], c->stretch.pos, c->stretch.lnp, c->stretch.q, c->stretch.newlnp,
+                    c->stretch.rand, c->stretch.chain, c->stretch.lnchain, c->stretch.partner, c->stretch.iter,
+                    c->stretch.nacc};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -680,7 +694,7 @@ extern "C" int psfmc_pass_size(const psfmc_ctx* c, int W) {
 // the likelihood pipeline over walkers whose prep records are in c->d_prep;
 // leaves the chi^2 partial sums in c->d_partial.  Fork/join on events keeps the caller's
 // stream semantics.
-static int run_pipeline(psfmc_ctx* c, int W, const uint8_t* d_skip, hipStream_t st) {
+static int run_pipeline(psfmc_ctx* c, int W, const uint8_t* d_skip, hipStream_t st, int w_off = 0) {
     const bool fused = c->backend == PSFMC_BACKEND_FUSED;
     const int chunk = pass_size(c, W);
     const int npass = (W + chunk - 1) / chunk;
@@ -692,9 +706,10 @@ static int run_pipeline(psfmc_ctx* c, int W, const uint8_t* d_skip, hipStream_t 
     int pass = 0;
     for (int w0 = 0; w0 < W; w0 += chunk, ++pass) {
         const int n = W - w0 < chunk ? W - w0 : chunk;
-        const double* prep = c->d_prep + (size_t)w0 * c->plen;
-        const uint8_t* skip = d_skip ? d_skip + w0 : nullptr;
-        double* partial = c->d_partial + (size_t)w0 * c->nblk;
+        // walkers [w_off, w_off + W) of the prep / skip / partial arrays
+        const double* prep = c->d_prep + (size_t)(w_off + w0) * c->plen;
+        const uint8_t* skip = d_skip ? d_skip + w_off + w0 : nullptr;
+        double* partial = c->d_partial + (size_t)(w_off + w0) * c->nblk;
         if (fused) {
             const int lane = pass % lanes;
             hipStream_t s = lane ? c->side[lane] : st;
@@ -1044,105 +1059,154 @@ extern "C" int psfmc_accumulate_images(psfmc_ctx* c, int W, const double* rows) 
 // ---------------------------------------------------------------------------
 // device-resident stretch-move sampling
 // ---------------------------------------------------------------------------
+// Sampler buffers live in the context and only ever grow: a block of iterations used to pay
+// a dozen hipMalloc / hipFree.
+template <typename Tp>
+static int grow(Tp** p, size_t* cap, size_t need) {
+    if (need <= *cap && *p) return PSFMC_OK;
+    if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
+    HIP_TRY(hipMalloc(p, (need ? need : 1) * sizeof(Tp)));
+    *cap = need ? need : 1;
+    return PSFMC_OK;
+}
+
+static int stretch_check(psfmc_ctx* c, int W) {
+    if (!c) return fail(PSFMC_EINVAL, "ctx is NULL");
+    if (!c->has_layout) return fail(PSFMC_EINVAL, "psfmc_set_layout has not been called");
+    if (W < 2 || (W & 1) || W > c->max_walkers) return fail(PSFMC_EINVAL, "W must be even, 2..max_walkers");
+    const int P = c->layout.n_params;
+    if (P < 1) return fail(PSFMC_EINVAL, "model has no free parameter");
+    // every prior must be evaluated on the device
+    std::vector<int> fam(P);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpy(fam.data(), c->layout.family, P * sizeof(int), hipMemcpyDeviceToHost));
+    for (int f : fam)
+        if (f == PRIOR_HOST) return fail(PSFMC_EINVAL, "a prior is evaluated on the host; use the host sampler");
+    return PSFMC_OK;
+}
+
+// upload the walkers, counters and the block's random numbers; size the chain buffers
+static int stretch_upload(psfmc_ctx* c, int W, int n_iter, const double* pos, const double* lnprob,
+                          int lnprob_valid, const double* z, const double* lz, const int* partner,
+                          const double* log_u, const long long* naccepted, bool store, hipStream_t st) {
+    psfmc_ctx::Stretch& S = c->stretch;
+    const int P = c->layout.n_params, half = W / 2;
+    const size_t n_rand = (size_t)n_iter * W;
+    RC_TRY(grow(&S.pos, &S.cap_pos, (size_t)W * P));
+    RC_TRY(grow(&S.lnp, &S.cap_lnp, (size_t)W));
+    RC_TRY(grow(&S.q, &S.cap_q, (size_t)half * P));
+    RC_TRY(grow(&S.newlnp, &S.cap_new, (size_t)half));
+    RC_TRY(grow(&S.nacc, &S.cap_nacc, (size_t)W));
+    RC_TRY(grow(&S.rand, &S.cap_rand, 3 * n_rand));
+    RC_TRY(grow(&S.partner, &S.cap_partner, n_rand));
+    RC_TRY(grow(&S.iter, &S.cap_iter, (size_t)1));
+    if (store && n_iter) {
+        RC_TRY(grow(&S.chain, &S.cap_chain, (size_t)W * n_iter * P));
+        RC_TRY(grow(&S.lnchain, &S.cap_lnchain, (size_t)W * n_iter));
+    }
+    S.W = W; S.n_iter = n_iter; S.store = store && n_iter; S.open = true;
+    if (n_rand) {
+        HIP_TRY(hipMemcpyAsync(S.rand, z, n_rand * sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(S.rand + n_rand, lz, n_rand * sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(S.rand + 2 * n_rand, log_u, n_rand * sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(S.partner, partner, n_rand * sizeof(int), hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(hipMemcpyAsync(S.pos, pos, (size_t)W * P * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(S.nacc, naccepted, (size_t)W * sizeof(long long), hipMemcpyHostToDevice, st));
+    if (lnprob_valid)
+        HIP_TRY(hipMemcpyAsync(S.lnp, lnprob, (size_t)W * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(S.iter, 0, sizeof(int), st));
+    return PSFMC_OK;
+}
+
+static int stretch_download(psfmc_ctx* c, double* pos, double* lnprob, double* chain, double* lnprob_chain,
+                            long long* naccepted, hipStream_t st) {
+    psfmc_ctx::Stretch& S = c->stretch;
+    const int P = c->layout.n_params, W = S.W;
+    HIP_TRY(hipMemcpyAsync(pos, S.pos, (size_t)W * P * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(lnprob, S.lnp, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(naccepted, S.nacc, (size_t)W * sizeof(long long), hipMemcpyDeviceToHost, st));
+    if (S.store && chain) {
+        HIP_TRY(hipMemcpyAsync(chain, S.chain, (size_t)W * S.n_iter * P * sizeof(double), hipMemcpyDeviceToHost, st));
+        if (lnprob_chain)
+            HIP_TRY(hipMemcpyAsync(lnprob_chain, S.lnchain, (size_t)W * S.n_iter * sizeof(double),
+                                   hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    return PSFMC_OK;
+}
+
+// first stage of a half-step: the stretch proposals of half `h` at iteration `it`, their
+// priors and prep records (every walker of the half: the accept step needs every proposal)
+static void stretch_propose(psfmc_ctx* c, int it, int h, bool graph_iter, hipStream_t st) {
+    psfmc_ctx::Stretch& S = c->stretch;
+    launch_theta_prep(c, S.W / 2, nullptr, nullptr, nullptr, st,
+                      StretchIn{S.pos, S.q, S.rand, S.partner, graph_iter ? S.iter : nullptr, it, S.W / 2, h});
+}
+
+// last stage: sum (or take the gathered values), accept, move, chain entry
+static void stretch_accept(psfmc_ctx* c, int it, int h, const double* d_newlnp, bool graph_iter, hipStream_t st) {
+    psfmc_ctx::Stretch& S = c->stretch;
+    const int half = S.W / 2;
+    const size_t n_rand = (size_t)S.n_iter * S.W;
+    hipLaunchKernelGGL(k_stretch_finish, dim3(finish_blocks(half)), dim3(kFinishThreads), 0, st, c->d_partial,
+                       c->d_skip, c->d_lnprior, c->nblk, d_newlnp, S.pos, S.lnp, S.q, S.rand + n_rand,
+                       S.rand + 2 * n_rand, S.nacc, S.store ? S.chain : nullptr, S.store ? S.lnchain : nullptr,
+                       graph_iter ? S.iter : nullptr, it, S.n_iter, half, h, c->layout.n_params);
+}
+
+static int stretch_prepare_accumulation(psfmc_ctx* c) {
+    if (!c->d_acc) RC_TRY(psfmc_reset_accumulated(c));
+    RC_TRY(ensure_image_staging(c));
+    if (c->backend == PSFMC_BACKEND_FUSED && !c->d_rawstage)
+        HIP_TRY(hipMalloc(&c->d_rawstage, (size_t)c->img_cap * c->S * sizeof(double)));
+    return PSFMC_OK;
+}
+
 extern "C" int psfmc_stretch_run(psfmc_ctx* c, int W, int n_iter, double* pos, double* lnprob,
                                  int lnprob_valid, const double* z, const double* lz, const int* partner,
                                  const double* log_u, double* chain, double* lnprob_chain,
                                  long long* naccepted, int accumulate) {
-    if (!c) return fail(PSFMC_EINVAL, "ctx is NULL");
-    if (!c->has_layout) return fail(PSFMC_EINVAL, "psfmc_set_layout has not been called");
-    if (W < 2 || (W & 1) || W > c->max_walkers) return fail(PSFMC_EINVAL, "W must be even, 2..max_walkers");
+    RC_TRY(stretch_check(c, W));
     if (n_iter < 0 || !pos || !lnprob || !naccepted || (n_iter && (!z || !lz || !partner || !log_u)))
         return fail(PSFMC_EINVAL, "NULL buffer");
-    const int P = c->layout.n_params, half = W / 2;
-    if (P < 1) return fail(PSFMC_EINVAL, "model has no free parameter");
-    {   // every prior must be evaluated on the device
-        std::vector<int> fam(P);
-        HIP_TRY(hipSetDevice(c->device));
-        HIP_TRY(hipMemcpy(fam.data(), c->layout.family, P * sizeof(int), hipMemcpyDeviceToHost));
-        for (int f : fam)
-            if (f == PRIOR_HOST) return fail(PSFMC_EINVAL, "a prior is evaluated on the host; use the host sampler");
-    }
+    const int half = W / 2;
     hipStream_t st = c->stream;
-    const size_t n_rand = (size_t)n_iter * W;
-    double *d_pos = nullptr, *d_lnp = nullptr, *d_q = nullptr, *d_new = nullptr, *d_rand = nullptr;
-    double *d_chain = nullptr, *d_lnchain = nullptr;
-    int *d_partner = nullptr, *d_iter = nullptr;
-    long long* d_nacc = nullptr;
-    int rc = PSFMC_OK;
-    auto cleanup = [&]() {
-        void* bufs[] = {d_pos, d_lnp, d_q, d_new, d_rand, d_chain, d_lnchain, d_partner, d_nacc, d_iter};
-        for (void* p : bufs)
-            if (p) (void)hipFree(p);
-    };
-#define SR_TRY(expr)                                                                         \
-    do {                                                                                     \
-        if ((expr) != hipSuccess) {                                                          \
-            rc = fail(PSFMC_EHIP, "%s failed: %s", #expr, hipGetErrorString(hipGetLastError())); \
-            cleanup();                                                                       \
-            return rc;                                                                       \
-        }                                                                                    \
-    } while (0)
-    SR_TRY(hipMalloc(&d_pos, (size_t)W * P * sizeof(double)));
-    SR_TRY(hipMalloc(&d_lnp, (size_t)W * sizeof(double)));
-    SR_TRY(hipMalloc(&d_q, (size_t)half * P * sizeof(double)));
-    SR_TRY(hipMalloc(&d_new, (size_t)half * sizeof(double)));
-    SR_TRY(hipMalloc(&d_nacc, (size_t)W * sizeof(long long)));
-    if (n_rand) {
-        SR_TRY(hipMalloc(&d_rand, 3 * n_rand * sizeof(double)));
-        SR_TRY(hipMalloc(&d_partner, n_rand * sizeof(int)));
-        SR_TRY(hipMemcpyAsync(d_rand, z, n_rand * sizeof(double), hipMemcpyHostToDevice, st));
-        SR_TRY(hipMemcpyAsync(d_rand + n_rand, lz, n_rand * sizeof(double), hipMemcpyHostToDevice, st));
-        SR_TRY(hipMemcpyAsync(d_rand + 2 * n_rand, log_u, n_rand * sizeof(double), hipMemcpyHostToDevice, st));
-        SR_TRY(hipMemcpyAsync(d_partner, partner, n_rand * sizeof(int), hipMemcpyHostToDevice, st));
-    }
-    if (chain && n_iter) SR_TRY(hipMalloc(&d_chain, (size_t)W * n_iter * P * sizeof(double)));
-    if (chain && n_iter) SR_TRY(hipMalloc(&d_lnchain, (size_t)W * n_iter * sizeof(double)));
-    SR_TRY(hipMemcpyAsync(d_pos, pos, (size_t)W * P * sizeof(double), hipMemcpyHostToDevice, st));
-    SR_TRY(hipMemcpyAsync(d_nacc, naccepted, (size_t)W * sizeof(long long), hipMemcpyHostToDevice, st));
-    if (lnprob_valid)
-        SR_TRY(hipMemcpyAsync(d_lnp, lnprob, (size_t)W * sizeof(double), hipMemcpyHostToDevice, st));
-    else
-        rc = eval_theta_device(c, W, d_pos, nullptr, d_lnp, st);
-    if (accumulate && rc == PSFMC_OK && !c->d_acc) rc = psfmc_reset_accumulated(c);
-    if (accumulate && rc == PSFMC_OK) rc = ensure_image_staging(c);
-    if (accumulate && rc == PSFMC_OK && c->backend == PSFMC_BACKEND_FUSED && !c->d_rawstage)
-        SR_TRY(hipMalloc(&c->d_rawstage, (size_t)c->img_cap * c->S * sizeof(double)));
-    SR_TRY(hipMalloc(&d_iter, sizeof(int)));
-    SR_TRY(hipMemsetAsync(d_iter, 0, sizeof(int), st));
+    psfmc_ctx::Stretch& S = c->stretch;
+    RC_TRY(stretch_upload(c, W, n_iter, pos, lnprob, lnprob_valid, z, lz, partner, log_u, naccepted,
+                          chain != nullptr, st));
+    if (!lnprob_valid) RC_TRY(eval_theta_device(c, W, S.pos, nullptr, S.lnp, st));
+    if (accumulate) RC_TRY(stretch_prepare_accumulation(c));
     // one iteration: two half-ensemble proposals (chain entries included), optional image
-    // sums.  The kernels take the iteration number by value, or from *d_iter when one
-    // captured iteration is replayed as a hipGraph.
+    // sums.  A half-step is three stages: proposals + priors + prep records (one kernel), the
+    // likelihood pipeline, and sum + accept + move + chain entry (one kernel).  The kernels take
+    // the iteration number by value, or from *S.iter when one captured iteration is replayed as
+    // a hipGraph.
     const bool use_d_iter = n_iter > 2 && c->use_graph && !c->profile && c->backend == PSFMC_BACKEND_FUSED;
     int it_host = 0;
     auto iteration = [&]() -> int {
-        // a half-step is three stages: proposals + priors + prep records (one kernel), the
-        // likelihood pipeline, and sum + accept + move + chain entry (one kernel)
         for (int h = 0; h < 2; ++h) {
-            launch_theta_prep(c, half, nullptr, nullptr, nullptr, st,
-                              StretchIn{d_pos, d_q, d_rand, d_partner, use_d_iter ? d_iter : nullptr, it_host,
-                                        half, h});
+            stretch_propose(c, it_host, h, use_d_iter, st);
             RC_TRY(run_pipeline(c, half, c->d_skip, st));
-            hipLaunchKernelGGL(k_stretch_finish, dim3(finish_blocks(half)), dim3(kFinishThreads), 0, st, c->d_partial,
-                               c->d_skip, c->d_lnprior, c->nblk, d_pos, d_lnp, d_q, d_rand + n_rand,
-                               d_rand + 2 * n_rand, d_nacc, d_chain, d_lnchain,
-                               use_d_iter ? d_iter : nullptr, it_host, n_iter, half, h, P);
+            stretch_accept(c, it_host, h, nullptr, use_d_iter, st);
         }
         if (accumulate) {
-            launch_theta_prep(c, W, d_pos, nullptr, nullptr, st, StretchIn{});
+            launch_theta_prep(c, W, S.pos, nullptr, nullptr, st, StretchIn{});
             RC_TRY(accumulate_from_prep(c, W, st));
         }
-        if (use_d_iter) hipLaunchKernelGGL(k_stretch_next, dim3(1), dim3(1), 0, st, d_iter);
+        if (use_d_iter) hipLaunchKernelGGL(k_stretch_next, dim3(1), dim3(1), 0, st, S.iter);
         ++it_host;
         return PSFMC_OK;
     };
-    // Capture one iteration into a hipGraph and replay it: a 128-walker half-step is
-    // ~10 short launches, and their launch gaps were a third of the iteration.
+    // Optionally capture one iteration into a hipGraph and replay it (set_option "graph";
+    // measured: no gain, the iteration is kernel-time- not launch-bound).
+    int rc = PSFMC_OK;
     hipGraphExec_t exec = nullptr;
-    if (rc == PSFMC_OK && use_d_iter) {
+    if (use_d_iter) {
         hipGraph_t graph = nullptr;
         // un-captured warm-up of the pipeline: one-time attribute calls must not fall
         // inside the capture
-        rc = eval_theta_device(c, half, d_pos, nullptr, d_new, st);
+        rc = eval_theta_device(c, half, S.pos, nullptr, S.newlnp, st);
         const long long count_before = c->acc_count;
         if (rc == PSFMC_OK && hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
             const int crc = iteration();
@@ -1151,6 +1215,7 @@ extern "C" int psfmc_stretch_run(psfmc_ctx* c, int W, int n_iter, double* pos, d
                 hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess)
                 exec = nullptr;
             if (graph) (void)hipGraphDestroy(graph);
+            it_host = 0;
         }
         (void)hipGetLastError();
         c->acc_count = count_before;            // the captured pass did not run
@@ -1167,22 +1232,115 @@ extern "C" int psfmc_stretch_run(psfmc_ctx* c, int W, int n_iter, double* pos, d
         (void)hipStreamSynchronize(st);
         (void)hipGraphExecDestroy(exec);
     }
-    if (rc == PSFMC_OK) {
-        SR_TRY(hipMemcpyAsync(pos, d_pos, (size_t)W * P * sizeof(double), hipMemcpyDeviceToHost, st));
-        SR_TRY(hipMemcpyAsync(lnprob, d_lnp, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, st));
-        SR_TRY(hipMemcpyAsync(naccepted, d_nacc, (size_t)W * sizeof(long long), hipMemcpyDeviceToHost, st));
-        if (d_chain) {
-            SR_TRY(hipMemcpyAsync(chain, d_chain, (size_t)W * n_iter * P * sizeof(double), hipMemcpyDeviceToHost, st));
-            if (lnprob_chain)
-                SR_TRY(hipMemcpyAsync(lnprob_chain, d_lnchain, (size_t)W * n_iter * sizeof(double),
-                                      hipMemcpyDeviceToHost, st));
-        }
-    }
-    SR_TRY(hipStreamSynchronize(st));
+    if (rc == PSFMC_OK) rc = stretch_download(c, pos, lnprob, chain, lnprob_chain, naccepted, st);
+    (void)hipStreamSynchronize(st);
     if (rc == PSFMC_OK && hipGetLastError() != hipSuccess) rc = fail(PSFMC_EHIP, "kernel launch failed");
-    cleanup();
-#undef SR_TRY
+    S.open = false;
     return rc;
+}
+
+// ---------------------------------------------------------------------------
+// The same sampler, one half-step at a time, for walkers sharded over several GPUs: every
+// rank holds ALL walkers and the same random numbers, evaluates the log-posterior of ITS
+// block of each half-step's proposals, the blocks are all-gathered by the caller (RCCL /
+// torch.distributed: the one collective of the path), and every rank applies the identical
+// accept / move.  Per-walker log-posteriors do not depend on the batch they are evaluated
+// in, so the chain equals the single-GPU chain bit for bit.
+// ---------------------------------------------------------------------------
+extern "C" int psfmc_stretch_open(psfmc_ctx* c, int W, int n_iter, const double* pos, const double* lnprob,
+                                  const double* z, const double* lz, const int* partner,
+                                  const double* log_u, const long long* naccepted, int store_chain) {
+    RC_TRY(stretch_check(c, W));
+    if (n_iter < 1 || !pos || !lnprob || !naccepted || !z || !lz || !partner || !log_u)
+        return fail(PSFMC_EINVAL, "NULL buffer or n_iter < 1");
+    RC_TRY(stretch_upload(c, W, n_iter, pos, lnprob, 1, z, lz, partner, log_u, naccepted, store_chain != 0,
+                          c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PSFMC_OK;
+}
+
+static int stretch_step_check(psfmc_ctx* c, int it, int h) {
+    if (!c) return fail(PSFMC_EINVAL, "ctx is NULL");
+    if (!c->stretch.open) return fail(PSFMC_EINVAL, "psfmc_stretch_open has not been called");
+    if (it < 0 || it >= c->stretch.n_iter || (h != 0 && h != 1))
+        return fail(PSFMC_EINVAL, "iteration %d / half %d out of range", it, h);
+    return PSFMC_OK;
+}
+
+extern "C" int psfmc_stretch_half_eval(psfmc_ctx* c, int it, int h, int lo, int n, double* d_newlnp_block,
+                                       void* stream) {
+    RC_TRY(stretch_step_check(c, it, h));
+    const int half = c->stretch.W / 2;
+    if (lo < 0 || n < 0 || lo + n > half) return fail(PSFMC_EINVAL, "block [%d, %d) outside the half-ensemble of %d", lo, lo + n, half);
+    if (n > 0 && !d_newlnp_block) return fail(PSFMC_EINVAL, "NULL output");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    stretch_propose(c, it, h, false, st);
+    if (n > 0) {
+        RC_TRY(run_pipeline(c, n, c->d_skip, st, lo));
+        hipLaunchKernelGGL(k_finish_posterior, dim3(finish_blocks(n)), dim3(kFinishThreads), 0, st,
+                           c->d_partial + (size_t)lo * c->nblk, c->d_skip + lo, c->d_lnprior + lo,
+                           d_newlnp_block, n, c->nblk);
+    }
+    HIP_TRY(hipGetLastError());
+    return PSFMC_OK;
+}
+
+extern "C" int psfmc_stretch_half_accept(psfmc_ctx* c, int it, int h, const double* d_newlnp_half, void* stream) {
+    RC_TRY(stretch_step_check(c, it, h));
+    if (!d_newlnp_half) return fail(PSFMC_EINVAL, "NULL input");
+    HIP_TRY(hipSetDevice(c->device));
+    stretch_accept(c, it, h, d_newlnp_half, false, stream ? (hipStream_t)stream : c->stream);
+    HIP_TRY(hipGetLastError());
+    return PSFMC_OK;
+}
+
+extern "C" int psfmc_stretch_accumulate(psfmc_ctx* c, int lo, int n, void* stream) {
+    if (!c) return fail(PSFMC_EINVAL, "ctx is NULL");
+    psfmc_ctx::Stretch& S = c->stretch;
+    if (!S.open) return fail(PSFMC_EINVAL, "psfmc_stretch_open has not been called");
+    if (lo < 0 || n < 0 || lo + n > S.W) return fail(PSFMC_EINVAL, "block outside the ensemble");
+    if (n == 0) return PSFMC_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    RC_TRY(stretch_prepare_accumulation(c));
+    launch_theta_prep(c, n, S.pos + (size_t)lo * c->layout.n_params, nullptr, nullptr, st, StretchIn{});
+    RC_TRY(accumulate_from_prep(c, n, st));
+    HIP_TRY(hipGetLastError());
+    return PSFMC_OK;
+}
+
+extern "C" int psfmc_stretch_close(psfmc_ctx* c, double* pos, double* lnprob, double* chain,
+                                   double* lnprob_chain, long long* naccepted, void* stream) {
+    if (!c) return fail(PSFMC_EINVAL, "ctx is NULL");
+    if (!c->stretch.open) return fail(PSFMC_EINVAL, "psfmc_stretch_open has not been called");
+    if (!pos || !lnprob || !naccepted) return fail(PSFMC_EINVAL, "NULL buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    const int rc = stretch_download(c, pos, lnprob, chain, lnprob_chain, naccepted,
+                                    stream ? (hipStream_t)stream : c->stream);
+    c->stretch.open = false;
+    return rc;
+}
+
+// raw sums of the posterior images ([4][ny][nx]: raw, convolved, model variance, PS-only
+// convolved) and their sample count, for adding up the ranks' shares
+extern "C" int psfmc_get_accumulated_sums(psfmc_ctx* c, double* sums, long long* count) {
+    if (!c || !sums || !count) return fail(PSFMC_EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    *count = c->acc_count;
+    if (!c->d_acc) { memset(sums, 0, (size_t)4 * c->S * sizeof(double)); return PSFMC_OK; }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(sums, c->d_acc, (size_t)4 * c->S * sizeof(double), hipMemcpyDeviceToHost));
+    return PSFMC_OK;
+}
+
+extern "C" int psfmc_set_accumulated_sums(psfmc_ctx* c, const double* sums, long long count) {
+    if (!c || !sums || count < 0) return fail(PSFMC_EINVAL, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->d_acc) RC_TRY(psfmc_reset_accumulated(c));
+    HIP_TRY(hipMemcpy(c->d_acc, sums, (size_t)4 * c->S * sizeof(double), hipMemcpyHostToDevice));
+    c->acc_count = count;
+    return PSFMC_OK;
 }
 
 extern "C" int psfmc_get_accumulated(psfmc_ctx* c, double* raw, double* conv, double* resid, double* ivm,

@@ -394,9 +394,13 @@ __global__ void k_finish_posterior(const double* __restrict__ partial, const uin
 // other half's positions do not change during this half-step, so iteration `it` of
 // walker g is final after the half-step that owns g.  One wave per walker (launch:
 // finish_blocks(half) x kFinishThreads).
+// `newlnp_in` (multi-GPU): the proposals' log-posteriors were evaluated in blocks on several
+// ranks and gathered; they are read from it instead of being summed here -- the values are the
+// ones k_finish_posterior produced from the same partial sums, so the chain is the same bit for bit.
 // ---------------------------------------------------------------------------
 __global__ void k_stretch_finish(const double* __restrict__ partial, const uint8_t* __restrict__ skip,
                                  const double* __restrict__ lnprior, int nblk,
+                                 const double* __restrict__ newlnp_in,
                                  double* __restrict__ pos, double* __restrict__ lnprob,
                                  const double* __restrict__ q, const double* __restrict__ lz,
                                  const double* __restrict__ log_u, long long* __restrict__ nacc,
@@ -408,7 +412,7 @@ __global__ void k_stretch_finish(const double* __restrict__ partial, const uint8
     const int w = blockIdx.x * (kFinishThreads / 64) + (threadIdx.x >> 6);
     if (w >= half) return;                                   // wave-uniform
     const int it = d_iter ? *d_iter : it_val;
-    const double newlnp = walker_lnprob(partial, skip, lnprior, nblk, w, lane);
+    const double newlnp = newlnp_in ? newlnp_in[w] : walker_lnprob(partial, skip, lnprior, nblk, w, lane);
     const size_t off = ((size_t)it * 2 + h) * half;
     const int g = h * half + w;
     double lp = lnprob[g];

@@ -97,6 +97,22 @@ def load_library():
     lib.psfmc_stretch_run.argtypes = [vp, ci, ci, _c_double_p, _c_double_p, ci, _c_double_p, _c_double_p,
                                       ip, _c_double_p, _c_double_p, _c_double_p,
                                       ctypes.POINTER(ctypes.c_longlong), ci]
+    llp = ctypes.POINTER(ctypes.c_longlong)
+    lib.psfmc_stretch_open.restype = ci
+    lib.psfmc_stretch_open.argtypes = [vp, ci, ci, _c_double_p, _c_double_p, _c_double_p, _c_double_p, ip,
+                                       _c_double_p, llp, ci]
+    lib.psfmc_stretch_half_eval.restype = ci
+    lib.psfmc_stretch_half_eval.argtypes = [vp, ci, ci, ci, ci, vp, vp]
+    lib.psfmc_stretch_half_accept.restype = ci
+    lib.psfmc_stretch_half_accept.argtypes = [vp, ci, ci, vp, vp]
+    lib.psfmc_stretch_accumulate.restype = ci
+    lib.psfmc_stretch_accumulate.argtypes = [vp, ci, ci, vp]
+    lib.psfmc_stretch_close.restype = ci
+    lib.psfmc_stretch_close.argtypes = [vp, _c_double_p, _c_double_p, _c_double_p, _c_double_p, llp, vp]
+    lib.psfmc_get_accumulated_sums.restype = ci
+    lib.psfmc_get_accumulated_sums.argtypes = [vp, _c_double_p, llp]
+    lib.psfmc_set_accumulated_sums.restype = ci
+    lib.psfmc_set_accumulated_sums.argtypes = [vp, _c_double_p, ctypes.c_longlong]
     lib.psfmc_accumulate_images.restype = ci
     lib.psfmc_accumulate_images.argtypes = [vp, ci, _c_double_p]
     lib.psfmc_get_accumulated.restype = ci
@@ -325,6 +341,58 @@ class Context(object):
             _dp(chain) if chain is not None else None, _dp(lnchain) if lnchain is not None else None,
             naccepted.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), int(bool(accumulate))))
         return pos, lnp, chain, lnchain
+
+    # -- the sampler one half-step at a time (walkers sharded over ranks) -----
+    def stretch_open(self, pos, lnprob, z, lz, partner, log_u, naccepted, store=True):
+        pos = np.ascontiguousarray(pos, dtype=np.float64)
+        n_w, n_iter = pos.shape[0], int(np.shape(z)[0])
+        lnp = np.ascontiguousarray(lnprob, dtype=np.float64)
+        z, lz, log_u = (_f64(a).reshape(n_iter, 2, n_w // 2) for a in (z, lz, log_u))
+        partner = np.ascontiguousarray(partner, dtype=np.int32).reshape(n_iter, 2, n_w // 2)
+        if naccepted.dtype != np.int64 or naccepted.shape != (n_w,):
+            raise ValueError('naccepted must be int64 [W]')
+        self._check(self._lib.psfmc_stretch_open(
+            self._ctx, n_w, n_iter, _dp(pos), _dp(lnp), _dp(z), _dp(lz),
+            partner.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), _dp(log_u),
+            naccepted.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), int(bool(store))))
+        self._stretch_shape = (n_w, n_iter, pos.shape[1], bool(store))
+
+    def stretch_half_eval(self, it, h, lo, n, d_out, stream=None):
+        self._check(self._lib.psfmc_stretch_half_eval(
+            self._ctx, int(it), int(h), int(lo), int(n), ctypes.c_void_p(d_out) if d_out else None,
+            ctypes.c_void_p(stream) if stream else None))
+
+    def stretch_half_accept(self, it, h, d_newlnp, stream=None):
+        self._check(self._lib.psfmc_stretch_half_accept(
+            self._ctx, int(it), int(h), ctypes.c_void_p(d_newlnp), ctypes.c_void_p(stream) if stream else None))
+
+    def stretch_accumulate(self, lo, n, stream=None):
+        self._check(self._lib.psfmc_stretch_accumulate(self._ctx, int(lo), int(n),
+                                                       ctypes.c_void_p(stream) if stream else None))
+
+    def stretch_close(self, naccepted, stream=None):
+        n_w, n_iter, n_p, store = self._stretch_shape
+        pos, lnp = np.empty((n_w, n_p)), np.empty(n_w)
+        chain = np.empty((n_w, n_iter, n_p)) if store else None
+        lnchain = np.empty((n_w, n_iter)) if store else None
+        self._check(self._lib.psfmc_stretch_close(
+            self._ctx, _dp(pos), _dp(lnp), _dp(chain) if store else None, _dp(lnchain) if store else None,
+            naccepted.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)),
+            ctypes.c_void_p(stream) if stream else None))
+        return pos, lnp, chain, lnchain
+
+    def accumulated_sums(self):
+        """(sums [4, ny, nx], count): the raw posterior-image sums of this context."""
+        sums = np.empty((4,) + self.shape)
+        count = ctypes.c_longlong(0)
+        self._check(self._lib.psfmc_get_accumulated_sums(self._ctx, _dp(sums), ctypes.byref(count)))
+        return sums, int(count.value)
+
+    def set_accumulated_sums(self, sums, count):
+        sums = _f64(sums)
+        if sums.shape != (4,) + self.shape:
+            raise ValueError('sums must be [4, ny, nx]')
+        self._check(self._lib.psfmc_set_accumulated_sums(self._ctx, _dp(sums), int(count)))
 
     def accumulate(self, rows):
         """Add the five images of every row's walker to the device-resident

@@ -388,6 +388,19 @@ class MultiComponentModel(object):
         self._device_samples += len(rows)
         self.accumulated_samples += len(rows)
 
+    def reduce_accumulated(self, ranks):
+        """Walkers sharded over GPUs (`parallel.RankGroup`): add up the ranks' device-resident
+        posterior sums, so that every rank holds the sums over ALL walkers.  One all-reduce of
+        4 images at the end of sampling."""
+        if ranks is None or ranks.world == 1 or self._engine is None:
+            return
+        sums, count = self._engine.accumulated_sums()
+        total = ranks.all_reduce_sum_host(np.concatenate([sums.ravel(), [float(count)]]))
+        n_all = int(round(total[-1]))
+        self._engine.set_accumulated_sums(total[:-1].reshape(sums.shape), n_all)
+        self._device_samples += n_all - count
+        self.accumulated_samples += n_all - count
+
     def collect_posterior_images(self):
         """Merge the device-resident sums into `posterior_images` (sample-count
         weighted; the weight map in the variance domain) and return that dict."""

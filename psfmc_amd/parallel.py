@@ -2,9 +2,18 @@
 Walker sharding across the GPUs of one node: one process per GPU, launched by
 `python -m torch.distributed.run`, ranks evaluate contiguous walker blocks and
 exchange only the per-walker log-posteriors with ONE all-gather (RCCL over xGMI
-with the `nccl` backend; `gloo` on CPU for tests).  The shared field arrays are
-replicated per GPU at context creation, so there is no other data-path
-collective.
+with the `nccl` backend; `gloo` on CPU for tests and for rehearsals on a box with
+fewer GPUs than ranks).  The shared field arrays are replicated per GPU at context
+creation, so there is no other data-path collective.  The
+reference has no counterpart: psfMC/fitting.py:55 notes that parallel evaluation of
+the walkers had to be given up.
+
+  shard_bounds          contiguous block of a rank
+  RankGroup             this rank's view of the process group + the device-side all-gather
+  ShardedLogPosterior   [W, P] vectors -> [W] log-posteriors, every rank taking its block
+                        (host sampler / `pool.map` route)
+The device-resident sampler shards each half-step's proposals the same way
+(`sampler.DeviceEnsembleSampler(group=...)`).
 """
 import numpy as np
 
@@ -16,43 +25,124 @@ def shard_bounds(n_walkers, world_size, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+class RankGroup(object):
+    """This rank's view of a torch.distributed process group.
+
+    group   a torch.distributed group (None: the default group; no initialised process
+            group at all -> a world of one)
+    device  torch device of this rank's GPU (None: CPU tensors, for CPU-only tests)
+    With the `gloo` backend the gathered tensors are staged through the host (tests,
+    rehearsals); with `nccl` (RCCL) they stay on the device."""
+
+    def __init__(self, group=None, device=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.group = group
+        self.active = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.active else 1
+        self.rank = dist.get_rank(group) if self.active else 0
+        self.device = torch.device(device) if device is not None else torch.device('cpu')
+        backend = dist.get_backend(group) if self.active else 'none'
+        self.host_staged = self.active and (backend != 'nccl' or self.device.type == 'cpu')
+        self._index = {}
+
+    def block(self, n):
+        return shard_bounds(n, self.world, self.rank)
+
+    def slot(self, n):
+        return -(-int(n) // self.world)
+
+    def _gather_index(self, n):
+        """Positions of the n results inside the [world, slot] gathered buffer."""
+        if n not in self._index:
+            slot = self.slot(n)
+            idx = np.concatenate([r * slot + np.arange(b - a) for r in range(self.world)
+                                  for a, b in [shard_bounds(n, self.world, r)]])
+            self._index[n] = self.torch.from_numpy(idx.astype(np.int64)).to(self.device)
+        return self._index[n]
+
+    def all_gather_blocks(self, send, n):
+        """send: [slot(n)] float64 tensor on `self.device` whose first (hi - lo) entries are
+        this rank's block -> [n] tensor with every rank's block in place.  One all-gather."""
+        torch, dist = self.torch, self.dist
+        if self.world == 1:
+            return send[:n]
+        slot = self.slot(n)
+        if self.host_staged:
+            recv = torch.empty(slot * self.world, dtype=torch.float64)
+            dist.all_gather_into_tensor(recv, send.detach().cpu().contiguous(), group=self.group)
+            recv = recv.to(self.device)
+        else:
+            recv = torch.empty(slot * self.world, dtype=torch.float64, device=self.device)
+            dist.all_gather_into_tensor(recv, send, group=self.group)
+        return recv.index_select(0, self._gather_index(n))
+
+    def all_reduce_sum_host(self, array):
+        """Element-wise sum over ranks of a host float64 array (posterior-image sums: a
+        one-off exchange at the end of sampling)."""
+        if self.world == 1:
+            return array
+        torch, dist = self.torch, self.dist
+        t = torch.from_numpy(np.ascontiguousarray(array, dtype=np.float64))
+        if self.host_staged:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            return t.numpy()
+        d = t.to(self.device)
+        dist.all_reduce(d, op=dist.ReduceOp.SUM, group=self.group)
+        return d.cpu().numpy()
+
+    def broadcast_object(self, obj, src=0):
+        if self.world == 1:
+            return obj
+        box = [obj]
+        self.dist.broadcast_object_list(box, src=src, group=self.group)
+        return box[0]
+
+
 class ShardedLogPosterior(object):
     """Evaluate `[W, P]` parameter vectors with every rank taking its block.
 
-    evaluate  callable([w, P] float64 ndarray) -> [w] float64 (the rank-local
-              batched evaluator, e.g. `model.log_posterior_batch`)
-    Every rank must call with the same `theta`; every rank gets the full [W]
-    result.  With world_size 1 (or no process group) it is a plain call.
+    evaluate  callable([w, P] float64 ndarray) -> [w] float64 (a rank-local batched
+              evaluator), or a `MultiComponentModel`: then the block is evaluated with the
+              walkers resident on the model's GPU (`psfmc_eval_theta_device`) and the blocks
+              are gathered as device tensors -- no host copy between evaluation and exchange.
+    Every rank must call with the same `theta`; every rank gets the full [W] result.
+    With world_size 1 (or no process group) it is a plain call.
     """
 
     def __init__(self, evaluate, group=None, device=None):
-        self.evaluate = evaluate
-        self.group = group
-        self.device = device
+        self.model = evaluate if hasattr(evaluate, 'log_posterior_batch') else None
+        self.evaluate = self.model.log_posterior_batch if self.model is not None else evaluate
+        if self.model is not None and device is None:
+            device = 'cuda:%d' % self.model._device
+        self._group_arg, self._device_arg = group, device
+        self._rg = None
+
+    @property
+    def ranks(self):
+        if self._rg is None:
+            self._rg = RankGroup(self._group_arg, self._device_arg)
+        return self._rg
 
     def __call__(self, theta):
-        import torch
-        import torch.distributed as dist
-        theta = np.asarray(theta, dtype=np.float64)
-        if not (dist.is_available() and dist.is_initialized()):
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        rg = self.ranks
+        if rg.world == 1:
             return self.evaluate(theta)
-        world = dist.get_world_size(self.group)
-        rank = dist.get_rank(self.group)
-        if world == 1:
-            return self.evaluate(theta)
+        torch = rg.torch
         n_w = theta.shape[0]
-        lo, hi = shard_bounds(n_w, world, rank)
-        mine = self.evaluate(theta[lo:hi]) if hi > lo else np.zeros(0)
-        # equal-sized slots so a single all_gather_into_tensor does the exchange
-        slot = -(-n_w // world)
-        dev = self.device if self.device is not None else 'cpu'
-        send = torch.full((slot,), float('nan'), dtype=torch.float64, device=dev)
-        send[:hi - lo] = torch.from_numpy(np.ascontiguousarray(mine)).to(dev)
-        recv = torch.empty(slot * world, dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(recv, send, group=self.group)
-        recv = recv.cpu().numpy().reshape(world, slot)
-        out = np.empty(n_w)
-        for r in range(world):
-            a, b = shard_bounds(n_w, world, r)
-            out[a:b] = recv[r, :b - a]
-        return out
+        lo, hi = rg.block(n_w)
+        send = torch.full((rg.slot(n_w),), float('nan'), dtype=torch.float64, device=rg.device)
+        if self.model is not None and not self.model._host_priors and hi > lo:
+            eng = self.model.engine
+            stream = torch.cuda.current_stream(rg.device).cuda_stream
+            out = []
+            for a in range(lo, hi, eng.max_walkers):            # larger blocks go through in slices
+                b = min(a + eng.max_walkers, hi)
+                th = torch.from_numpy(theta[a:b]).to(rg.device)
+                eng.logpost_theta_device(b - a, th.data_ptr(), 0, send[a - lo:].data_ptr(), stream)
+                out.append(th)                                  # keep alive until the gather is enqueued
+        elif hi > lo:
+            send[:hi - lo] = torch.from_numpy(np.ascontiguousarray(self.evaluate(theta[lo:hi]))).to(rg.device)
+        return rg.all_gather_blocks(send, n_w).cpu().numpy()

@@ -275,14 +275,30 @@ class DeviceEnsembleSampler(EnsembleSampler):
     generator state that follows that iteration's draws, while `iterations`, `naccepted`
     and the stored chain advance a whole block at a time.
 
+    group: a torch.distributed process group (True = the default group) or a
+    `parallel.RankGroup`: the walkers of every half-step's proposals are then sharded over the
+    ranks (one process per GPU) -- each rank evaluates its contiguous block, the blocks'
+    log-posteriors are all-gathered (the one collective of the path) and every rank applies the
+    same accept / move, so all ranks hold the same chain, equal to the single-GPU chain bit for
+    bit.  Every rank must construct the sampler with the same `random_state` and call `sample`
+    with the same arguments.
+
     Needs a `MultiComponentModel` whose priors all belong to the families the library
     evaluates (uniform, normal, weibull_min, discrete uniform); otherwise use
     `EnsembleSampler(batch_lnpostfn=model.log_posterior_batch)`.
     """
 
-    def __init__(self, nwalkers, model, a=2.0, live_dangerously=False, block=64, accumulate=False):
+    def __init__(self, nwalkers, model, a=2.0, live_dangerously=False, block=64, accumulate=False,
+                 group=None):
+        from .parallel import RankGroup, ShardedLogPosterior
+        ranks = group if isinstance(group, RankGroup) else None
+        if ranks is None and group is not None:
+            ranks = RankGroup(None if group is True else group, 'cuda:%d' % model._device)
+        self.ranks = ranks if ranks is not None and ranks.world > 1 else None
+        evaluate = (ShardedLogPosterior(model, group=self.ranks.group) if self.ranks is not None
+                    else model.log_posterior_batch)
         super(DeviceEnsembleSampler, self).__init__(nwalkers, model.num_params, a=a,
-                                                    batch_lnpostfn=model.log_posterior_batch,
+                                                    batch_lnpostfn=evaluate,
                                                     live_dangerously=live_dangerously)
         self.model = model
         self.block = int(block)
@@ -293,6 +309,28 @@ class DeviceEnsembleSampler(EnsembleSampler):
         if model._host_priors:
             raise ValueError('priors {} are evaluated on the host: the device sampler cannot be '
                              'used'.format([p.name for p, _ in model._host_priors]))
+
+    def _run_block_sharded(self, pos, lnprob, z, lz, partner, log_u, nacc, store=True, accumulate=False):
+        """One block of iterations with every half-step's proposals sharded over the ranks
+        (include/psfmc_hip.h psfmc_stretch_open / _half_eval / _half_accept / _close)."""
+        rg, eng = self.ranks, self.model.engine
+        torch = rg.torch
+        n_iter, half = int(np.shape(z)[0]), self.k // 2
+        lo, hi = rg.block(half)
+        a_lo, a_hi = rg.block(self.k)
+        with torch.cuda.device(rg.device):
+            stream = torch.cuda.current_stream(rg.device).cuda_stream
+            send = torch.zeros(rg.slot(half), dtype=torch.float64, device=rg.device)
+            eng.stretch_open(pos, lnprob, z, lz, partner, log_u, nacc, store=store)
+            for it in range(n_iter):
+                for h in range(2):
+                    eng.stretch_half_eval(it, h, lo, hi - lo, send.data_ptr(), stream)
+                    full = rg.all_gather_blocks(send, half).contiguous()
+                    eng.stretch_half_accept(it, h, full.data_ptr(), stream)
+                if accumulate:
+                    eng.stretch_accumulate(a_lo, a_hi - a_lo, stream)
+            torch.cuda.current_stream(rg.device).synchronize()
+            return eng.stretch_close(nacc, stream)
 
     def _draw(self, n_iter):
         """Random numbers of n_iter iterations in emcee's order (per half-step:
@@ -338,17 +376,24 @@ class DeviceEnsembleSampler(EnsembleSampler):
         while done < iterations:
             n = min(self.block, iterations - done)
             n_next = min(self.block, iterations - done - n)
-            job = _run_async(self.model.engine.stretch_run, p, lnprob, *draws, nacc, store=True,
-                             accumulate=self.accumulate)
             block_states = states
-            try:
+            if self.ranks is not None:
+                # collectives are issued from this thread, in the same order on every rank
+                result = self._run_block_sharded(p, lnprob, *draws, nacc, store=True,
+                                                 accumulate=self.accumulate)
                 draws, states = self._draw(n_next) if n_next > 0 else (None, None)
-            finally:
-                result = job()
+            else:
+                job = _run_async(self.model.engine.stretch_run, p, lnprob, *draws, nacc, store=True,
+                                 accumulate=self.accumulate)
+                try:
+                    draws, states = self._draw(n_next) if n_next > 0 else (None, None)
+                finally:
+                    result = job()
             p, lnprob, chain, lnchain = result
-            if self.accumulate:
-                self.model._device_samples += n * self.k
-                self.model.accumulated_samples += n * self.k
+            if self.accumulate:                 # sharded: this rank summed its block of the walkers
+                share = n * self.k if self.ranks is None else n * (lambda b: b[1] - b[0])(self.ranks.block(self.k))
+                self.model._device_samples += share
+                self.model.accumulated_samples += share
             # per-block bookkeeping in whole-array operations: at a few hundred microseconds
             # per iteration on the GPU, per-iteration numpy calls here were 10 % of the run
             if storechain:

@@ -1,0 +1,130 @@
+"""Multi-rank GPU tests on the ONE-GPU box: two ranks (gloo rendezvous, both on device 0)
+drive the REAL engine -- the sharded log-posterior, the device-resident sampler with every
+half-step's proposals sharded over the ranks, and `model_galaxy_mcmc` end to end -- and must
+reproduce the single-rank results bit for bit (per-walker log-posteriors do not depend on
+the batch they are evaluated in).  The RCCL (`nccl`) data path differs only in where the
+gathered tensor lives (parallel.RankGroup.host_staged); the driver exercises it at N > 1."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import helpers
+import synth_field
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_WALK, N_ITER = 48, 5
+
+WORKER = r'''
+import os, sys
+import numpy as np
+import torch, torch.distributed as dist
+root, out = sys.argv[1], sys.argv[2]
+sys.path[:0] = [root, root + '/oracle', root + '/tools', root + '/tests']
+import helpers, synth_field
+from psfmc_amd.parallel import ShardedLogPosterior, RankGroup
+from psfmc_amd.sampler import DeviceEnsembleSampler
+from psfmc_amd import model_galaxy_mcmc
+dist.init_process_group('gloo')
+rank = dist.get_rank()
+torch.cuda.set_device(0)
+case = helpers.load_case('synth256')
+work = os.path.join(out, 'w%d' % rank)
+os.makedirs(work)
+model = helpers.build_model('synth256', case, work, backend='fused', max_walkers=128)
+# (a) sharded evaluation of the golden vectors (65 walkers over 2 ranks: blocks of 33 and 32)
+sharded = ShardedLogPosterior(model)
+lnp = sharded(case['params'])
+np.save(os.path.join(out, 'lnp%d.npy' % rank), lnp)
+# (b) the device-resident sampler, half-steps sharded, images accumulated per rank
+p0 = synth_field.draw_walkers(256, 1, __NWALK__, seed=77, near_truth=case['params'][-1])
+samp = DeviceEnsembleSampler(__NWALK__, model, group=True, block=3, accumulate=True)
+samp.random_state = np.random.RandomState(123).get_state()
+for res in samp.sample(p0, iterations=__NITER__):
+    pass
+np.save(os.path.join(out, 'chain%d.npy' % rank), samp.chain)
+np.save(os.path.join(out, 'lnchain%d.npy' % rank), samp.lnprobability)
+np.save(os.path.join(out, 'nacc%d.npy' % rank), samp.naccepted)
+own = model.accumulated_samples
+model.reduce_accumulated(samp.ranks)
+post = model.collect_posterior_images()
+np.savez(os.path.join(out, 'post%d.npz' % rank), count=model.accumulated_samples, own=own, **post)
+model.close()
+# (c) the entry point end to end on the reference's example field
+np.random.seed(3 + rank)                 # rank 0's start positions are broadcast
+mfile = os.path.join(root, 'tests', 'golden', 'example', 'model_example.py')
+shared = os.path.join(out, 'mcmc')
+os.makedirs(shared, exist_ok=True)
+m, db = model_galaxy_mcmc(mfile, output_name=os.path.join(shared, 'run'), iterations=6, burn=3, chains=40,
+                          random_state=5, quiet=True, write_fits=('convolved_model',))
+np.save(os.path.join(out, 'dbln%d.npy' % rank), np.asarray(db['lnprobability']))
+m.close()
+dist.destroy_process_group()
+'''
+
+
+def test_two_ranks_reproduce_one_rank(tmp_path):
+    from psfmc_amd import model_galaxy_mcmc, fits_io
+    from psfmc_amd.database import load_database
+    from psfmc_amd.sampler import DeviceEnsembleSampler
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER.replace('__NWALK__', str(N_WALK)).replace('__NITER__', str(N_ITER)))
+    out = tmp_path / 'out'
+    out.mkdir()
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, OMP_NUM_THREADS='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    subprocess.check_call(
+        [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+         '--master-addr', '127.0.0.1', '--master-port', str(port), str(script), ROOT, str(out)],
+        env=env, timeout=600)
+
+    case = helpers.load_case('synth256')
+    # (a) gathered log-posteriors: identical on both ranks, equal to the reference's
+    l0, l1 = np.load(out / 'lnp0.npy'), np.load(out / 'lnp1.npy')
+    assert np.array_equal(l0, l1)
+    assert helpers.rel_err(l0, case['lnprob']) <= 1e-6
+    single = tmp_path / 'single'
+    single.mkdir()
+    model = helpers.build_model('synth256', case, single, backend='fused', max_walkers=128)
+    assert np.array_equal(model.log_posterior_batch(case['params']), l0)      # bitwise: batch independent
+    # (b) the two-rank chain is the one-rank chain
+    p0 = synth_field.draw_walkers(256, 1, N_WALK, seed=77, near_truth=case['params'][-1])
+    samp = DeviceEnsembleSampler(N_WALK, model, block=3, accumulate=True)
+    samp.random_state = np.random.RandomState(123).get_state()
+    for _ in samp.sample(p0, iterations=N_ITER):
+        pass
+    for r in (0, 1):
+        assert np.array_equal(np.load(out / ('chain%d.npy' % r)), samp.chain), r
+        assert np.array_equal(np.load(out / ('lnchain%d.npy' % r)), samp.lnprobability), r
+        assert np.array_equal(np.load(out / ('nacc%d.npy' % r)), samp.naccepted), r
+    assert samp.naccepted.sum() > 0
+    post = model.collect_posterior_images()
+    for r in (0, 1):
+        got = np.load(out / ('post%d.npz' % r))
+        assert int(got['count']) == N_WALK * N_ITER == model.accumulated_samples
+        assert int(got['own']) == N_WALK * N_ITER // 2          # each rank summed its half of the walkers
+        for kind, img in post.items():
+            scale = np.abs(img[np.isfinite(img)]).max()
+            assert np.abs(got[kind] - img).max() <= 1e-12 * scale, (r, kind)
+    model.close()
+    # (c) the entry point: same database from two ranks and from one process
+    np.random.seed(3)
+    mfile = os.path.join(ROOT, 'tests', 'golden', 'example', 'model_example.py')
+    m, db = model_galaxy_mcmc(mfile, output_name=str(single / 'run'), iterations=6, burn=3, chains=40,
+                              random_state=5, quiet=True, write_fits=('convolved_model',), group=None)
+    m.close()
+    ref = np.asarray(db['lnprobability'])
+    assert np.array_equal(np.load(out / 'dbln0.npy'), ref) and np.array_equal(np.load(out / 'dbln1.npy'), ref)
+    two = load_database(str(out / 'mcmc' / 'run_db.fits'))
+    for name in db.colnames:
+        assert np.array_equal(two[name], db[name]), name
+    a = fits_io.read_image(str(out / 'mcmc' / 'run_convolved_model.fits'))
+    b = fits_io.read_image(str(single / 'run_convolved_model.fits'))
+    assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max()

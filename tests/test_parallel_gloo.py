@@ -17,7 +17,8 @@ import numpy as np
 import torch.distributed as dist
 sys.path[:0] = [%(root)r, %(root)r + '/oracle', %(root)r + '/tools', %(root)r + '/tests']
 import helpers
-from psfmc_amd.parallel import ShardedLogPosterior
+import torch
+from psfmc_amd.parallel import ShardedLogPosterior, RankGroup
 dist.init_process_group('gloo')
 case = helpers.load_case('synth128x2')
 field = helpers.oracle_field(case)
@@ -30,6 +31,17 @@ theta = case['params'][:7]
 out = ShardedLogPosterior(evaluate)(theta)
 np.save(os.path.join(%(out)r, 'rank%%d.npy' %% dist.get_rank()), out)
 np.save(os.path.join(%(out)r, 'calls%%d.npy' %% dist.get_rank()), np.array(calls))
+# the rank-group primitives the sharded sampler uses: uneven blocks, sum, broadcast
+rg = RankGroup()
+n = 11
+lo, hi = rg.block(n)
+send = torch.zeros(rg.slot(n), dtype=torch.float64)
+send[:hi - lo] = torch.arange(lo, hi, dtype=torch.float64) * 1.5
+full = rg.all_gather_blocks(send, n).numpy()
+tot = rg.all_reduce_sum_host(np.full(5, rg.rank + 1.0))
+obj = rg.broadcast_object({'rank': rg.rank, 'state': np.arange(3) + rg.rank})
+np.savez(os.path.join(%(out)r, 'prim%%d.npz' %% rg.rank), full=full, tot=tot, obj_rank=obj['rank'],
+         obj_state=obj['state'], world=rg.world, staged=rg.host_staged)
 dist.destroy_process_group()
 '''
 
@@ -63,3 +75,9 @@ def test_two_rank_all_gather(tmp_path):
     assert helpers.rel_err(r0, case['loglike_f64'][:7]) <= 1e-12
     assert np.load(tmp_path / 'calls0.npy').tolist() == [4]
     assert np.load(tmp_path / 'calls1.npy').tolist() == [3]
+    for r in (0, 1):
+        prim = np.load(tmp_path / ('prim%d.npz' % r))
+        assert int(prim['world']) == 2 and bool(prim['staged'])
+        assert np.array_equal(prim['full'], np.arange(11) * 1.5)
+        assert np.array_equal(prim['tot'], np.full(5, 3.0))
+        assert int(prim['obj_rank']) == 0 and np.array_equal(prim['obj_state'], np.arange(3))
