@@ -214,6 +214,32 @@ int psfmc_get_accumulated_sums(psfmc_ctx* ctx, double* sums, long long* count);
 int psfmc_set_accumulated_sums(psfmc_ctx* ctx, const double* sums, long long count);
 
 /*
+ * One process driving several GPUs (the form SURVEY.md section 8(b) sketched; the
+ * one-process-per-GPU form with torch.distributed / RCCL is psfmc_amd/parallel.py).  The
+ * field is replicated on every listed device (a device may be listed more than once),
+ * walkers are split into contiguous blocks (block r = walkers [r W/n ...)), every device's
+ * upload, evaluation and download are enqueued before any is waited for, and each block
+ * lands at its offset of the caller's host array.  max_walkers bounds W of the whole
+ * group.  Results equal the single-context ones bit for bit.  No reference counterpart
+ * (psfMC/fitting.py:55).
+ */
+typedef struct psfmc_group psfmc_group;
+int psfmc_group_create(psfmc_group** out, int n_dev, const int* devices, int ny, int nx,
+                       const double* sci, const double* obs_var, const uint8_t* bad_px,
+                       int n_psf, int psf_ny, int psf_nx, const double* psf, const double* psf_var,
+                       int n_ps, int n_sersic, int max_walkers, int backend);
+int psfmc_group_destroy(psfmc_group* group);
+int psfmc_group_size(const psfmc_group* group);
+int psfmc_group_set_layout(psfmc_group* group, int n_sky, int n_params, const int* slot_col,
+                           const double* slot_const, const int* ps_method, const int* sersic_degrees,
+                           double mag_zeropoint, const int* family, const double* p0, const double* p1,
+                           const double* p2);
+int psfmc_group_eval_batch(psfmc_group* group, int W, const double* rows, const uint8_t* skip,
+                           double* loglike);
+int psfmc_group_eval_theta(psfmc_group* group, int W, const double* theta, const double* extra_lnprior,
+                           double* lnprob);
+
+/*
  * Posterior-image accumulation on the device (replaces the per-sample blob
  * hand-over and the running mean of MultiComponentModel.accumulate_images,
  * models.py:74-97, fed from fitting.py:83).  psfmc_accumulate_images adds the images

@@ -1,10 +1,13 @@
 // psfmc_fft.h -- register/LDS complex FFT engine for gfx950 (fp64).
 //
-// One length-N transform (N = P*T, power of two) is computed by T adjacent lanes
-// of a wave, each holding P points in registers:
-//     v[a] = x[T*a + t]          on entry  (t = lane within the group, a < P)
-//     v[e] = X[t + T*e]          on exit   (natural order, same striding)
-// so that global loads/stores of consecutive lanes touch consecutive addresses.
+// One length-N transform (N = P*T; N a product of 2s, 3s and 5s) is computed by T adjacent
+// lanes of a wave (T <= 32, a wave holds 64/T transforms; with T not a power of two the last
+// 64 - T*(64/T) lanes idle), each holding P points in registers:
+//     v[a] = x[T*a + t]              on entry  (t = lane within the group, a < P)
+//     v[e] = X[fft_k_of(t, e)]       on exit:  e = h + H*d, H = ceil(P/T),
+//                                    k = (t + T*h) + P*d, valid iff t + T*h < P
+// When T divides P (every power-of-two shape) that is k = t + T*e: natural order with the same
+// striding.  Either way consecutive lanes touch consecutive addresses in global loads/stores.
 // Decimation in frequency, two stages with ONE exchange through LDS:
 //   stage 1  radix-P DFT over a in registers, then the twiddle W_N^(t*c)
 //   exchange y[t][c] -> LDS rows of P+1 complex (the +1 keeps ds_write_b128 of
@@ -12,12 +15,15 @@
 //            wave-local, so there is no workgroup barrier anywhere in a transform
 //   stage 2  P/T radix-T DFTs over the T lanes' values, in registers
 //   X[c + P*d] = sum_b W_N^(b c) W_T^(b d) sum_a x[T a + b] W_P^(a c)
-// The in-register DFTs are fully unrolled radix-2 recursions with compile-time
-// twiddles (trivial factors 1, -i, (1-i)/sqrt2 special-cased).  Direction is a
+// The in-register DFTs are fully unrolled decimation-in-time recursions with compile-time
+// twiddles: radix 5 and 3 butterflies for those factors, radix 2 for the rest (a butterfly with a
+// non-trivial twiddle is 6 FMAs; twiddles 1 and -+i cost only the additions).  Direction is a
 // template parameter: SIGN = -1 forward (numpy's convention), +1 inverse
 // (unnormalised).  A 64-lane wave holds 64/T transforms side by side.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include "psfmc_trig_table.h"
 
 namespace psfmc {
 
@@ -49,11 +55,61 @@ __device__ __forceinline__ cd load_stream(const cd* p) {
 }
 
 template <int N> struct FftShape;
-template <> struct FftShape<64>   { static constexpr int P = 8,  T = 8;  };
-template <> struct FftShape<128>  { static constexpr int P = 16, T = 8;  };
-template <> struct FftShape<256>  { static constexpr int P = 16, T = 16; };
-template <> struct FftShape<512>  { static constexpr int P = 32, T = 16; };
-template <> struct FftShape<1024> { static constexpr int P = 32, T = 32; };
+#define PSFMC_FFT_SHAPE(N_, P_, T_)                                                                 \
+    template <> struct FftShape<N_> {                                                               \
+        static constexpr int P = P_, T = T_;                                                        \
+        static_assert(P_ * T_ == N_ && T_ <= 32 && P_ <= 32, "shape");                              \
+        static constexpr int H = (P_ + T_ - 1) / T_;        /* stage-2 transforms per lane */       \
+        static constexpr int R = H * T_;                    /* registers (complex) per lane, >= P */ \
+        static constexpr int TPW = 64 / T_;                 /* transforms per wave */               \
+        static constexpr bool kExact = (P_ % T_ == 0);      /* k = t + T e on exit */               \
+        static constexpr bool kFull = (TPW * T_ == 64);     /* every lane of a wave works */        \
+        static constexpr bool kPlain = kExact && kFull;     /* the power-of-two shapes */           \
+    };
+PSFMC_FFT_SHAPE(64, 8, 8)
+PSFMC_FFT_SHAPE(128, 16, 8)
+PSFMC_FFT_SHAPE(256, 16, 16)
+PSFMC_FFT_SHAPE(512, 32, 16)
+PSFMC_FFT_SHAPE(1024, 32, 32)
+// sides with factors 3 and 5 (any even side of this list runs on the fused kernels)
+PSFMC_FFT_SHAPE(96, 12, 8)
+PSFMC_FFT_SHAPE(100, 10, 10)
+PSFMC_FFT_SHAPE(120, 15, 8)
+PSFMC_FFT_SHAPE(144, 12, 12)
+PSFMC_FFT_SHAPE(150, 15, 10)
+PSFMC_FFT_SHAPE(160, 20, 8)
+PSFMC_FFT_SHAPE(180, 12, 15)
+PSFMC_FFT_SHAPE(192, 24, 8)
+PSFMC_FFT_SHAPE(200, 20, 10)
+PSFMC_FFT_SHAPE(240, 15, 16)
+PSFMC_FFT_SHAPE(250, 25, 10)
+PSFMC_FFT_SHAPE(288, 24, 12)
+PSFMC_FFT_SHAPE(300, 30, 10)
+PSFMC_FFT_SHAPE(320, 16, 20)
+PSFMC_FFT_SHAPE(360, 24, 15)
+PSFMC_FFT_SHAPE(384, 24, 16)
+PSFMC_FFT_SHAPE(400, 20, 20)
+PSFMC_FFT_SHAPE(480, 30, 16)
+PSFMC_FFT_SHAPE(500, 20, 25)
+PSFMC_FFT_SHAPE(576, 24, 24)
+PSFMC_FFT_SHAPE(600, 30, 20)
+PSFMC_FFT_SHAPE(640, 20, 32)
+PSFMC_FFT_SHAPE(720, 24, 30)
+PSFMC_FFT_SHAPE(768, 24, 32)
+PSFMC_FFT_SHAPE(800, 25, 32)
+PSFMC_FFT_SHAPE(900, 30, 30)
+PSFMC_FFT_SHAPE(960, 30, 32)
+#undef PSFMC_FFT_SHAPE
+
+// the output index lane t holds in register e, and whether that register holds one at all
+template <int N> __device__ __forceinline__ constexpr int fft_k_of(int t, int e) {
+    using S = FftShape<N>;
+    return (t + S::T * (e % S::H)) + S::P * (e / S::H);
+}
+template <int N> __device__ __forceinline__ constexpr bool fft_slot_valid(int t, int e) {
+    using S = FftShape<N>;
+    return S::kExact || t + S::T * (e % S::H) < S::P;
+}
 
 // LDS doubles one transform needs for its exchange (one component at a time)
 template <int N> constexpr int fft_lds_elems() { return FftShape<N>::T * (FftShape<N>::P + 1); }
@@ -70,13 +126,20 @@ __device__ constexpr double kCos32[9] = {
     0.19509032201612826784828486847702224092769161775195480775450,
     0.0};
 
-// real / imaginary part of exp(SIGN * 2 pi i * k / R), compile time, R | 32
+// real / imaginary part of exp(2 pi i * K / R), compile time: R | 32 from the 32nd-turn
+// constants above, any other R <= 48 from the generated table
 template <int R, int K> __device__ constexpr double tw_cos() {
-    constexpr int k = ((K % R) + R) % R * (32 / R);          // in 32nds of a turn
-    return k <= 8 ? kCos32[k] : k <= 16 ? -kCos32[16 - k] : k <= 24 ? -kCos32[k - 16] : kCos32[32 - k];
+    if constexpr (32 % R == 0) {
+        constexpr int k = ((K % R) + R) % R * (32 / R);          // in 32nds of a turn
+        return k <= 8 ? kCos32[k] : k <= 16 ? -kCos32[16 - k] : k <= 24 ? -kCos32[k - 16] : kCos32[32 - k];
+    } else {
+        static_assert(R <= kTrigMaxDen, "twiddle denominator outside the generated table");
+        return kCosTab[R][((K % R) + R) % R];
+    }
 }
 template <int R, int K> __device__ constexpr double tw_sin() {   // sin(2 pi K / R)
-    return tw_cos<R, K - R / 4>();
+    if constexpr (32 % R == 0) return tw_cos<R, K - R / 4>();
+    else return kSinTab[R][((K % R) + R) % R];
 }
 
 // t = v * exp(SIGN 2 pi i K / R)
@@ -97,8 +160,94 @@ template <int R, int K, int SIGN> __device__ __forceinline__ cd tw_mul(cd v) {
     }
 }
 
+// the radix a length-R codelet splits off first: 5, then 3, then 2
+template <int R> constexpr int dft_radix() { return R % 5 == 0 ? 5 : R % 3 == 0 ? 3 : 2; }
+
 // in-register DFT of R points, natural order in and out
-template <int R, int SIGN> struct Dft {
+template <int R, int SIGN, int RADIX = dft_radix<R>()> struct Dft;
+
+// radix 3 / 5: decimation in time -- RADIX interleaved sub-transforms of length R / RADIX, then
+// for each k the twiddled values go through one RADIX-point butterfly:
+//   X[k + M q] = sum_j W_RADIX^(j q) (W_R^(j k) sub_j[k]),  M = R / RADIX
+template <int R, int SIGN> struct Dft<R, SIGN, 3> {
+    static constexpr int M = R / 3;
+    static __device__ __forceinline__ void run(cd (&v)[R]) {
+        cd s0[M], s1[M], s2[M];
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            s0[i] = v[3 * i];
+            s1[i] = v[3 * i + 1];
+            s2[i] = v[3 * i + 2];
+        }
+        Dft<M, SIGN>::run(s0);
+        Dft<M, SIGN>::run(s1);
+        Dft<M, SIGN>::run(s2);
+        combine<0>(v, s0, s1, s2);
+    }
+    template <int K>
+    static __device__ __forceinline__ void combine(cd (&v)[R], const cd (&s0)[M], const cd (&s1)[M],
+                                                   const cd (&s2)[M]) {
+        if constexpr (K < M) {
+            constexpr double kS3 = SIGN * 0.86602540378443864676372317075293618347;   // sin(2 pi / 3)
+            const cd a0 = s0[K], a1 = tw_mul<R, K, SIGN>(s1[K]), a2 = tw_mul<R, 2 * K, SIGN>(s2[K]);
+            const cd s = cadd(a1, a2), d = csub(a1, a2);
+            const cd m = cd{__builtin_fma(-0.5, s.x, a0.x), __builtin_fma(-0.5, s.y, a0.y)};
+            v[K] = cadd(a0, s);
+            v[K + M] = cd{__builtin_fma(-kS3, d.y, m.x), __builtin_fma(kS3, d.x, m.y)};        // m + i kS3 d
+            v[K + 2 * M] = cd{__builtin_fma(kS3, d.y, m.x), __builtin_fma(-kS3, d.x, m.y)};    // m - i kS3 d
+            combine<K + 1>(v, s0, s1, s2);
+        }
+    }
+};
+
+template <int R, int SIGN> struct Dft<R, SIGN, 5> {
+    static constexpr int M = R / 5;
+    static __device__ __forceinline__ void run(cd (&v)[R]) {
+        cd s0[M], s1[M], s2[M], s3[M], s4[M];
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            s0[i] = v[5 * i];
+            s1[i] = v[5 * i + 1];
+            s2[i] = v[5 * i + 2];
+            s3[i] = v[5 * i + 3];
+            s4[i] = v[5 * i + 4];
+        }
+        Dft<M, SIGN>::run(s0);
+        Dft<M, SIGN>::run(s1);
+        Dft<M, SIGN>::run(s2);
+        Dft<M, SIGN>::run(s3);
+        Dft<M, SIGN>::run(s4);
+        combine<0>(v, s0, s1, s2, s3, s4);
+    }
+    template <int K>
+    static __device__ __forceinline__ void combine(cd (&v)[R], const cd (&s0)[M], const cd (&s1)[M],
+                                                   const cd (&s2)[M], const cd (&s3)[M], const cd (&s4)[M]) {
+        if constexpr (K < M) {
+            constexpr double c1 = 0.30901699437494742410229341718281905886;    // cos(2 pi / 5)
+            constexpr double c2 = -0.80901699437494742410229341718281905886;   // cos(4 pi / 5)
+            constexpr double q1 = SIGN * 0.95105651629515357211643933337938214340;   // sin(2 pi / 5)
+            constexpr double q2 = SIGN * 0.58778525229247312916870595463907276860;   // sin(4 pi / 5)
+            const cd a0 = s0[K], a1 = tw_mul<R, K, SIGN>(s1[K]), a2 = tw_mul<R, 2 * K, SIGN>(s2[K]),
+                     a3 = tw_mul<R, 3 * K, SIGN>(s3[K]), a4 = tw_mul<R, 4 * K, SIGN>(s4[K]);
+            const cd p1 = cadd(a1, a4), p2 = cadd(a2, a3), d1 = csub(a1, a4), d2 = csub(a2, a3);
+            v[K] = cadd(a0, cadd(p1, p2));
+            const cd m1 = cd{__builtin_fma(c2, p2.x, __builtin_fma(c1, p1.x, a0.x)),
+                             __builtin_fma(c2, p2.y, __builtin_fma(c1, p1.y, a0.y))};
+            const cd m2 = cd{__builtin_fma(c1, p2.x, __builtin_fma(c2, p1.x, a0.x)),
+                             __builtin_fma(c1, p2.y, __builtin_fma(c2, p1.y, a0.y))};
+            const cd n1 = cd{__builtin_fma(q2, d2.x, q1 * d1.x), __builtin_fma(q2, d2.y, q1 * d1.y)};
+            const cd n2 = cd{__builtin_fma(-q1, d2.x, q2 * d1.x), __builtin_fma(-q1, d2.y, q2 * d1.y)};
+            v[K + M] = cd{m1.x - n1.y, m1.y + n1.x};              // m1 + i n1
+            v[K + 4 * M] = cd{m1.x + n1.y, m1.y - n1.x};
+            v[K + 2 * M] = cd{m2.x - n2.y, m2.y + n2.x};          // m2 + i n2
+            v[K + 3 * M] = cd{m2.x + n2.y, m2.y - n2.x};
+            combine<K + 1>(v, s0, s1, s2, s3, s4);
+        }
+    }
+};
+
+// radix 2 (what is left once the 5s and 3s are split off: the power-of-two codelets)
+template <int R, int SIGN> struct Dft<R, SIGN, 2> {
     static __device__ __forceinline__ void run(cd (&v)[R]) {
         cd ev[R / 2], od[R / 2];
 #pragma unroll
@@ -134,10 +283,10 @@ template <int R, int SIGN> struct Dft {
         }
     }
 };
-template <int SIGN> struct Dft<1, SIGN> {
+template <int SIGN> struct Dft<1, SIGN, 2> {
     static __device__ __forceinline__ void run(cd (&)[1]) {}
 };
-template <int SIGN> struct Dft<2, SIGN> {
+template <int SIGN> struct Dft<2, SIGN, 2> {
     static __device__ __forceinline__ void run(cd (&v)[2]) {
         const cd a = v[0], b = v[1];
         v[0] = cadd(a, b);
@@ -201,16 +350,28 @@ __device__ __forceinline__ void load_twiddles(cd* w /* [TwRegs<N, TWM>::value] *
 
 // The cooperative transform.  `xbuf` = this transform's private LDS region of
 // fft_lds_elems<N>() DOUBLES; the T lanes of a transform sit in one wave (T <= 32),
-// `t` in [0,T).  `w` from load_twiddles (forward table).  Converged call only.
+// `t` in [0,T).  `w` from load_twiddles (forward table).  Converged call only: every lane of
+// the wave calls; `active` = false for the idle tail lanes of a wave whose T does not divide
+// 64 (they compute on whatever they hold and must not write LDS).
 // The exchange goes through LDS one component at a time (real parts, then
 // imaginary parts): half the LDS footprint per wave, which is what bounds how many
 // waves a CU can hold, for the same number of LDS bytes moved.
 template <int N, int SIGN, int TWM = PSFMC_TW_MODE>
-__device__ __forceinline__ void fft_wave(cd (&v)[FftShape<N>::P], const cd* w /* [TwRegs<N, TWM>::value] */,
+__device__ __forceinline__ void fft_wave(cd (&v)[FftShape<N>::R], const cd* w /* [TwRegs<N, TWM>::value] */,
                                          const cd* __restrict__ table, int t, double* __restrict__ xbuf,
-                                         const cd* __restrict__ twl) {
-    constexpr int P = FftShape<N>::P, T = FftShape<N>::T;
-    Dft<P, SIGN>::run(v);
+                                         const cd* __restrict__ twl, bool active = true) {
+    using S = FftShape<N>;
+    constexpr int P = S::P, T = S::T, H = S::H;
+    if constexpr (S::R == P) {
+        Dft<P, SIGN>::run(v);
+    } else {                                        // the first P registers hold the input
+        cd a[P];
+#pragma unroll
+        for (int c = 0; c < P; ++c) a[c] = v[c];
+        Dft<P, SIGN>::run(a);
+#pragma unroll
+        for (int c = 0; c < P; ++c) v[c] = a[c];
+    }
 #pragma unroll
     for (int c = 1; c < P; ++c) {
         cd wc;
@@ -220,29 +381,66 @@ __device__ __forceinline__ void fft_wave(cd (&v)[FftShape<N>::P], const cd* w /*
         v[c] = cmul(v[c], SIGN < 0 ? wc : cconj(wc));
     }
     double* row = xbuf + t * (P + 1);
-    cd z[P / T][T];
+    // lane t's stage-2 transforms work on c = t + T h; a c >= P (only when T does not divide P)
+    // reads a valid column instead and its results are never used
+    int col[H];
 #pragma unroll
-    for (int c = 0; c < P; ++c) row[c] = v[c].x;
+    for (int h = 0; h < H; ++h) col[h] = (S::kExact || t + T * h < P) ? t + T * h : 0;
+    cd z[H][T];
+    if (S::kFull || active) {
+#pragma unroll
+        for (int c = 0; c < P; ++c) row[c] = v[c].x;
+    }
     wave_lds_sync();
 #pragma unroll
-    for (int h = 0; h < P / T; ++h)
+    for (int h = 0; h < H; ++h)
 #pragma unroll
-        for (int b = 0; b < T; ++b) z[h][b].x = xbuf[b * (P + 1) + t + T * h];
+        for (int b = 0; b < T; ++b) z[h][b].x = xbuf[b * (P + 1) + col[h]];
+    wave_lds_sync();
+    if (S::kFull || active) {
+#pragma unroll
+        for (int c = 0; c < P; ++c) row[c] = v[c].y;
+    }
     wave_lds_sync();
 #pragma unroll
-    for (int c = 0; c < P; ++c) row[c] = v[c].y;
+    for (int h = 0; h < H; ++h)
+#pragma unroll
+        for (int b = 0; b < T; ++b) z[h][b].y = xbuf[b * (P + 1) + col[h]];
     wave_lds_sync();
 #pragma unroll
-    for (int h = 0; h < P / T; ++h)
-#pragma unroll
-        for (int b = 0; b < T; ++b) z[h][b].y = xbuf[b * (P + 1) + t + T * h];
-    wave_lds_sync();
-#pragma unroll
-    for (int h = 0; h < P / T; ++h) {
+    for (int h = 0; h < H; ++h) {
         Dft<T, SIGN>::run(z[h]);
 #pragma unroll
-        for (int d = 0; d < T; ++d) v[h + (P / T) * d] = z[h][d];
+        for (int d = 0; d < T; ++d) v[h + H * d] = z[h][d];
     }
+}
+
+// Output order -> input order for a shape whose T does not divide P: register e of lane t
+// holds X[fft_k_of(t, e)]; afterwards register a holds X[T a + t] (what a following transform
+// of the same data expects).  Through the transform's LDS region, one component at a time
+// (T (P+1) doubles >= N).  Converged call; idle tail lanes pass active = false.
+template <int N>
+__device__ __forceinline__ void fft_regroup(cd (&v)[FftShape<N>::R], int t, double* __restrict__ xbuf,
+                                            bool active) {
+    using S = FftShape<N>;
+    constexpr int P = S::P, T = S::T, R = S::R;
+    double re[P];
+#pragma unroll
+    for (int e = 0; e < R; ++e)
+        if ((S::kFull || active) && fft_slot_valid<N>(t, e)) xbuf[fft_k_of<N>(t, e)] = v[e].x;
+    wave_lds_sync();
+#pragma unroll
+    for (int a = 0; a < P; ++a) re[a] = xbuf[T * a + t];
+    wave_lds_sync();
+#pragma unroll
+    for (int e = 0; e < R; ++e)
+        if ((S::kFull || active) && fft_slot_valid<N>(t, e)) xbuf[fft_k_of<N>(t, e)] = v[e].y;
+    wave_lds_sync();
+#pragma unroll
+    for (int a = 0; a < P; ++a) v[a] = cd{re[a], xbuf[T * a + t]};
+#pragma unroll
+    for (int a = P; a < R; ++a) v[a] = cd{0.0, 0.0};
+    wave_lds_sync();
 }
 
 // ---------------------------------------------------------------------------

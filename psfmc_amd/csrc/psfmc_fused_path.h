@@ -45,7 +45,13 @@ constexpr int kColThreads = 256;     // column kernel: 4 waves, persistent
 #define PSFMC_COLS_PREFETCH 1         /* register double-buffering of the column loads */
 #endif
 
-template <int NX> constexpr int row_group() { return 64 / FftShape<NX>::T; }      // rows per wave
+template <int NX> constexpr int row_group() { return FftShape<NX>::TPW; }         // rows per wave
+// rows that share a contiguous run of T per kx (the "RG" of the layout comment above): the rows
+// of one wave for the power-of-two shapes, 4 otherwise (ny is rounded up to a multiple of it in
+// the layout; the spare rows are never read)
+template <int NX> constexpr int layout_rg_log2() {
+    return FftShape<NX>::kPlain ? __builtin_ctz(FftShape<NX>::TPW) : 2;
+}
 template <int NX> constexpr int row_waves() {
     return PSFMC_ROW_WAVES ? PSFMC_ROW_WAVES : (row_group<NX>() >= 4 ? 1 : 4);
 }
@@ -57,15 +63,15 @@ template <int NX> constexpr size_t fused_row_wave_lds_doubles() {
 template <int NX> constexpr size_t fused_row_lds_bytes() {
     return (size_t)row_waves<NX>() * fused_row_wave_lds_doubles<NX>() * sizeof(double);
 }
-template <int NY> constexpr int col_ffts_per_block() { return kColThreads / FftShape<NY>::T; }
+template <int NY> constexpr int col_ffts_per_block() { return (kColThreads / 64) * FftShape<NY>::TPW; }
 template <int NY> constexpr size_t fused_col_wave_lds_doubles() {
-    return (size_t)(64 / FftShape<NY>::T) * fft_lds_elems<NY>() + 2 * (size_t)fft_tw_lds_elems<NY, PSFMC_TW_MODE_COLS>();
+    return (size_t)FftShape<NY>::TPW * fft_lds_elems<NY>() + 2 * (size_t)fft_tw_lds_elems<NY, PSFMC_TW_MODE_COLS>();
 }
 template <int NY> constexpr size_t fused_col_lds_bytes() {
     return (size_t)(kColThreads / 64) * fused_col_wave_lds_doubles<NY>() * sizeof(double);
 }
 // waves per SIMD the register allocator must leave room for
-template <int N> constexpr int fused_min_waves() { return FftShape<N>::P > 16 ? 1 : 2; }
+template <int N> constexpr int fused_min_waves() { return FftShape<N>::R > 16 ? 1 : 2; }
 
 // Address = wave-uniform base (scalar registers) + 32-bit byte offset per lane: the form
 // global_load/store take directly (saddr + voffset).  64-bit per-lane pointer arithmetic was
@@ -88,6 +94,10 @@ __device__ __forceinline__ int t_elem(int y, int c, int rg_log2) {
     const int rg = 1 << rg_log2;
     return (((y >> rg_log2) * 2 + c) << rg_log2) + (y & (rg - 1));
 }
+// column length of the layout: ny rounded up to a whole number of row groups
+__host__ __device__ __forceinline__ int t_col_len(int ny, int rg_log2) {
+    return ((ny + (1 << rg_log2) - 1) >> rg_log2) << rg_log2;
+}
 
 // packed, pre-permuted field arrays for rows_inv: pix[(yg*P + e)*64 + lane] =
 // {sci or NaN at excluded pixels, obs_var} of pixel (y = yg*RG + lane/T, x = lane%T + T*e)
@@ -95,16 +105,27 @@ struct FieldPx {
     double sci, var;
 };
 
+template <int NX> constexpr size_t fused_field_len(int ny) {
+    return (size_t)((ny + FftShape<NX>::TPW - 1) / FftShape<NX>::TPW) * FftShape<NX>::R * 64;
+}
+
+// out[(yg*R + e)*64 + lane] = pixel (y = yg*RG + lane/T, x = fft_k_of(lane%T, e)); slots that
+// hold no pixel (idle tail lanes, registers past P of an inexact shape, rows past ny) are
+// marked excluded (NaN sci) with unit variance, so the chi^2 loop needs no other guard
 template <int NX>
 __global__ void k_pack_field(const double* __restrict__ sci, const double* __restrict__ obs_var,
                              const uint8_t* __restrict__ bad, FieldPx* __restrict__ out, int ny) {
-    constexpr int P = FftShape<NX>::P, T = FftShape<NX>::T, RG = row_group<NX>();
-    const int n = ny * NX;
+    using S = FftShape<NX>;
+    constexpr int T = S::T, R = S::R, RG = S::TPW;
+    const int n = (int)fused_field_len<NX>(ny);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int lane = i & 63, e = (i >> 6) % P, yg = i / (64 * P);
-        const int y = yg * RG + lane / T, x = lane % T + T * e;
-        const size_t src = (size_t)y * NX + x;
-        out[i] = FieldPx{bad[src] ? __builtin_nan("") : sci[src], obs_var[src]};
+        const int lane = i & 63, e = (i >> 6) % R, yg = i / (64 * R);
+        const int f = lane / T, t = lane % T;
+        const int y = yg * RG + f, x = fft_k_of<NX>(t, e);
+        const bool holds = f < RG && y < ny && fft_slot_valid<NX>(t, e);
+        const size_t src = holds ? (size_t)y * NX + x : 0;
+        out[i] = holds ? FieldPx{bad[src] ? __builtin_nan("") : sci[src], obs_var[src]}
+                       : FieldPx{__builtin_nan(""), 1.0};
     }
 }
 
@@ -120,24 +141,34 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
            const cd* __restrict__ twx, cd* __restrict__ Tbuf, int n_ps, int n_sersic, int ny,
            int ps_only, const double* __restrict__ img, const double* __restrict__ img_scale,
            double* __restrict__ raw_out) {
-    constexpr int P = FftShape<NX>::P, T = FftShape<NX>::T, RG = row_group<NX>();
+    using S = FftShape<NX>;
+    constexpr int P = S::P, T = S::T, R = S::R, RG = row_group<NX>();
     constexpr int NXH = NX / 2 + 1;
+    constexpr int RGL2 = layout_rg_log2<NX>(), RGL = 1 << RGL2;       // rows per layout group
     extern __shared__ __align__(16) double smem[];
     const int w = blockIdx.y;
     if (skip && skip[w]) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int f = lane / T, t = lane % T;
     const int yg = blockIdx.x * row_waves<NX>() + wave;
+    if constexpr (!S::kPlain)
+        if (yg * RG >= ny) return;                                    // wave-uniform: past the last row group
+    const bool lane_on = S::kFull || f < RG;                          // not one of the idle tail lanes
+    const int fe = S::kFull ? f : (f < RG ? f : RG - 1);              // LDS region (idle lanes alias the last)
     const int iy = yg * RG + f;
-    const size_t S = (size_t)ny * NX;
+    const bool row_on = S::kPlain || (lane_on && iy < ny);            // this lane's row exists
+    const int nyp = t_col_len(ny, RGL2);
+    const size_t Spx = (size_t)ny * NX;
 
-    cd v[P];
+    cd v[R];
+#pragma unroll
+    for (int k = P; k < R; ++k) v[k] = cd{0.0, 0.0};
     if constexpr (FROM_IMAGE) {
-        const double* a = img + (size_t)(2 * w) * S + (size_t)iy * NX;
-        const double* b = a + S;
+        const double* a = img + (size_t)(2 * w) * Spx + (size_t)(row_on ? iy : 0) * NX;
+        const double* b = a + Spx;
         const double sc = img_scale[w];
 #pragma unroll
-        for (int k = 0; k < P; ++k) v[k] = cd{a[T * k + t], b[T * k + t] * sc};
+        for (int k = 0; k < P; ++k) v[k] = row_on ? cd{a[T * k + t], b[T * k + t] * sc} : cd{0.0, 0.0};
     } else {
         const double* wprep = prep + (size_t)w * prep_len(n_ps, n_sersic);   // wave-uniform
         const double mu = wprep[kPrepMu];
@@ -145,8 +176,8 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
         raster_row<P, T>(wprep, n_ps, n_sersic, t, iy, ps_only != 0, r);
 #pragma unroll
         for (int k = 0; k < P; ++k) v[k] = cd{r[k], mu * r[k] * r[k]};
-        if (raw_out) {
-            double* o = raw_out + (size_t)w * S + (size_t)iy * NX;
+        if (raw_out && row_on) {
+            double* o = raw_out + (size_t)w * Spx + (size_t)iy * NX;
 #pragma unroll
             for (int k = 0; k < P; ++k) o[T * k + t] = v[k].x;
         }
@@ -155,38 +186,63 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
     cd* twl = reinterpret_cast<cd*>(wave_lds + (size_t)RG * fft_lds_elems<NX>());
     cd tw[fft_tw_regs<NX>()];
     load_twiddles<NX>(tw, twx, t, twl, lane);
-    double* xbuf = wave_lds + (size_t)f * fft_lds_elems<NX>();
-    fft_wave<NX, -1>(v, tw, twx, t, xbuf, twl);
+    double* xbuf = wave_lds + (size_t)fe * fft_lds_elems<NX>();
+    fft_wave<NX, -1>(v, tw, twx, t, xbuf, twl, lane_on);
 
-    // Untangle.  Lane t holds Z[k], k = t + T e.  Z[NX - k] is held by lane
-    // (T - t) % T at e' = P-1-e (t != 0) or P-e (t == 0), i.e. in the upper half of
-    // its registers: pass the upper halves through LDS (wave-local; the N/2 complex
-    // fit the transform's exchange region of T (P+1) doubles).
     cd* ubuf = reinterpret_cast<cd*>(xbuf);
+    cd* wbase = Tbuf + (size_t)w * 2 * NXH * nyp;                    // wave-uniform
+    const unsigned kstride = 2u * (unsigned)nyp * kCd;               // bytes between kx columns
+    if constexpr (S::kPlain) {
+        // Untangle.  Lane t holds Z[k], k = t + T e.  Z[NX - k] is held by lane
+        // (T - t) % T at e' = P-1-e (t != 0) or P-e (t == 0), i.e. in the upper half of
+        // its registers: pass the upper halves through LDS (wave-local; the N/2 complex
+        // fit the transform's exchange region of T (P+1) doubles).
 #pragma unroll
-    for (int e = P / 2; e < P; ++e) ubuf[(e - P / 2) * T + t] = v[e];
-    wave_lds_sync();
-    const int tm = (T - t) % T;
-    const int shift = t ? P - 1 : P;
-    cd* wbase = Tbuf + (size_t)w * 2 * NXH * ny;                    // wave-uniform
-    const unsigned kstride = 2u * (unsigned)ny * kCd;                // bytes between kx columns
-    const unsigned off0 = (unsigned)t_elem(iy, 0, __builtin_ctz(RG)) * kCd + (unsigned)t * kstride;
+        for (int e = P / 2; e < P; ++e) ubuf[(e - P / 2) * T + t] = v[e];
+        wave_lds_sync();
+        const int tm = (T - t) % T;
+        const int shift = t ? P - 1 : P;
+        const unsigned off0 = (unsigned)t_elem(iy, 0, RGL2) * kCd + (unsigned)t * kstride;
 #pragma unroll
-    for (int e = 0; e < P / 2; ++e) {
-        const cd zk = v[e];
-        cd zm = (e == 0 && t == 0) ? zk                       // k = 0 is its own mirror
-                                   : ubuf[(shift - e - P / 2) * T + tm];
-        cd* o = at_bytes(wbase, off0 + (unsigned)(T * e) * kstride);
-        // TWICE the spectra of raw and of mu raw^2: the 1/2 of the untangling is a power of
-        // two and rides on the kernel spectra (k_scale_kernel_spectrum), bit for bit the same
-        o[0] = cd{zk.x + zm.x, zk.y - zm.y};
-        o[RG] = cd{zk.y + zm.y, zm.x - zk.x};
-    }
-    if (t == 0) {                                           // Nyquist column, its own mirror
-        const cd z = v[P / 2];
-        cd* o = at_bytes(wbase, off0 + (unsigned)(NX / 2) * kstride);
-        o[0] = cd{z.x + z.x, 0.0};
-        o[RG] = cd{z.y + z.y, 0.0};
+        for (int e = 0; e < P / 2; ++e) {
+            const cd zk = v[e];
+            cd zm = (e == 0 && t == 0) ? zk                       // k = 0 is its own mirror
+                                       : ubuf[(shift - e - P / 2) * T + tm];
+            cd* o = at_bytes(wbase, off0 + (unsigned)(T * e) * kstride);
+            // TWICE the spectra of raw and of mu raw^2: the 1/2 of the untangling is a power of
+            // two and rides on the kernel spectra (k_scale_kernel_spectrum), bit for bit the same
+            o[0] = cd{zk.x + zm.x, zk.y - zm.y};
+            o[RGL] = cd{zk.y + zm.y, zm.x - zk.x};
+        }
+        if (t == 0) {                                           // Nyquist column, its own mirror
+            const cd z = v[P / 2];
+            cd* o = at_bytes(wbase, off0 + (unsigned)(NX / 2) * kstride);
+            o[0] = cd{z.x + z.x, 0.0};
+            o[RGL] = cd{z.y + z.y, 0.0};
+        }
+    } else {
+        // General shapes: register e of lane t holds Z[k], k = fft_k_of(t, e).  Every Z[k] with
+        // k > NX/2 goes to LDS slot NX - k; the holder of k <= NX/2 reads its mirror from slot k
+        // (k = 0 and k = NX/2 are their own mirrors, for which the same formulas give the
+        // doubled real spectrum values).
+#pragma unroll
+        for (int e = 0; e < R; ++e) {
+            const int k = fft_k_of<NX>(t, e);
+            if (lane_on && fft_slot_valid<NX>(t, e) && 2 * k > NX) ubuf[NX - k] = v[e];
+        }
+        wave_lds_sync();
+        const unsigned off_row = (unsigned)t_elem(row_on ? iy : 0, 0, RGL2) * kCd;
+#pragma unroll
+        for (int e = 0; e < R; ++e) {
+            const int k = fft_k_of<NX>(t, e);
+            if (row_on && fft_slot_valid<NX>(t, e) && 2 * k <= NX) {
+                const cd zk = v[e];
+                const cd zm = (k == 0 || 2 * k == NX) ? zk : ubuf[k];
+                cd* o = at_bytes(wbase, off_row + (unsigned)k * kstride);
+                o[0] = cd{zk.x + zm.x, zk.y - zm.y};
+                o[RGL] = cd{zk.y + zm.y, zm.x - zk.x};
+            }
+        }
     }
 }
 
@@ -223,17 +279,23 @@ __global__ void __launch_bounds__(kColThreads, fused_min_waves<NY>())
 k_cols(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restrict__ prep,
        const uint8_t* __restrict__ skip, const cd* __restrict__ twy, int plen, int nxh, int n_w,
        int rg_log2) {
-    constexpr int P = FftShape<NY>::P, T = FftShape<NY>::T;
+    using S = FftShape<NY>;
+    constexpr int P = S::P, T = S::T, R = S::R, TPW = S::TPW;
     constexpr int FPB = col_ffts_per_block<NY>();
     extern __shared__ __align__(16) double smem[];
-    const int s = threadIdx.x / T, t = threadIdx.x % T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fl = lane / T, t = lane % T;
+    const bool slot_on = S::kFull || fl < TPW;                       // not an idle tail lane
+    const int fe = S::kFull ? fl : (fl < TPW ? fl : TPW - 1);
+    const int s = wave * TPW + fe;                                   // slot within the workgroup
     double* wave_lds = smem + (size_t)wave * fused_col_wave_lds_doubles<NY>();
-    double* xbuf = wave_lds + (size_t)(lane / T) * fft_lds_elems<NY>();
-    cd* twl = reinterpret_cast<cd*>(wave_lds + (size_t)(64 / T) * fft_lds_elems<NY>());
+    double* xbuf = wave_lds + (size_t)fe * fft_lds_elems<NY>();
+    cd* twl = reinterpret_cast<cd*>(wave_lds + (size_t)TPW * fft_lds_elems<NY>());
     constexpr int TM = PSFMC_TW_MODE_COLS;
     cd tw[TwRegs<NY, TM>::value];
     load_twiddles<NY, TM>(tw, twy, t, twl, lane);
+    const int nyp = S::kPlain ? NY : t_col_len(NY, rg_log2);         // column length of the layout
+    const int rg_mask = (1 << rg_log2) - 1;
     const int n_cols = n_w * 2 * nxh;
     const int n_groups = (n_cols + FPB - 1) / FPB;
     const GroupRange gr = xcd_group_range(n_groups);
@@ -241,54 +303,88 @@ k_cols(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restric
     // Slots past the last column (final group only) and skipped walkers still LOAD -- from
     // the last valid column / the walker's stale data -- and transform; only their stores are
     // masked.  Zero-filling their registers instead cost 32 moves per group in every lane.
+    // Returns the column's base: element (y, c) sits at base[2 y - (y & rg_mask)] (t_elem with
+    // the component's offset folded into the base).
     auto locate = [&](int grp, int& w, int& kx, int& c, bool& active) -> cd* {
         int col = grp * FPB + s;
-        active = col < n_cols;
-        col = active ? col : n_cols - 1;
+        active = slot_on && col < n_cols;
+        col = col < n_cols ? col : n_cols - 1;
         c = col & 1;                              // component
         const int pr = col >> 1;                  // kx * n_w + walker
         kx = pr / n_w;
         w = pr - kx * n_w;
         if (active && skip && skip[w]) active = false;
-        return Tbuf + ((size_t)w * nxh + kx) * 2 * NY + (c << rg_log2) + t_elem(t, 0, rg_log2);
+        return Tbuf + ((size_t)w * nxh + kx) * 2 * nyp + (c << rg_log2);
     };
-    // Software pipeline (P <= 16): the next group's column is loaded into a second register
+    // element offset of row y inside a column (see locate); for the power-of-two shapes the
+    // row groups divide T, so the offset is affine in the register index
+    auto row_off = [&](int y) -> int { return 2 * y - (y & rg_mask); };
+    // Software pipeline (small shapes): the next group's column is loaded into a second register
     // set while this one is transformed.  Loads return in order, so they are issued AFTER the
     // kernel-spectrum loads were consumed and fly during the inverse transform and the
     // stores (issued before the forward transform they made the multiply wait for them:
     // 56 us instead of 46; here 43 us).  The twiddles live in LDS to make room.
-    constexpr bool PF = PSFMC_COLS_PREFETCH && P <= 16;
+    constexpr bool PF = PSFMC_COLS_PREFETCH && S::kPlain && R <= 16;
     struct Slot {
         cd* base;
         int w, kx, c;
         bool active;
     };
-    auto load_group = [&](int grp, cd (&dst)[P], Slot& sl) {
+    auto load_group = [&](int grp, cd (&dst)[R], Slot& sl) {
         sl.base = locate(grp, sl.w, sl.kx, sl.c, sl.active);
+        if constexpr (S::kPlain) {
+            const cd* b0 = sl.base + row_off(t);
 #pragma unroll
-        for (int a = 0; a < P; ++a) dst[a] = load_stream(sl.base + 2 * T * a);
+            for (int a = 0; a < P; ++a) dst[a] = load_stream(b0 + 2 * T * a);
+        } else {
+#pragma unroll
+            for (int a = 0; a < P; ++a) dst[a] = load_stream(sl.base + row_off(T * a + t));
+#pragma unroll
+            for (int a = P; a < R; ++a) dst[a] = cd{0.0, 0.0};
+        }
     };
     // one column per slot: forward, * kernel spectrum, `between()`, inverse, store in place
-    auto transform = [&](cd (&v)[P], const Slot& sl, auto&& between) {
-        fft_wave<NY, -1, TM>(v, tw, twy, t, xbuf, twl);
+    auto transform = [&](cd (&v)[R], const Slot& sl, auto&& between) {
+        fft_wave<NY, -1, TM>(v, tw, twy, t, xbuf, twl, slot_on);
         if constexpr (CONVOLVE) {
             // a skipped walker's record may hold anything: its (masked) lanes use PSF 0
             const int psf = sl.active ? (int)prep[(size_t)sl.w * plen + kPrepPsfIdx] : 0;
             const cd* k = Kt + (((size_t)psf * nxh + sl.kx) * 2 + sl.c) * NY;
+            if constexpr (S::kPlain) {
 #pragma unroll
-            for (int e = 0; e < P; ++e) v[e] = cmul(v[e], k[t + T * e]);
+                for (int e = 0; e < R; ++e) v[e] = cmul(v[e], k[t + T * e]);
+            } else {
+                // register e holds X[fft_k_of(t, e)]
+#pragma unroll
+                for (int e = 0; e < R; ++e) {
+                    const int ky = fft_slot_valid<NY>(t, e) ? fft_k_of<NY>(t, e) : 0;
+                    v[e] = cmul(v[e], k[ky]);
+                }
+            }
         }
         between();
-        if constexpr (CONVOLVE) fft_wave<NY, +1, TM>(v, tw, twy, t, xbuf, twl);
+        if constexpr (CONVOLVE) {
+            // an inexact shape leaves X[(t + T h) + P d] in register h + H d, and a transform
+            // wants x[T a + t] in register a: regroup through LDS
+            if constexpr (!S::kExact) fft_regroup<NY>(v, t, xbuf, slot_on);
+            fft_wave<NY, +1, TM>(v, tw, twy, t, xbuf, twl, slot_on);
+        }
         if (sl.active) {
+            if constexpr (S::kPlain) {
+                cd* b0 = sl.base + row_off(t);
 #pragma unroll
-            for (int e = 0; e < P; ++e) sl.base[2 * T * e] = v[e];
+                for (int e = 0; e < R; ++e) b0[2 * T * e] = v[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < R; ++e)
+                    if (fft_slot_valid<NY>(t, e)) sl.base[row_off(fft_k_of<NY>(t, e))] = v[e];
+            }
         }
     };
     if constexpr (PF) {
         // two register sets take turns (no copies): while one is transformed the other
         // receives the next group
-        cd A[P], B[P];
+        cd A[R], B[R];
         Slot sa{Tbuf, 0, 0, 0, false}, sb{Tbuf, 0, 0, 0, false};
         const int step = gr.step;
         if (gr.first < gr.end) load_group(gr.first, A, sa);
@@ -308,7 +404,7 @@ k_cols(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restric
         }
     } else {
         for (int grp = gr.first; grp < gr.end; grp += gr.step) {
-            cd v[P];
+            cd v[R];
             Slot sl{Tbuf, 0, 0, 0, false};
             load_group(grp, v, sl);
             transform(v, sl, [] {});
@@ -400,8 +496,10 @@ k_rows_inv(const cd* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
            const FieldPx* __restrict__ field, double* __restrict__ partial, int ny,
            const double* __restrict__ prep, int plen,
            double* __restrict__ conv_out, double* __restrict__ var_out) {
-    constexpr int P = FftShape<NX>::P, T = FftShape<NX>::T, RG = row_group<NX>();
+    using S = FftShape<NX>;
+    constexpr int P = S::P, T = S::T, R = S::R, RG = row_group<NX>();
     constexpr int NXH = NX / 2 + 1;
+    constexpr int RGL2 = layout_rg_log2<NX>(), RGL = 1 << RGL2;
     extern __shared__ __align__(16) double smem[];
 
     const int w = blockIdx.y;
@@ -409,79 +507,123 @@ k_rows_inv(const cd* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int f = lane / T, t = lane % T;
     const int yg = blockIdx.x * row_waves<NX>() + wave;
+    if constexpr (!S::kPlain)
+        if (yg * RG >= ny) return;                                    // wave-uniform
+    const bool lane_on = S::kFull || f < RG;
+    const int fe = S::kFull ? f : (f < RG ? f : RG - 1);
     const int iy = yg * RG + f;
-    const cd* wbase = Tbuf + (size_t)w * 2 * NXH * ny;              // wave-uniform
-    const unsigned kstride = 2u * (unsigned)ny * kCd;                // bytes between kx columns
-    const unsigned off0 = (unsigned)t_elem(iy, 0, __builtin_ctz(RG)) * kCd + (unsigned)t * kstride;
+    const bool row_on = S::kPlain || (lane_on && iy < ny);
+    const int nyp = t_col_len(ny, RGL2);
+    const int nyg = S::kPlain ? (int)gridDim.x * row_waves<NX>() : (ny + RG - 1) / RG;
+    const cd* wbase = Tbuf + (size_t)w * 2 * NXH * nyp;             // wave-uniform
+    const unsigned kstride = 2u * (unsigned)nyp * kCd;               // bytes between kx columns
 
     // Y[k], k = T a + t:  k <= NX/2: G[k] + i H[k];  else conj(G[NX-k]) + i conj(H[NX-k]).
     // Every (G, H) pair is loaded once, by the lane that owns k <= NX/2; that lane also
-    // forms the mirrored value and hands it to the owner of NX - k (lane (T - t) % T, at
-    // a' = P-1-a for t != 0, P-a for t == 0) through the transform's LDS region.
+    // forms the mirrored value and hands it to the owner of NX - k through the transform's
+    // LDS region.
     double* wave_lds = smem + (size_t)wave * fused_row_wave_lds_doubles<NX>();
-    cd* mbuf = reinterpret_cast<cd*>(wave_lds + (size_t)f * fft_lds_elems<NX>());   // [P/2][T] complex
-    cd v[P];
+    cd* mbuf = reinterpret_cast<cd*>(wave_lds + (size_t)fe * fft_lds_elems<NX>());
+    cd v[R];
 #pragma unroll
-    for (int a = 0; a < P / 2; ++a) {
-        const cd* p = at_bytes(wbase, off0 + (unsigned)(T * a) * kstride);
-        const cd g = load_stream(p), h = load_stream(p + RG);
-        v[a] = cd{g.x - h.y, g.y + h.x};
-        mbuf[a * T + t] = cd{g.x + h.y, h.x - g.y};
-    }
-    {   // Nyquist column k = NX/2 (lane 0 only); the other lanes take a mirror for a = P/2
-        const cd* p = at_bytes(wbase, off0 + (unsigned)(NX / 2) * kstride);   // t == 0: kx = NX/2
-        cd g = cd{0.0, 0.0}, h = cd{0.0, 0.0};
-        if (t == 0) { g = load_stream(p); h = load_stream(p + RG); }
-        v[P / 2] = cd{g.x - h.y, g.y + h.x};
-    }
-    wave_lds_sync();
-    {
-        const int tm = (T - t) % T;
-        const int shift = t ? P - 1 : P;
+    for (int a = P; a < R; ++a) v[a] = cd{0.0, 0.0};
+    if constexpr (S::kPlain) {
+        // the owner of NX - k is lane (T - t) % T at a' = P-1-a (t != 0) or P-a (t == 0);
+        // mbuf is [P/2][T] complex
+        const unsigned off0 = (unsigned)t_elem(iy, 0, RGL2) * kCd + (unsigned)t * kstride;
 #pragma unroll
-        for (int a = P / 2; a < P; ++a) {
-            if (a == P / 2 && t == 0) continue;               // lane 0 holds the Nyquist value
-            v[a] = mbuf[(shift - a) * T + tm];
+        for (int a = 0; a < P / 2; ++a) {
+            const cd* p = at_bytes(wbase, off0 + (unsigned)(T * a) * kstride);
+            const cd g = load_stream(p), h = load_stream(p + RGL);
+            v[a] = cd{g.x - h.y, g.y + h.x};
+            mbuf[a * T + t] = cd{g.x + h.y, h.x - g.y};
+        }
+        {   // Nyquist column k = NX/2 (lane 0 only); the other lanes take a mirror for a = P/2
+            const cd* p = at_bytes(wbase, off0 + (unsigned)(NX / 2) * kstride);   // t == 0: kx = NX/2
+            cd g = cd{0.0, 0.0}, h = cd{0.0, 0.0};
+            if (t == 0) { g = load_stream(p); h = load_stream(p + RGL); }
+            v[P / 2] = cd{g.x - h.y, g.y + h.x};
+        }
+        wave_lds_sync();
+        {
+            const int tm = (T - t) % T;
+            const int shift = t ? P - 1 : P;
+#pragma unroll
+            for (int a = P / 2; a < P; ++a) {
+                if (a == P / 2 && t == 0) continue;               // lane 0 holds the Nyquist value
+                v[a] = mbuf[(shift - a) * T + tm];
+            }
+        }
+    } else {
+        // general shapes: the mirror of k goes to LDS slot k (0 < k < NX/2), the owner of
+        // k' > NX/2 reads slot NX - k'
+        const unsigned off_row = (unsigned)t_elem(row_on ? iy : 0, 0, RGL2) * kCd;
+#pragma unroll
+        for (int a = 0; a < P; ++a) {
+            const int k = T * a + t;
+            if (2 * T * a <= NX) {                                // (folds when unrolled) some lane of this register is in the lower half
+                const bool low = 2 * k <= NX;
+                cd g = cd{0.0, 0.0}, h = cd{0.0, 0.0};
+                if (low && row_on) {
+                    const cd* p = at_bytes(wbase, off_row + (unsigned)k * kstride);
+                    g = load_stream(p);
+                    h = load_stream(p + RGL);
+                }
+                v[a] = cd{g.x - h.y, g.y + h.x};
+                if (low && lane_on && k > 0 && 2 * k < NX) mbuf[k] = cd{g.x + h.y, h.x - g.y};
+            }
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int a = 0; a < P; ++a) {
+            const int k = T * a + t;
+            if (2 * (T * a + T - 1) > NX) {                       // (folds) some lane of this register is in the upper half
+                if (2 * k > NX) v[a] = mbuf[NX - k];
+            }
         }
     }
     wave_lds_sync();
     cd* twl = reinterpret_cast<cd*>(wave_lds + (size_t)RG * fft_lds_elems<NX>());
     cd tw[fft_tw_regs<NX>()];
     load_twiddles<NX>(tw, twx, t, twl, lane);
-    fft_wave<NX, +1>(v, tw, twx, t, wave_lds + (size_t)f * fft_lds_elems<NX>(), twl);
+    fft_wave<NX, +1>(v, tw, twx, t, wave_lds + (size_t)fe * fft_lds_elems<NX>(), twl, lane_on);
     // imaginary part is lambda * model variance (see build_prep)
     const double inv_lambda = prep[(size_t)w * plen + kPrepInvLambda];
 
     if (conv_out) {
-        const size_t rowoff = (size_t)w * ny * NX + (size_t)iy * NX;
+        const size_t rowoff = (size_t)w * ny * NX + (size_t)(row_on ? iy : 0) * NX;
 #pragma unroll
-        for (int e = 0; e < P; ++e) {
-            conv_out[rowoff + T * e + t] = v[e].x;
-            var_out[rowoff + T * e + t] = v[e].y * inv_lambda;
+        for (int e = 0; e < R; ++e) {
+            if (row_on && fft_slot_valid<NX>(t, e)) {
+                const int x = fft_k_of<NX>(t, e);
+                conv_out[rowoff + x] = v[e].x;
+                var_out[rowoff + x] = v[e].y * inv_lambda;
+            }
         }
     }
     // sum over the lane's good pixels of r^2 / d + ln(2 pi d), d = model_var + obs_var
-    // (= r^2 ivm - ln(ivm / 2 pi), models.py:233-236).  The P logarithms of a lane are
+    // (= r^2 ivm - ln(ivm / 2 pi), models.py:233-236).  The logarithms of a lane are
     // taken as ONE: ln prod d = ln2 (log2 prod mant(d) + sum exp(d)), with the mantissas in
-    // [1/2, 1) so that the product of P <= 32 of them cannot underflow -- a log2 is 27
+    // [1/2, 1) so that the product of <= 32 of them cannot underflow -- a log2 is 27
     // instructions, frexp + multiply + integer add are 4.  d <= 0 or NaN gives NaN like the
     // reference's log of a non-positive weight.
-    // Waves whose pixels are all good (NaN sci marks an excluded pixel) skip the selects.
-    const FieldPx* fbase = field + (size_t)yg * P * 64;              // wave-uniform
+    // Waves whose pixels are all good (NaN sci marks an excluded pixel, and a register slot
+    // that holds no pixel at all) skip the selects.
+    const FieldPx* fbase = field + (size_t)yg * R * 64;              // wave-uniform
     const unsigned foff = (unsigned)lane * (unsigned)sizeof(FieldPx);
-    FieldPx px[P];
+    FieldPx px[R];
     bool any_bad = false;
 #pragma unroll
-    for (int e = 0; e < P; ++e) {
+    for (int e = 0; e < R; ++e) {
         px[e] = *at_bytes(fbase, foff + (unsigned)(e * 64 * sizeof(FieldPx)));
         any_bad |= px[e].sci != px[e].sci;
     }
     double acc = 0.0, mant = 1.0;
-    int expo = 0, n_good = P;
+    int expo = 0, n_good = R;
     bool invalid = false;
     if (!__any(any_bad)) {
 #pragma unroll
-        for (int e = 0; e < P; ++e) {
+        for (int e = 0; e < R; ++e) {
             const double d = __builtin_fma(v[e].y, inv_lambda, px[e].var);
             const double r = px[e].sci - v[e].x;
             acc = __builtin_fma(r * r, fast_rcp(d), acc);
@@ -492,7 +634,7 @@ k_rows_inv(const cd* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
     } else {
         n_good = 0;
 #pragma unroll
-        for (int e = 0; e < P; ++e) {
+        for (int e = 0; e < R; ++e) {
             const bool good = px[e].sci == px[e].sci;
             const double d = __builtin_fma(v[e].y, inv_lambda, px[e].var);
             const double r = px[e].sci - v[e].x;
@@ -510,7 +652,7 @@ k_rows_inv(const cd* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
     acc = invalid ? __builtin_nan("") : acc;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-    if (lane == 0) partial[(size_t)w * gridDim.x * row_waves<NX>() + yg] = acc;
+    if (lane == 0) partial[(size_t)w * nyg + yg] = acc;
 }
 
 // Kt[psf][kx][c][ky] = spec_c[psf][ky][kx] * (-1)^(kx+ky) / S from the
@@ -526,7 +668,7 @@ __global__ void k_scale_kernel_spectrum(const cd* __restrict__ raw, cd* __restri
         const int pk = i / (2 * ny);                    // psf*nxh + kx
         const int kx = pk % nxh;
         const double sc = ((kx + ky) & 1) ? -inv_s : inv_s;
-        const cd v = raw[(size_t)pk * 2 * ny + t_elem(ky, c, rg_log2)];
+        const cd v = raw[(size_t)pk * 2 * t_col_len(ny, rg_log2) + t_elem(ky, c, rg_log2)];
         Kt[i] = cd{v.x * sc, v.y * sc};
     }
 }
@@ -541,7 +683,7 @@ __global__ void k_untranspose_spectrum(const cd* __restrict__ raw, cd* __restric
         const int ky = (i / nxh) % ny;
         const int p = i / (nxh * ny);
         const double sc = 0.5 * (c ? 1.0 / rho[p] : 1.0);      // k_rows_fwd doubles
-        const cd v = raw[((size_t)p * nxh + kx) * 2 * ny + t_elem(ky, c, rg_log2)];
+        const cd v = raw[((size_t)p * nxh + kx) * 2 * t_col_len(ny, rg_log2) + t_elem(ky, c, rg_log2)];
         out[i] = cd{v.x * sc, v.y * sc};
     }
 }

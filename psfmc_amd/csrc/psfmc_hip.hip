@@ -59,15 +59,45 @@ static int fail(int code, const char* fmt, ...) {
         if (rc_ != PSFMC_OK) return rc_; \
     } while (0)
 
-// run BODY with `N_` a compile-time copy of the (power-of-two) length n
-#define DISPATCH_LEN(n, BODY)                                                                   \
-    switch (n) {                                                                                \
-        case 64:   { constexpr int N_ = 64;   BODY; } break;                                    \
-        case 128:  { constexpr int N_ = 128;  BODY; } break;                                    \
-        case 256:  { constexpr int N_ = 256;  BODY; } break;                                    \
-        case 512:  { constexpr int N_ = 512;  BODY; } break;                                    \
-        case 1024: { constexpr int N_ = 1024; BODY; } break;                                    \
-        default: return fail(PSFMC_EINVAL, "fused backend supports sides 64..1024, got %d", n); \
+// sides the fused kernels are instantiated for (FftShape in psfmc_fft.h): every power of two
+// 64..1024 and the even 5-smooth sides listed there
+#define PSFMC_FUSED_SIDES "64 96 100 120 128 144 150 160 180 192 200 240 250 256 288 300 320 360 384 400 480 500 512 576 600 640 720 768 800 900 960 1024"
+// run BODY with `N_` a compile-time copy of the length n
+#define DISPATCH_LEN(n, BODY) \
+    switch (n) { \
+        case 64: { constexpr int N_ = 64; BODY; } break; \
+        case 96: { constexpr int N_ = 96; BODY; } break; \
+        case 100: { constexpr int N_ = 100; BODY; } break; \
+        case 120: { constexpr int N_ = 120; BODY; } break; \
+        case 128: { constexpr int N_ = 128; BODY; } break; \
+        case 144: { constexpr int N_ = 144; BODY; } break; \
+        case 150: { constexpr int N_ = 150; BODY; } break; \
+        case 160: { constexpr int N_ = 160; BODY; } break; \
+        case 180: { constexpr int N_ = 180; BODY; } break; \
+        case 192: { constexpr int N_ = 192; BODY; } break; \
+        case 200: { constexpr int N_ = 200; BODY; } break; \
+        case 240: { constexpr int N_ = 240; BODY; } break; \
+        case 250: { constexpr int N_ = 250; BODY; } break; \
+        case 256: { constexpr int N_ = 256; BODY; } break; \
+        case 288: { constexpr int N_ = 288; BODY; } break; \
+        case 300: { constexpr int N_ = 300; BODY; } break; \
+        case 320: { constexpr int N_ = 320; BODY; } break; \
+        case 360: { constexpr int N_ = 360; BODY; } break; \
+        case 384: { constexpr int N_ = 384; BODY; } break; \
+        case 400: { constexpr int N_ = 400; BODY; } break; \
+        case 480: { constexpr int N_ = 480; BODY; } break; \
+        case 500: { constexpr int N_ = 500; BODY; } break; \
+        case 512: { constexpr int N_ = 512; BODY; } break; \
+        case 576: { constexpr int N_ = 576; BODY; } break; \
+        case 600: { constexpr int N_ = 600; BODY; } break; \
+        case 640: { constexpr int N_ = 640; BODY; } break; \
+        case 720: { constexpr int N_ = 720; BODY; } break; \
+        case 768: { constexpr int N_ = 768; BODY; } break; \
+        case 800: { constexpr int N_ = 800; BODY; } break; \
+        case 900: { constexpr int N_ = 900; BODY; } break; \
+        case 960: { constexpr int N_ = 960; BODY; } break; \
+        case 1024: { constexpr int N_ = 1024; BODY; } break; \
+        default: return fail(PSFMC_EINVAL, "fused backend: side %d is not one of " PSFMC_FUSED_SIDES, n); \
     }
 
 // ---------------------------------------------------------------------------
@@ -76,6 +106,7 @@ static int fail(int code, const char* fmt, ...) {
 struct psfmc_ctx {
     int device = 0;
     int ny = 0, nx = 0, nxh = 0, S = 0, F = 0;
+    int nyp = 0;                  // column length of the T layout: ny rounded up to whole row groups
     int n_psf = 0, n_ps = 0, n_sersic = 0;
     int max_walkers = 0, chunk = 0, backend = 0;
     int single_cap = 0;                               // walkers T buffer 0 holds (>= chunk)
@@ -193,21 +224,29 @@ static int alloc_work(psfmc_ctx* c) {
     c->single_cap = 2 * c->chunk < c->max_walkers ? 2 * c->chunk : c->max_walkers;
     if (c->single_cap < c->chunk) c->single_cap = c->chunk;
     for (int i = 0; i < c->n_streams; ++i)
-        HIP_TRY(hipMalloc(&c->d_Ts[i], (size_t)(i ? c->chunk : c->single_cap) * 2 * c->nxh * c->ny * sizeof(cd)));
+        HIP_TRY(hipMalloc(&c->d_Ts[i], (size_t)(i ? c->chunk : c->single_cap) * 2 * c->nxh * c->nyp * sizeof(cd)));
     c->d_T = c->d_Ts[0];
     return PSFMC_OK;
 }
 
-static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+static bool fused_side(int n) {
+    static const int sides[] = {64,96,100,120,128,144,150,160,180,192,200,240,250,256,288,300,320,360,384,400,480,500,512,576,600,640,720,768,800,900,960,1024};
+    for (int v : sides)
+        if (v == n) return true;
+    return false;
+}
+
+// per-side constants of the row kernels
+struct RowShape { int rg, waves, rg_log2, regs; bool plain; };
+static int row_shape_for(int nx, RowShape* out) {
+    DISPATCH_LEN(nx, (*out = RowShape{row_group<N_>(), row_waves<N_>(), layout_rg_log2<N_>(), FftShape<N_>::R,
+                                      FftShape<N_>::kPlain}));
+    return PSFMC_OK;
+}
 
 // ---------------------------------------------------------------------------
 // fused path launchers
 // ---------------------------------------------------------------------------
-static int row_group_for(int nx) {
-    DISPATCH_LEN(nx, return row_group<N_>());
-    return 0;
-}
-
 template <int NX, bool FROM_IMAGE>
 static int launch_rows_fwd(psfmc_ctx* c, int n, const double* prep, const uint8_t* skip, cd* Tbuf,
                            int ps_only, const double* img, const double* img_scale, double* raw_out,
@@ -221,7 +260,7 @@ static int launch_rows_fwd(psfmc_ctx* c, int n, const double* prep, const uint8_
             attr_device = c->device;
         }
     }
-    hipLaunchKernelGGL((k_rows_fwd<NX, FROM_IMAGE>), dim3(c->ny / row_group<NX>() / row_waves<NX>(), n),
+    hipLaunchKernelGGL((k_rows_fwd<NX, FROM_IMAGE>), dim3((c->nblk + row_waves<NX>() - 1) / row_waves<NX>(), n),
                        dim3(row_threads<NX>()), lds, st, prep, skip, c->d_twx, Tbuf, c->n_ps, c->n_sersic,
                        c->ny, ps_only, img, img_scale, raw_out);
     return PSFMC_OK;
@@ -231,7 +270,7 @@ template <int NY, bool CONVOLVE>
 static int launch_cols(psfmc_ctx* c, cd* Tbuf, int n_w, const double* prep, const uint8_t* skip,
                        hipStream_t st) {
     const int n_cols = n_w * 2 * c->nxh;
-    if constexpr (NY >= 512) {          // long columns: wave-wide three-stage engine
+    if constexpr (NY == 512 || NY == 1024) {          // long power-of-two columns: wave-wide three-stage engine
         if (c->cols3) {
             constexpr size_t lds3 = fused_col3_lds_bytes<NY>();
             const int per_block = kColThreads / 64;
@@ -268,7 +307,7 @@ static int launch_rows_inv(psfmc_ctx* c, int n, const cd* Tbuf, const double* pr
             attr_device = c->device;
         }
     }
-    hipLaunchKernelGGL((k_rows_inv<NX>), dim3(c->ny / row_group<NX>() / row_waves<NX>(), n), dim3(row_threads<NX>()), lds, st,
+    hipLaunchKernelGGL((k_rows_inv<NX>), dim3((c->nblk + row_waves<NX>() - 1) / row_waves<NX>(), n), dim3(row_threads<NX>()), lds, st,
                        Tbuf, skip, c->d_twx, c->d_field, partial, c->ny, prep, c->plen, conv_out,
                        var_out);
     return PSFMC_OK;
@@ -366,7 +405,8 @@ static int spectra_hipfft(psfmc_ctx* c, const double* d_canvas) {
 
 static int spectra_fused(psfmc_ctx* c, const double* d_canvas) {
     const size_t n_el = (size_t)c->n_psf * 2 * c->nxh * c->ny;
-    HIP_TRY(hipMalloc(&c->d_Kraw, n_el * sizeof(cd)));
+    HIP_TRY(hipMalloc(&c->d_Kraw, (size_t)c->n_psf * 2 * c->nxh * c->nyp * sizeof(cd)));
+    HIP_TRY(hipMemsetAsync(c->d_Kraw, 0, (size_t)c->n_psf * 2 * c->nxh * c->nyp * sizeof(cd), c->stream));
     HIP_TRY(hipMalloc(&c->d_Kt, n_el * sizeof(cd)));
     DISPATCH_LEN(c->nx, RC_TRY((launch_rows_fwd<N_, true>(c, c->n_psf, nullptr, nullptr, c->d_Kraw, 0,
                                                           d_canvas, c->d_rho, nullptr, c->stream))));
@@ -427,7 +467,9 @@ static int ctx_init(psfmc_ctx* c, const double* sci, const double* obs_var, cons
         }
         HIP_TRY(hipMalloc(&c->d_rho, c->n_psf * sizeof(double)));
         HIP_TRY(hipMemcpy(c->d_rho, rho.data(), c->n_psf * sizeof(double), hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc(&c->d_field, (size_t)c->S * sizeof(FieldPx)));
+        size_t field_len = 0;
+        DISPATCH_LEN(c->nx, field_len = fused_field_len<N_>(c->ny));
+        HIP_TRY(hipMalloc(&c->d_field, field_len * sizeof(FieldPx)));
         DISPATCH_LEN(c->nx, RC_TRY(pack_field<N_>(c)));
     }
 
@@ -478,14 +520,17 @@ extern "C" int psfmc_ctx_create(psfmc_ctx** out, int device, int ny, int nx, con
     if (backend != PSFMC_BACKEND_HIPFFT && backend != PSFMC_BACKEND_FUSED)
         return fail(PSFMC_EINVAL, "unknown backend %d", backend);
     int row_tiles = 0;
+    RowShape rs{};
     if (backend == PSFMC_BACKEND_FUSED) {
-        if (!(is_pow2(ny) && is_pow2(nx)) || nx < 64 || ny < 64 || nx > 1024 || ny > 1024)
-            return fail(PSFMC_EINVAL, "fused backend needs power-of-two sides in 64..1024 (got %d x %d)",
+        if (!fused_side(ny) || !fused_side(nx))
+            return fail(PSFMC_EINVAL, "fused backend: sides must be among " PSFMC_FUSED_SIDES " (got %d x %d)",
                         ny, nx);
-        const int rg = row_group_for(nx);
-        if (rg <= 0 || ny % rg)
-            return fail(PSFMC_EINVAL, "fused backend: ny=%d must be a multiple of %d for nx=%d", ny, rg, nx);
-        row_tiles = ny / rg;
+        RC_TRY(row_shape_for(nx, &rs));
+        // the power-of-two row kernels run without row guards: whole workgroups of rows only
+        if (rs.plain && ny % (rs.rg * rs.waves))
+            return fail(PSFMC_EINVAL, "fused backend: ny=%d must be a multiple of %d for nx=%d", ny,
+                        rs.rg * rs.waves, nx);
+        row_tiles = (ny + rs.rg - 1) / rs.rg;
     }
 
     int ndev = 0;
@@ -505,14 +550,16 @@ extern "C" int psfmc_ctx_create(psfmc_ctx** out, int device, int ny, int nx, con
     c->max_walkers = max_walkers; c->backend = backend;
     c->rlen = row_len(n_ps, n_sersic);
     c->plen = prep_len(n_ps, n_sersic);
+    c->nyp = ny;
     if (backend == PSFMC_BACKEND_FUSED) {
         c->nblk = row_tiles;
-        c->rg_log2 = __builtin_ctz(ny / row_tiles);
+        c->rg_log2 = rs.rg_log2;
+        c->nyp = t_col_len(ny, c->rg_log2);
         c->cols_grid = prop.multiProcessorCount * 2;
         // walkers per internal pass: the transposed half-spectra of one pass
         // (two passes in flight, together just under the 256 MiB Infinity Cache: measured
         // best at 256^2 -- 104..120 walkers; 136 and more fall off -- see DESIGN.md)
-        const double per_walker = 2.0 * c->nxh * c->ny * 16.0;
+        const double per_walker = 2.0 * c->nxh * c->nyp * 16.0;
         int chunk = ((int)(112.0 * 1048576.0 / per_walker) + 8) & ~15;
         if (chunk < 16) chunk = 16;
         c->chunk = chunk;
@@ -631,6 +678,7 @@ extern "C" double psfmc_get_option(const psfmc_ctx* cc, const char* key) {
         if (!strcmp(key, name)) { prof_collect(c); return (double)c->prof_n[i]; }
     }
     if (!strcmp(key, "row_group")) return 1 << c->rg_log2;
+    if (!strcmp(key, "partials_per_walker")) return c->nblk;
     if (!strcmp(key, "graph_launches")) return (double)c->graph_launches;
     if (!strcmp(key, "chunk_walkers")) return c->chunk;
     if (!strcmp(key, "backend")) return c->backend;
@@ -1390,6 +1438,127 @@ extern "C" int psfmc_get_spectra(psfmc_ctx* c, double* psf_spec, double* var_spe
     }
     (void)hipFree(tmp);
     return rc;
+}
+
+// ---------------------------------------------------------------------------
+// psfmc_group: ONE process driving several GPUs: a context per
+// device with the field replicated, walkers split into contiguous blocks, every device's
+// upload / evaluation / download enqueued on its own stream before any is waited for, the
+// blocks landing at their offsets of the caller's host array (for a host-side result that
+// is the whole "gather"; the one-process-per-GPU form with an RCCL all-gather of device
+// tensors is psfmc_amd/parallel.py).
+// ---------------------------------------------------------------------------
+struct psfmc_group {
+    std::vector<psfmc_ctx*> ctx;
+};
+
+static void group_block(int W, int n, int r, int* lo, int* hi) {
+    const int base = W / n, extra = W % n;
+    *lo = r * base + (r < extra ? r : extra);
+    *hi = *lo + base + (r < extra ? 1 : 0);
+}
+
+extern "C" int psfmc_group_create(psfmc_group** out, int n_dev, const int* devices, int ny, int nx,
+                                  const double* sci, const double* obs_var, const uint8_t* bad_px,
+                                  int n_psf, int psf_ny, int psf_nx, const double* psf,
+                                  const double* psf_var, int n_ps, int n_sersic, int max_walkers,
+                                  int backend) {
+    if (!out) return fail(PSFMC_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (n_dev < 1 || n_dev > 64 || !devices) return fail(PSFMC_EINVAL, "need 1..64 devices");
+    psfmc_group* g = new psfmc_group;
+    // every device may be handed the whole batch's share rounded up
+    const int per_dev = (max_walkers + n_dev - 1) / n_dev;
+    for (int i = 0; i < n_dev; ++i) {
+        psfmc_ctx* c = nullptr;
+        const int rc = psfmc_ctx_create(&c, devices[i], ny, nx, sci, obs_var, bad_px, n_psf, psf_ny, psf_nx,
+                                        psf, psf_var, n_ps, n_sersic, per_dev < 1 ? 1 : per_dev, backend);
+        if (rc != PSFMC_OK) {
+            const std::string keep = g_err;
+            for (psfmc_ctx* d : g->ctx) psfmc_ctx_destroy(d);
+            delete g;
+            g_err = keep;
+            return rc;
+        }
+        g->ctx.push_back(c);
+    }
+    *out = g;
+    return PSFMC_OK;
+}
+
+extern "C" int psfmc_group_destroy(psfmc_group* g) {
+    if (!g) return PSFMC_OK;
+    for (psfmc_ctx* c : g->ctx) psfmc_ctx_destroy(c);
+    delete g;
+    return PSFMC_OK;
+}
+
+extern "C" int psfmc_group_size(const psfmc_group* g) { return g ? (int)g->ctx.size() : PSFMC_EINVAL; }
+
+extern "C" int psfmc_group_set_layout(psfmc_group* g, int n_sky, int n_params, const int* slot_col,
+                                      const double* slot_const, const int* ps_method,
+                                      const int* sersic_degrees, double mag_zeropoint, const int* family,
+                                      const double* p0, const double* p1, const double* p2) {
+    if (!g) return fail(PSFMC_EINVAL, "group is NULL");
+    for (psfmc_ctx* c : g->ctx)
+        RC_TRY(psfmc_set_layout(c, n_sky, n_params, slot_col, slot_const, ps_method, sersic_degrees,
+                                mag_zeropoint, family, p0, p1, p2));
+    return PSFMC_OK;
+}
+
+// rows != nullptr: log-likelihoods of derived rows; else log-posteriors of raw vectors
+static int group_eval(psfmc_group* g, int W, const double* rows, const uint8_t* skip, const double* theta,
+                      const double* extra, double* out) {
+    if (!g) return fail(PSFMC_EINVAL, "group is NULL");
+    if (W < 0 || (W > 0 && (!out || (!rows && !theta)))) return fail(PSFMC_EINVAL, "bad argument");
+    const int n = (int)g->ctx.size();
+    int rc = PSFMC_OK;
+    for (int r = 0; r < n && rc == PSFMC_OK; ++r) {          // enqueue everything ...
+        int lo, hi;
+        group_block(W, n, r, &lo, &hi);
+        psfmc_ctx* c = g->ctx[r];
+        const int w = hi - lo;
+        if (w == 0) continue;
+        if (w > c->max_walkers) return fail(PSFMC_EINVAL, "W=%d exceeds the group's max_walkers", W);
+        HIP_TRY(hipSetDevice(c->device));
+        hipStream_t st = c->stream;
+        if (rows) {
+            HIP_TRY(hipMemcpyAsync(c->d_rows, rows + (size_t)lo * c->rlen, (size_t)w * c->rlen * sizeof(double),
+                                   hipMemcpyHostToDevice, st));
+            if (skip) HIP_TRY(hipMemcpyAsync(c->d_skip, skip + lo, (size_t)w, hipMemcpyHostToDevice, st));
+            rc = eval_device(c, w, c->d_rows, skip ? c->d_skip : nullptr, c->d_like, st);
+        } else {
+            rc = check_theta_call(c, w, theta, out);
+            if (rc != PSFMC_OK) break;
+            const int P = c->layout.n_params;
+            if (P) HIP_TRY(hipMemcpyAsync(c->d_theta, theta + (size_t)lo * P, (size_t)w * P * sizeof(double),
+                                          hipMemcpyHostToDevice, st));
+            if (extra) HIP_TRY(hipMemcpyAsync(c->d_extra, extra + lo, (size_t)w * sizeof(double),
+                                              hipMemcpyHostToDevice, st));
+            rc = eval_theta_device(c, w, c->d_theta, extra ? c->d_extra : nullptr, c->d_like, st);
+        }
+        if (rc == PSFMC_OK)
+            HIP_TRY(hipMemcpyAsync(out + lo, c->d_like, (size_t)w * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    for (int r = 0; r < n; ++r) {                             // ... then wait for every device
+        psfmc_ctx* c = g->ctx[r];
+        if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
+            if (rc == PSFMC_OK) rc = fail(PSFMC_EHIP, "device %d failed: %s", c->device,
+                                          hipGetErrorString(hipGetLastError()));
+    }
+    return rc;
+}
+
+extern "C" int psfmc_group_eval_batch(psfmc_group* g, int W, const double* rows, const uint8_t* skip,
+                                      double* loglike) {
+    if (W > 0 && !rows) return fail(PSFMC_EINVAL, "NULL rows");
+    return group_eval(g, W, rows, skip, nullptr, nullptr, loglike);
+}
+
+extern "C" int psfmc_group_eval_theta(psfmc_group* g, int W, const double* theta, const double* extra_lnprior,
+                                      double* lnprob) {
+    if (W > 0 && !theta) return fail(PSFMC_EINVAL, "NULL theta");
+    return group_eval(g, W, nullptr, nullptr, theta, extra_lnprior, lnprob);
 }
 
 // ---------------------------------------------------------------------------

@@ -14,6 +14,19 @@ BACKENDS = {'fused': BACKEND_FUSED, 'hipfft': BACKEND_HIPFFT}
 
 ROW_SKY, ROW_PS, ROW_SERSIC = 1, 4, 9
 
+# sides the fused kernels are built for (psfmc_amd/csrc/psfmc_fft.h FftShape)
+FUSED_SIDES = (64, 96, 100, 120, 128, 144, 150, 160, 180, 192, 200, 240, 250, 256, 288, 300, 320, 360,
+               384, 400, 480, 500, 512, 576, 600, 640, 720, 768, 800, 900, 960, 1024)
+# rows per workgroup of the power-of-two row kernels (they run without row guards)
+_PLAIN_ROW_BLOCK = {64: 8, 128: 8, 256: 4, 512: 4, 1024: 8}
+
+
+def fused_supports(ny, nx):
+    """Whether psfmc_ctx_create accepts this image shape for the fused back end."""
+    if ny not in FUSED_SIDES or nx not in FUSED_SIDES:
+        return False
+    return nx not in _PLAIN_ROW_BLOCK or ny % _PLAIN_ROW_BLOCK[nx] == 0
+
 _LIB_NAME = 'libpsfmc_hip.so'
 _lib = None
 
@@ -119,6 +132,20 @@ def load_library():
     lib.psfmc_get_accumulated.argtypes = [vp] + [_c_double_p] * 5 + [ctypes.POINTER(ctypes.c_longlong)]
     lib.psfmc_reset_accumulated.restype = ci
     lib.psfmc_reset_accumulated.argtypes = [vp]
+    lib.psfmc_group_create.restype = ci
+    lib.psfmc_group_create.argtypes = [ctypes.POINTER(vp), ci, ip, ci, ci, _c_double_p, _c_double_p,
+                                       _c_u8_p, ci, ci, ci, _c_double_p, _c_double_p, ci, ci, ci, ci]
+    lib.psfmc_group_destroy.restype = ci
+    lib.psfmc_group_destroy.argtypes = [vp]
+    lib.psfmc_group_size.restype = ci
+    lib.psfmc_group_size.argtypes = [vp]
+    lib.psfmc_group_set_layout.restype = ci
+    lib.psfmc_group_set_layout.argtypes = [vp, ci, ci, ip, _c_double_p, ip, ip, cd, ip, _c_double_p,
+                                           _c_double_p, _c_double_p]
+    lib.psfmc_group_eval_batch.restype = ci
+    lib.psfmc_group_eval_batch.argtypes = [vp, ci, _c_double_p, _c_u8_p, _c_double_p]
+    lib.psfmc_group_eval_theta.restype = ci
+    lib.psfmc_group_eval_theta.argtypes = [vp, ci, _c_double_p, _c_double_p, _c_double_p]
     lib.psfmc_debug_math.restype = ci
     lib.psfmc_debug_math.argtypes = [ci, ci, ci, _c_double_p, _c_double_p]
     if lib.psfmc_abi_version() != 1:
@@ -426,3 +453,80 @@ class Context(object):
 
     def get_option(self, key):
         return self._lib.psfmc_get_option(self._ctx, key.encode())
+
+
+class ContextGroup(object):
+    """One observed field replicated on several GPUs driven by THIS process (wraps
+    `psfmc_group`): walkers are split into contiguous blocks, one per listed device.
+    The one-process-per-GPU form (torch.distributed / RCCL) is `psfmc_amd.parallel`."""
+
+    def __init__(self, devices, sci, obs_var, bad_px, psfs, psf_vars, n_ps, n_sersic,
+                 max_walkers=4096, backend='fused'):
+        self._lib = load_library()
+        self._grp = None
+        sci, obs_var = _f64(sci), _f64(obs_var)
+        bad = np.ascontiguousarray(np.asarray(bad_px).astype(bool), dtype=np.uint8)
+        psfs, psf_vars = _f64(psfs), _f64(psf_vars)
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        handle = ctypes.c_void_p()
+        rc = self._lib.psfmc_group_create(
+            ctypes.byref(handle), len(devs), devs.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
+            sci.shape[0], sci.shape[1], _dp(sci), _dp(obs_var), bad.ctypes.data_as(_c_u8_p),
+            psfs.shape[0], psfs.shape[1], psfs.shape[2], _dp(psfs), _dp(psf_vars), int(n_ps),
+            int(n_sersic), int(max_walkers), BACKENDS[backend] if isinstance(backend, str) else int(backend))
+        self._check(rc)
+        self._grp = handle
+        self.devices = [int(d) for d in devs]
+        self.max_walkers = int(max_walkers)
+        self.row_len = ROW_SKY + ROW_PS * int(n_ps) + ROW_SERSIC * int(n_sersic) + 1
+        self.n_params = None
+
+    def _check(self, rc):
+        if rc != 0:
+            raise NativeError(rc, self._lib.psfmc_last_error().decode('utf-8', 'replace'))
+
+    def close(self):
+        if self._grp is not None:
+            self._lib.psfmc_group_destroy(self._grp)
+            self._grp = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_layout(self, n_sky, n_params, slot_col, slot_const, ps_method, sersic_degrees,
+                   mag_zeropoint, family, p0, p1, p2):
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        ipt = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+        slot_col, ps_method, sersic_degrees, family = map(i32, (slot_col, ps_method, sersic_degrees, family))
+        slot_const, p0, p1, p2 = map(_f64, (slot_const, p0, p1, p2))
+        self._check(self._lib.psfmc_group_set_layout(
+            self._grp, int(n_sky), int(n_params), ipt(slot_col), _dp(slot_const), ipt(ps_method),
+            ipt(sersic_degrees), float(mag_zeropoint), ipt(family), _dp(p0), _dp(p1), _dp(p2)))
+        self.n_params = int(n_params)
+
+    def loglike(self, rows, skip=None):
+        rows = _f64(rows)
+        if rows.ndim != 2 or rows.shape[1] != self.row_len:
+            raise ValueError('rows must be [W, {}]'.format(self.row_len))
+        out = np.empty(rows.shape[0])
+        skip_p = None
+        if skip is not None:
+            skip = np.ascontiguousarray(np.asarray(skip).astype(bool), dtype=np.uint8)
+            skip_p = skip.ctypes.data_as(_c_u8_p)
+        if len(rows):
+            self._check(self._lib.psfmc_group_eval_batch(self._grp, len(rows), _dp(rows), skip_p, _dp(out)))
+        return out
+
+    def logpost_theta(self, theta, extra_lnprior=None):
+        theta = _f64(theta)
+        if theta.ndim != 2 or theta.shape[1] != self.n_params:
+            raise ValueError('theta must be [W, {}]'.format(self.n_params))
+        out = np.empty(theta.shape[0])
+        extra = _f64(extra_lnprior) if extra_lnprior is not None else None
+        if len(theta):
+            self._check(self._lib.psfmc_group_eval_theta(self._grp, len(theta), _dp(theta),
+                                                         _dp(extra) if extra is not None else None, _dp(out)))
+        return out

@@ -52,8 +52,9 @@ class MultiComponentModel(object):
     (reference: models.py:9-61).
 
     device / backend / max_walkers configure the GPU context, which is created
-    on first use.  backend: 'fused' (hand-written FFT kernels; power-of-two sides
-    64...1024), 'hipfft' (any even size) or 'auto' (fused whenever the shape allows).
+    on first use.  backend: 'fused' (hand-written FFT kernels; sides from
+    `engine.FUSED_SIDES`: the powers of two 64...1024 and the even 5-smooth sides in
+    between), 'hipfft' (any even size) or 'auto' (fused whenever the shape allows).
     """
 
     def __init__(self, components, device=0, backend='auto', max_walkers=4096):
@@ -100,8 +101,7 @@ class MultiComponentModel(object):
         self._sersic = [c for c in components if isinstance(c, Sersic)]
         if backend == 'auto':
             ny, nx = config.obs_data.shape
-            pow2 = all(64 <= n <= 1024 and n & (n - 1) == 0 for n in (ny, nx))
-            backend = 'fused' if pow2 else 'hipfft'
+            backend = 'fused' if engine.fused_supports(ny, nx) else 'hipfft'
         self._device, self._backend = device, backend
         self._max_walkers = int(max_walkers)
         self._engine = None
@@ -171,6 +171,18 @@ class MultiComponentModel(object):
                        [SHIFT_METHODS[c.shift_method] for c in self._ps],
                        [int(bool(c.angle_degrees)) for c in self._sersic],
                        self.config.mag_zeropoint, family, p0, p1, p2)
+
+    def device_group(self, devices, max_walkers=None):
+        """A `engine.ContextGroup`: this model's field on several GPUs driven by this one
+        process, layout and priors registered (psfmc_group_*).  Its `logpost_theta(theta)`
+        splits the walkers over the devices.  The caller closes it."""
+        sel = self.config.psf_selector
+        grp = engine.ContextGroup(devices, self.config.obs_data, self.config.obs_var, self.config.bad_px,
+                                  np.stack(sel.psf_data), np.stack(sel.psf_var), n_ps=len(self._ps),
+                                  n_sersic=len(self._sersic), max_walkers=max_walkers or self._max_walkers,
+                                  backend=self._backend)
+        self._register_layout(grp)
+        return grp
 
     def _host_prior_sum(self, theta):
         """log-prior of the priors the library leaves to the host, or None."""

@@ -46,6 +46,23 @@ class RankGroup(object):
         backend = dist.get_backend(group) if self.active else 'none'
         self.host_staged = self.active and (backend != 'nccl' or self.device.type == 'cpu')
         self._index = {}
+        self._stream = None
+
+    def on_stream(self):
+        """Context manager: torch work and library launches of the sharded paths share ONE real
+        (non-NULL) HIP stream.  The library treats a NULL stream argument as "the context's own
+        stream", which is not ordered with torch's default stream."""
+        import contextlib
+        if self.device.type != 'cuda':
+            return contextlib.nullcontext()
+        if self._stream is None:
+            self._stream = self.torch.cuda.Stream(self.device)
+            self._stream.wait_stream(self.torch.cuda.current_stream(self.device))
+        return self.torch.cuda.stream(self._stream)
+
+    def stream_ptr(self):
+        """hipStream_t (int) of the stream `on_stream` selects; call inside `on_stream()`."""
+        return self.torch.cuda.current_stream(self.device).cuda_stream
 
     def block(self, n):
         return shard_bounds(n, self.world, self.rank)
@@ -133,16 +150,17 @@ class ShardedLogPosterior(object):
         torch = rg.torch
         n_w = theta.shape[0]
         lo, hi = rg.block(n_w)
-        send = torch.full((rg.slot(n_w),), float('nan'), dtype=torch.float64, device=rg.device)
-        if self.model is not None and not self.model._host_priors and hi > lo:
-            eng = self.model.engine
-            stream = torch.cuda.current_stream(rg.device).cuda_stream
-            out = []
-            for a in range(lo, hi, eng.max_walkers):            # larger blocks go through in slices
-                b = min(a + eng.max_walkers, hi)
-                th = torch.from_numpy(theta[a:b]).to(rg.device)
-                eng.logpost_theta_device(b - a, th.data_ptr(), 0, send[a - lo:].data_ptr(), stream)
-                out.append(th)                                  # keep alive until the gather is enqueued
-        elif hi > lo:
-            send[:hi - lo] = torch.from_numpy(np.ascontiguousarray(self.evaluate(theta[lo:hi]))).to(rg.device)
-        return rg.all_gather_blocks(send, n_w).cpu().numpy()
+        eng = self.model.engine if self.model is not None else None      # creates context + layout
+        with rg.on_stream():
+            send = torch.full((rg.slot(n_w),), float('nan'), dtype=torch.float64, device=rg.device)
+            if eng is not None and not self.model._host_priors and hi > lo:
+                stream = rg.stream_ptr()
+                keep = []
+                for a in range(lo, hi, eng.max_walkers):            # larger blocks go through in slices
+                    b = min(a + eng.max_walkers, hi)
+                    th = torch.from_numpy(theta[a:b]).to(rg.device)
+                    eng.logpost_theta_device(b - a, th.data_ptr(), 0, send[a - lo:].data_ptr(), stream)
+                    keep.append(th)                                 # alive until the gather is enqueued
+            elif hi > lo:
+                send[:hi - lo] = torch.from_numpy(np.ascontiguousarray(self.evaluate(theta[lo:hi]))).to(rg.device)
+            return rg.all_gather_blocks(send, n_w).cpu().numpy()

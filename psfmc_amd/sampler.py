@@ -318,8 +318,8 @@ class DeviceEnsembleSampler(EnsembleSampler):
         n_iter, half = int(np.shape(z)[0]), self.k // 2
         lo, hi = rg.block(half)
         a_lo, a_hi = rg.block(self.k)
-        with torch.cuda.device(rg.device):
-            stream = torch.cuda.current_stream(rg.device).cuda_stream
+        with torch.cuda.device(rg.device), rg.on_stream():
+            stream = rg.stream_ptr()
             send = torch.zeros(rg.slot(half), dtype=torch.float64, device=rg.device)
             eng.stretch_open(pos, lnprob, z, lz, partner, log_u, nacc, store=store)
             for it in range(n_iter):

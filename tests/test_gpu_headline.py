@@ -96,3 +96,27 @@ def test_config3_and_config4_share_at_full_batch(n_side, n_sersic, n_w):
     assert np.array_equal(small, got[slots[:16]])
     assert np.array_equal(model.log_posterior_batch(theta[slots[-3:]]), got[slots[-3:]])
     model.close()
+
+
+def test_device_group_splits_walkers_over_devices(tmp_path):
+    """psfmc_group_* (one process, several devices): with the one GPU of the test box listed
+    twice the walkers are split over two contexts; results equal the single context's bit for
+    bit, for the raw-vector and the derived-row entry points, ragged and tiny batches included."""
+    case = helpers.load_case('synth256')
+    model = helpers.build_model('synth256', case, tmp_path, backend='fused', max_walkers=128)
+    single = model.log_posterior_batch(case['params'])
+    assert helpers.rel_err(single, case['lnprob']) <= REF_TOL
+    grp = model.device_group([0, 0], max_walkers=128)
+    for n in (65, 64, 3, 1):
+        assert np.array_equal(grp.logpost_theta(case['params'][:n]), single[:n]), n
+    fin = np.isfinite(case['lnprior'])
+    rows = model.derived_rows(case['params'][fin])
+    assert np.array_equal(grp.loglike(rows), model.engine.loglike(rows))
+    skip = np.zeros(len(rows), dtype=bool)
+    skip[::3] = True
+    got = grp.loglike(rows, skip)
+    assert np.all(got[skip] == -np.inf) and np.array_equal(got[~skip], model.engine.loglike(rows)[~skip])
+    with pytest.raises(Exception):
+        grp.logpost_theta(np.tile(case['params'], (3, 1)))            # 195 > max_walkers
+    grp.close()
+    model.close()

@@ -12,9 +12,11 @@ import synth_field
 pytestmark = pytest.mark.gpu
 
 
-def random_case(seed):
+def random_case(seed, shape=None):
     rng = np.random.RandomState(seed)
     ny, nx = rng.choice([64, 128, 256]), rng.choice([64, 128, 256])
+    if shape is not None:
+        ny, nx = shape
     n_psf = rng.choice([1, 1, 2, 3])
     py, px = rng.choice([9, 16, 21, 32, 33]), rng.choice([9, 16, 21, 32, 33])
     psfs, pivms = [], []
@@ -111,3 +113,58 @@ def test_random_model_matches_oracle(seed):
                 tol = 1e-9 if kind == 'composite_ivm' else 1e-11
                 assert np.abs(dev[kind][0][fin] - ref[fin]).max() <= tol * scale, (seed, backend, kind)
         model.close()
+
+
+# every side the fused kernels are built for beyond the powers of two (psfmc_fft.h FftShape),
+# each once as the row length and once as the column length, in rectangular pairs that also mix
+# in power-of-two sides
+GENERAL_SIDES = [96, 100, 120, 144, 150, 160, 180, 192, 200, 240, 250, 288, 300, 320, 360, 384, 400, 480,
+                 500, 576, 600, 640, 720, 768, 800, 900, 960]
+
+
+def general_shapes():
+    from psfmc_amd import engine
+    n = len(GENERAL_SIDES)
+    shapes = [(GENERAL_SIDES[i], GENERAL_SIDES[(5 * i + 3) % n]) for i in range(n)]
+    shapes += [(200, 200), (300, 300), (500, 500), (256, 200), (200, 256), (96, 512), (1024, 120), (160, 64), (150, 96)]
+    assert all(engine.fused_supports(ny, nx) for ny, nx in shapes)
+    # the power-of-two row kernels take whole workgroups of rows only: such shapes (and any side
+    # with a prime factor > 5) go to the hipFFT back end under backend='auto'
+    assert not engine.fused_supports(150, 64) and not engine.fused_supports(140, 140)
+    return shapes
+
+
+@pytest.mark.parametrize('shape', general_shapes(), ids=lambda s: '%dx%d' % s)
+def test_general_sides_match_oracle(shape):
+    """Sides with factors 3 and 5 (real cut-outs are rarely 2^k) on the fused kernels: likelihood
+    and all five images against the fp64 oracle, and the two back ends against each other."""
+    seed = 1000 + shape[0] * 7 + shape[1]
+    case = random_case(seed, shape)
+    field = orc.make_field(case['sci'], case['ivm'], case['psfs'], case['pivms'], mask=case['mask'],
+                           mag_zp=case['zp'])
+    want, imgs = orc.evaluate(field, case['comps'], case['psf_index'], raw_dtype=np.float64,
+                              want_ps_sub=True)
+    want = want if np.isfinite(want) else -np.inf
+    n_free = 1 if len(case['psfs']) > 1 else 0
+    theta = np.full((3, n_free), float(case['psf_index']))
+    model = build(case, 'fused')
+    assert model._backend == 'fused'
+    got = model.log_likelihood_batch(theta)
+    assert got[0] == got[1] == got[2]
+    if np.isfinite(want):
+        assert abs(got[0] - want) <= 2e-10 * abs(want), (shape, got[0], want)
+        dev = model.sample_images(theta[:1])
+        for kind, ref in imgs.items():
+            fin = np.isfinite(ref)
+            assert np.array_equal(np.isfinite(dev[kind][0]), fin), (shape, kind)
+            scale = max(np.abs(ref[fin]).max(), 1e-300)
+            tol = 1e-9 if kind == 'composite_ivm' else 1e-11
+            assert np.abs(dev[kind][0][fin] - ref[fin]).max() <= tol * scale, (shape, kind)
+    else:
+        assert got[0] == -np.inf
+    # the device-computed PSF spectra of this shape against numpy
+    psf_spec, var_spec = model.engine.spectra()
+    for k in range(len(case['psfs'])):
+        assert np.abs(psf_spec[k] - field.psf_spec[k]).max() <= 1e-13 * np.abs(field.psf_spec[k]).max()
+        assert np.abs(var_spec[k] - field.var_spec[k]).max() <= 1e-13 * np.abs(field.var_spec[k]).max()
+    model.close()
