@@ -130,7 +130,7 @@ def kernel_profile(eng, args, one_batch, torch, dev, reps):
     t_bytes = 2 * nxh * n * 16                  # transposed half-spectra of one walker
     designed = {'rows_fwd': t_bytes, 'cols': 2 * t_bytes, 'rows_inv': t_bytes}
     names = {'rows_fwd': 'k_rows_fwd<%d, false>' % n, 'rows_inv': 'k_rows_inv<%d>' % n,
-             'cols': ('k_cols3<%d, true>' if n >= 512 else 'k_cols<%d, true>') % n}
+             'cols': ('k_cols3<%d, true>' if n in (512, 1024) else 'k_cols<%d, true>') % n}
     streams = eng.get_option('streams')
     eng.set_option('streams', 1)
     eng.set_option('profile', 1)

@@ -71,28 +71,31 @@ PSFMC_FFT_SHAPE(128, 16, 8)
 PSFMC_FFT_SHAPE(256, 16, 16)
 PSFMC_FFT_SHAPE(512, 32, 16)
 PSFMC_FFT_SHAPE(1024, 32, 32)
-// sides with factors 3 and 5 (any even side of this list runs on the fused kernels)
+// sides with factors 3 and 5 (any even side of this list runs on the fused kernels).  The
+// shapes keep R = max(P, ceil(P/T) T) small -- registers, hence waves per SIMD, are what the
+// memory-bound column kernel lives on -- at the price of a few idle lanes (T = 10, 15, 20, 30
+// use 60 of a wave's 64 lanes, T = 18 54, T = 24 48, T = 25 50) or idle stage-2 slots (P < T).
 PSFMC_FFT_SHAPE(96, 12, 8)
 PSFMC_FFT_SHAPE(100, 10, 10)
 PSFMC_FFT_SHAPE(120, 15, 8)
 PSFMC_FFT_SHAPE(144, 12, 12)
-PSFMC_FFT_SHAPE(150, 15, 10)
-PSFMC_FFT_SHAPE(160, 20, 8)
+PSFMC_FFT_SHAPE(150, 10, 15)
+PSFMC_FFT_SHAPE(160, 10, 16)
 PSFMC_FFT_SHAPE(180, 12, 15)
-PSFMC_FFT_SHAPE(192, 24, 8)
+PSFMC_FFT_SHAPE(192, 12, 16)
 PSFMC_FFT_SHAPE(200, 20, 10)
 PSFMC_FFT_SHAPE(240, 15, 16)
-PSFMC_FFT_SHAPE(250, 25, 10)
-PSFMC_FFT_SHAPE(288, 24, 12)
-PSFMC_FFT_SHAPE(300, 30, 10)
+PSFMC_FFT_SHAPE(250, 10, 25)
+PSFMC_FFT_SHAPE(288, 16, 18)
+PSFMC_FFT_SHAPE(300, 15, 20)
 PSFMC_FFT_SHAPE(320, 16, 20)
-PSFMC_FFT_SHAPE(360, 24, 15)
-PSFMC_FFT_SHAPE(384, 24, 16)
+PSFMC_FFT_SHAPE(360, 18, 20)
+PSFMC_FFT_SHAPE(384, 16, 24)
 PSFMC_FFT_SHAPE(400, 20, 20)
-PSFMC_FFT_SHAPE(480, 30, 16)
+PSFMC_FFT_SHAPE(480, 20, 24)
 PSFMC_FFT_SHAPE(500, 20, 25)
 PSFMC_FFT_SHAPE(576, 24, 24)
-PSFMC_FFT_SHAPE(600, 30, 20)
+PSFMC_FFT_SHAPE(600, 24, 25)
 PSFMC_FFT_SHAPE(640, 20, 32)
 PSFMC_FFT_SHAPE(720, 24, 30)
 PSFMC_FFT_SHAPE(768, 24, 32)

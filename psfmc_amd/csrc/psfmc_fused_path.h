@@ -71,7 +71,13 @@ template <int NY> constexpr size_t fused_col_lds_bytes() {
     return (size_t)(kColThreads / 64) * fused_col_wave_lds_doubles<NY>() * sizeof(double);
 }
 // waves per SIMD the register allocator must leave room for
-template <int N> constexpr int fused_min_waves() { return FftShape<N>::R > 16 ? 1 : 2; }
+#ifndef PSFMC_GEN_R_2WAVES
+#define PSFMC_GEN_R_2WAVES 16     /* general shapes with up to this many registers are compiled for 2 waves per SIMD
+                                     (20 spills: k_cols<300> 102 us instead of 77, k_cols<320> 88 instead of 53) */
+#endif
+template <int N> constexpr int fused_min_waves() {
+    return FftShape<N>::kPlain ? (FftShape<N>::R > 16 ? 1 : 2) : (FftShape<N>::R > PSFMC_GEN_R_2WAVES ? 1 : 2);
+}
 
 // Address = wave-uniform base (scalar registers) + 32-bit byte offset per lane: the form
 // global_load/store take directly (saddr + voffset).  64-bit per-lane pointer arithmetic was
@@ -324,7 +330,8 @@ k_cols(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restric
     // kernel-spectrum loads were consumed and fly during the inverse transform and the
     // stores (issued before the forward transform they made the multiply wait for them:
     // 56 us instead of 46; here 43 us).  The twiddles live in LDS to make room.
-    constexpr bool PF = PSFMC_COLS_PREFETCH && S::kPlain && R <= 16;
+    // (general shapes: only those compiled for one wave per SIMD have the registers for it)
+    constexpr bool PF = PSFMC_COLS_PREFETCH && (S::kPlain ? R <= 16 : (R > PSFMC_GEN_R_2WAVES && R <= 20));
     struct Slot {
         cd* base;
         int w, kx, c;

@@ -174,8 +174,9 @@ def test_degenerate_component_sets(backend):
 
 
 def test_hipfft_backend_handles_any_even_size_and_fused_refuses():
-    """Non-power-of-two (even) images: the hipFFT back end evaluates them, the fused one
-    says clearly that it cannot; odd sizes are rejected by the setup like in the reference."""
+    """Even sides with a prime factor above 5 (here 90 = 2 * 3^2 * 5 is fine as a number but is
+    not among the built sides): the hipFFT back end evaluates them, the fused one says clearly
+    that it cannot; odd sizes are rejected by the setup like in the reference."""
     from psfmc_amd import MultiComponentModel, engine
     from psfmc_amd.ModelComponents import Configuration, Sky, PointSource, Sersic
     rng = np.random.RandomState(12)
@@ -201,6 +202,6 @@ def test_hipfft_backend_handles_any_even_size_and_fused_refuses():
     model.close()
     with pytest.raises(engine.NativeError) as err:
         build('fused').log_likelihood_batch(np.zeros((1, 0)))
-    assert 'power-of-two' in str(err.value)
+    assert 'sides must be among' in str(err.value)
     with pytest.raises(ValueError):
         Configuration(sci[:99], ivm[:99], psf, pivm)
