@@ -559,9 +559,12 @@ extern "C" int psfmc_ctx_create(psfmc_ctx** out, int device, int ny, int nx, con
         // walkers per internal pass: the transposed half-spectra of one pass
         // (two passes in flight, together just under the 256 MiB Infinity Cache: measured
         // best at 256^2 -- 104..120 walkers; 136 and more fall off -- see DESIGN.md)
+        // Never rounded UP past that budget: 32 walkers at 512^2 (2 x 135 MB) ran 6 % slower than
+        // 24, 16 at 1024^2 8 % slower than 6 (gpurun_out r2i sweep).
         const double per_walker = 2.0 * c->nxh * c->nyp * 16.0;
-        int chunk = ((int)(112.0 * 1048576.0 / per_walker) + 8) & ~15;
-        if (chunk < 16) chunk = 16;
+        const int fit = (int)(112.0 * 1048576.0 / per_walker);
+        int chunk = fit >= 64 ? ((fit + 4) & ~7) : fit >= 16 ? (fit & ~7) : (fit & ~1);
+        if (chunk < 4) chunk = 4;
         c->chunk = chunk;
     } else {
         c->nblk = (c->S + 1023) / 1024;
