@@ -10,7 +10,7 @@
 // striding.  Either way consecutive lanes touch consecutive addresses in global loads/stores.
 // Decimation in frequency, two stages with ONE exchange through LDS:
 //   stage 1  radix-P DFT over a in registers, then the twiddle W_N^(t*c)
-//   exchange y[t][c] -> LDS rows of P+1 complex (the +1 keeps ds_write_b128 of
+//   exchange y[t][c] -> LDS rows of P|1 doubles (an odd stride keeps the writes of
 //            the T lanes on distinct banks; reads are contiguous across lanes);
 //            wave-local, so there is no workgroup barrier anywhere in a transform
 //   stage 2  P/T radix-T DFTs over the T lanes' values, in registers
@@ -62,6 +62,8 @@ template <int N> struct FftShape;
         static constexpr int H = (P_ + T_ - 1) / T_;        /* stage-2 transforms per lane */       \
         static constexpr int R = H * T_;                    /* registers (complex) per lane, >= P */ \
         static constexpr int TPW = 64 / T_;                 /* transforms per wave */               \
+        static constexpr int LS = P_ | 1;                   /* LDS row stride (doubles): odd, so that the \
+                                                               T lanes of an exchange hit distinct banks */  \
         static constexpr bool kExact = (P_ % T_ == 0);      /* k = t + T e on exit */               \
         static constexpr bool kFull = (TPW * T_ == 64);     /* every lane of a wave works */        \
         static constexpr bool kPlain = kExact && kFull;     /* the power-of-two shapes */           \
@@ -115,7 +117,7 @@ template <int N> __device__ __forceinline__ constexpr bool fft_slot_valid(int t,
 }
 
 // LDS doubles one transform needs for its exchange (one component at a time)
-template <int N> constexpr int fft_lds_elems() { return FftShape<N>::T * (FftShape<N>::P + 1); }
+template <int N> constexpr int fft_lds_elems() { return FftShape<N>::T * FftShape<N>::LS; }
 
 // cos(2 pi k / 32), k = 0..8
 __device__ constexpr double kCos32[9] = {
@@ -383,7 +385,7 @@ __device__ __forceinline__ void fft_wave(cd (&v)[FftShape<N>::R], const cd* w /*
         else wc = table[t * c];
         v[c] = cmul(v[c], SIGN < 0 ? wc : cconj(wc));
     }
-    double* row = xbuf + t * (P + 1);
+    double* row = xbuf + t * S::LS;
     // lane t's stage-2 transforms work on c = t + T h; a c >= P (only when T does not divide P)
     // reads a valid column instead and its results are never used
     int col[H];
@@ -398,7 +400,7 @@ __device__ __forceinline__ void fft_wave(cd (&v)[FftShape<N>::R], const cd* w /*
 #pragma unroll
     for (int h = 0; h < H; ++h)
 #pragma unroll
-        for (int b = 0; b < T; ++b) z[h][b].x = xbuf[b * (P + 1) + col[h]];
+        for (int b = 0; b < T; ++b) z[h][b].x = xbuf[b * S::LS + col[h]];
     wave_lds_sync();
     if (S::kFull || active) {
 #pragma unroll
@@ -408,7 +410,7 @@ __device__ __forceinline__ void fft_wave(cd (&v)[FftShape<N>::R], const cd* w /*
 #pragma unroll
     for (int h = 0; h < H; ++h)
 #pragma unroll
-        for (int b = 0; b < T; ++b) z[h][b].y = xbuf[b * (P + 1) + col[h]];
+        for (int b = 0; b < T; ++b) z[h][b].y = xbuf[b * S::LS + col[h]];
     wave_lds_sync();
 #pragma unroll
     for (int h = 0; h < H; ++h) {

@@ -52,8 +52,19 @@ template <int NX> constexpr int row_group() { return FftShape<NX>::TPW; }       
 template <int NX> constexpr int layout_rg_log2() {
     return FftShape<NX>::kPlain ? __builtin_ctz(FftShape<NX>::TPW) : 2;
 }
+// General shapes: a wave's RG rows need not be a whole number of the layout's 4-row groups
+// (RG = 6 for T = 10, 3 for T = 20, 5 for T = 12): as many consecutive waves as make one (12 or
+// 20 rows) share a workgroup, so that the second touch of a straddled cache line comes from the
+// same CU at about the same time (k_rows_inv<300> fetched 1.39x its bytes with one wave per
+// workgroup, profiles/r2b_pmc_300_*).
+#ifndef PSFMC_GEN_ROW_WAVES
+#define PSFMC_GEN_ROW_WAVES 1
+#endif
 template <int NX> constexpr int row_waves() {
-    return PSFMC_ROW_WAVES ? PSFMC_ROW_WAVES : (row_group<NX>() >= 4 ? 1 : 4);
+    if (PSFMC_ROW_WAVES) return PSFMC_ROW_WAVES;
+    if (FftShape<NX>::kPlain) return row_group<NX>() >= 4 ? 1 : 4;
+    constexpr int rg = row_group<NX>();
+    return !PSFMC_GEN_ROW_WAVES ? 1 : (rg % 4 == 0 ? 1 : rg % 2 == 0 ? 2 : 4);
 }
 template <int NX> constexpr int row_threads() { return 64 * row_waves<NX>(); }
 // per wave: the exchange regions of its RG transforms, then its twiddle table

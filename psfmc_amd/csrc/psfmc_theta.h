@@ -274,24 +274,53 @@ k_theta_prep(ThetaLayout G, const double* __restrict__ theta,
     double* row_tile = th_tile + (size_t)kThetaThreads * P;
     double* peak_tile = row_tile + (size_t)kThetaThreads * rlen;       // [component][walker]
     const int tid = threadIdx.y * kThetaThreads + threadIdx.x, nthr = kThetaThreads * blockDim.y;
-    // the four int tables and the four double tables are contiguous in the blob
-    for (int i = tid; i < ns + G.n_ps + G.n_sersic + P; i += nthr) li[i] = G.slot_col[i];
-    for (int i = tid; i < n_dbl; i += nthr) ld[i] = G.slot_const[i];
+    // The four int tables and the four double tables are contiguous in the blob.  The layout
+    // tables and the parameter tile are independent: every thread first ISSUES its (first) load
+    // of each, then stores them to LDS -- one memory round trip instead of three in a row (the
+    // kernel is a chain of latencies: 16 us for a 128-walker half-step whatever the batch).
+    const int n_tab_i = ns + G.n_ps + G.n_sersic + P;
     const int w0 = blockIdx.x * kThetaThreads;
     const int n_here = W - w0 < kThetaThreads ? W - w0 : kThetaThreads;
+    const int n_tile = n_here * P;
+    int first_i = 0;
+    double first_d = 0.0, first_t = 0.0;
+    if (tid < n_tab_i) first_i = G.slot_col[tid];
+    if (tid < n_dbl) first_d = G.slot_const[tid];
+    size_t soff = 0;
+    double s_own = 0.0, c_other = 0.0, zz = 0.0;
     if (sp.pos) {                                                   // propose into the tile
         const int it = sp.d_iter ? *sp.d_iter : sp.it;
-        const size_t off = ((size_t)it * 2 + sp.h) * sp.half;
-        for (int i = tid; i < n_here * P; i += nthr) {
+        soff = ((size_t)it * 2 + sp.h) * sp.half;
+        if (tid < n_tile) {
+            const int lw = tid / P, d = tid - lw * P, w = w0 + lw;
+            s_own = sp.pos[(size_t)(sp.h * sp.half + w) * P + d];
+            c_other = sp.pos[(size_t)((1 - sp.h) * sp.half + sp.partner[soff + w]) * P + d];
+            zz = sp.z[soff + w];
+        }
+    } else if (tid < n_tile) {
+        first_t = theta[(size_t)w0 * P + tid];
+    }
+    if (tid < n_tab_i) li[tid] = first_i;
+    if (tid < n_dbl) ld[tid] = first_d;
+    for (int i = tid + nthr; i < n_tab_i; i += nthr) li[i] = G.slot_col[i];
+    for (int i = tid + nthr; i < n_dbl; i += nthr) ld[i] = G.slot_const[i];
+    if (sp.pos) {
+        if (tid < n_tile) {
+            const double q = stretch_point(s_own, c_other, zz);
+            th_tile[tid] = q;
+            sp.q[(size_t)w0 * P + tid] = q;
+        }
+        for (int i = tid + nthr; i < n_tile; i += nthr) {
             const int lw = i / P, d = i - lw * P, w = w0 + lw;
             const double s = sp.pos[(size_t)(sp.h * sp.half + w) * P + d];
-            const double c = sp.pos[(size_t)((1 - sp.h) * sp.half + sp.partner[off + w]) * P + d];
-            const double q = stretch_point(s, c, sp.z[off + w]);
+            const double c = sp.pos[(size_t)((1 - sp.h) * sp.half + sp.partner[soff + w]) * P + d];
+            const double q = stretch_point(s, c, sp.z[soff + w]);
             th_tile[i] = q;
             sp.q[(size_t)w0 * P + i] = q;
         }
     } else {
-        for (int i = tid; i < n_here * P; i += nthr)                // coalesced tile load
+        if (tid < n_tile) th_tile[tid] = first_t;
+        for (int i = tid + nthr; i < n_tile; i += nthr)             // coalesced tile load
             th_tile[i] = theta[(size_t)w0 * P + i];
     }
     __syncthreads();

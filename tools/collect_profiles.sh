@@ -2,7 +2,7 @@
 # Collect the round's rocprofv3 evidence on the GPU box and stage the summaries for
 # profiles/ (run through gpurun; results come back under gpurun_out/profiles_new and are
 # copied into profiles/ by hand).
-# usage: tools/collect_profiles.sh <round tag, e.g. r2> [configs: any of 256 512 1024, default all]
+# usage: tools/collect_profiles.sh <round tag, e.g. r2> [configs: any of 256 512 1024 200 300, default the first three]
 # Configs (BASELINE.json / SURVEY.md section 8(d)):
 #   256   headline: 256^2, 1 PS + 1 Sersic, 4096 walkers per batch
 #   512   config 3: 512^2, 1 PS + 2 Sersic, 1024 walkers
@@ -18,8 +18,10 @@ cp $R/profiles/pmc_traffic.json $OUT/pmc_traffic.json 2>/dev/null || true
 for N in $CONFIGS; do
   case $N in
     256)  ARGS="--size 256 --sersic 1 --walkers 4096"; CH=128 ;;
-    512)  ARGS="--size 512 --sersic 2 --walkers 1024"; CH=32 ;;
-    1024) ARGS="--size 1024 --sersic 4 --walkers 256"; CH=16 ;;
+    512)  ARGS="--size 512 --sersic 2 --walkers 1024"; CH=24 ;;
+    1024) ARGS="--size 1024 --sersic 4 --walkers 256"; CH=6 ;;
+    200)  ARGS="--size 200 --sersic 1 --walkers 4096"; CH=184 ;;
+    300)  ARGS="--size 300 --sersic 1 --walkers 2048"; CH=80 ;;
     *) echo "unknown config $N"; exit 1 ;;
   esac
   COMMON="$ARGS --no-cpu --no-example --no-extras"
@@ -34,7 +36,7 @@ for N in $CONFIGS; do
   # (3) PMC passes (own runs, no trace domains), one pass in flight, CH walkers per launch
   cd $R
   tools/prof_pmc.sh ${TAG}_pmc_$N $COMMON --batches 1 --opt streams=1 --chunk $CH > $OUT/${TAG}_pmc_${N}_summary.txt 2>&1
-  for n in sq1 sq2 fetch write; do cp gpurun_out/${TAG}_pmc_$N/$n/*/*counter_collection.csv $OUT/${TAG}_pmc_${N}_${n}_counter_collection.csv; done
+  for n in sq1 sq2 fetch write rdreq wrreq; do cp gpurun_out/${TAG}_pmc_$N/$n/*/*counter_collection.csv $OUT/${TAG}_pmc_${N}_${n}_counter_collection.csv 2>/dev/null || true; done
   python3 tools/pmc_to_json.py gpurun_out/${TAG}_pmc_$N $N $CH $OUT/pmc_traffic.json > /dev/null
   echo "config $N done"
 done
@@ -46,6 +48,8 @@ for N in $CONFIGS; do
     256)  python3 bench.py > $OUT/${TAG}_bench.json 2>$OUT/${TAG}_bench.err ;;
     512)  python3 bench.py --size 512 --sersic 2 --walkers 1024 --no-example --cpu-seconds 6 > $OUT/${TAG}_bench_512.json 2>$OUT/${TAG}_bench_512.err ;;
     1024) python3 bench.py --size 1024 --sersic 4 --walkers 256 --no-example --cpu-seconds 6 --cpu-procs 0 > $OUT/${TAG}_bench_1024.json 2>$OUT/${TAG}_bench_1024.err ;;
+    200)  python3 bench.py --size 200 --sersic 1 --walkers 4096 --no-example --cpu-seconds 6 --cpu-procs 0 > $OUT/${TAG}_bench_200.json 2>$OUT/${TAG}_bench_200.err ;;
+    300)  python3 bench.py --size 300 --sersic 1 --walkers 2048 --no-example --cpu-seconds 6 --cpu-procs 0 > $OUT/${TAG}_bench_300.json 2>$OUT/${TAG}_bench_300.err ;;
   esac
 done
 tail -c 600 $OUT/${TAG}_bench*.json

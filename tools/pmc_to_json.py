@@ -27,8 +27,17 @@ def per_kernel(name, counter):
     return {k: agg[k] / cnt[k] for k in agg}
 
 
+def optional(name, counter):
+    try:
+        return per_kernel(name, counter)
+    except (IndexError, IOError, OSError):
+        return {}
+
+
 fetch = per_kernel('fetch', 'FETCH_SIZE')
 write = per_kernel('write', 'WRITE_SIZE')
+rd = {c: optional('rdreq', 'TCC_EA0_RDREQ' + c + '_sum') for c in ('', '_32B', '_64B', '_128B')}
+wr = {c: optional('wrreq', 'TCC_EA0_WRREQ' + c + '_sum') for c in ('', '_64B')}
 table = {}
 for k in sorted(set(fetch) | set(write)):
     if not any(s in k for s in ('k_rows_fwd<%d, false' % side, 'k_cols<%d, true' % side,
@@ -38,6 +47,19 @@ for k in sorted(set(fetch) | set(write)):
     table[k] = {'FETCH_SIZE_KiB_per_launch': f_kib, 'WRITE_SIZE_KiB_per_launch': w_kib,
                 'walkers_per_launch': walkers,
                 'hbm_bytes_per_walker': (2.0 * f_kib + w_kib) * 1024.0 / walkers}
+    if k in rd['']:
+        # exact request sizes (cross-check of the x2 rule): requests not tallied as 32- / 64- /
+        # 128-byte ones are taken as 64-byte
+        n, n32, n64, n128 = (rd[c].get(k, 0.0) for c in ('', '_32B', '_64B', '_128B'))
+        other = max(n - n32 - n64 - n128, 0.0) if (n64 or n128) else 0.0
+        rbytes = 32 * n32 + 64 * (n64 + other) + 128 * n128 if (n64 or n128) else None
+        table[k]['read_requests_per_launch'] = {'all': n, '32B': n32, '64B': n64, '128B': n128}
+        if rbytes is not None:
+            table[k]['exact_read_bytes_per_walker'] = rbytes / walkers
+    if k in wr['']:
+        nw, nw64 = wr[''].get(k, 0.0), wr['_64B'].get(k, 0.0)
+        table[k]['write_requests_per_launch'] = {'all': nw, '64B': nw64}
+        table[k]['exact_write_bytes_per_walker'] = (64 * nw64 + 32 * max(nw - nw64, 0.0)) / walkers
 try:
     full = json.load(open(out))
 except (IOError, ValueError):

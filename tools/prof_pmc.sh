@@ -16,9 +16,13 @@ run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INS
 run sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS
 run fetch FETCH_SIZE
 run write WRITE_SIZE
+# request-size breakdown at the L2's memory side: an exact byte count to set beside the
+# guide's FETCH_SIZE x 2 rule (which assumes every read request is a 128-B one)
+run rdreq TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum
+run wrreq TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum
 python3 - <<PY
 import csv, glob, collections
-for name in ['sq1','sq2','fetch','write']:
+for name in ['sq1','sq2','fetch','write','rdreq','wrreq']:
     files = glob.glob('$OUT/%s/*/*counter_collection.csv' % name)
     if not files: print(name, 'no output'); continue
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
