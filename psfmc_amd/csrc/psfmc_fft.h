@@ -54,6 +54,16 @@ __device__ __forceinline__ cd load_stream(const cd* p) {
 #endif
 }
 
+// LDS row stride (doubles) of a shape's exchange: odd, so that the T lanes writing one register
+// hit distinct banks, and with T (stride - 1) a multiple of 32 where that costs at most half as
+// much LDS again, so that the transforms sharing a wave (region = T * stride doubles apart) do
+// not collide on the reads either (k_cols<300>: two thirds of its LDS cycles were conflicts).
+constexpr int fft_lds_stride(int P, int T) {
+    for (int ls = P | 1; ls <= P + P / 2 + 8; ls += 2)
+        if ((T * (ls - 1)) % 32 == 0) return ls;
+    return P | 1;
+}
+
 template <int N> struct FftShape;
 #define PSFMC_FFT_SHAPE(N_, P_, T_)                                                                 \
     template <> struct FftShape<N_> {                                                               \
@@ -62,8 +72,7 @@ template <int N> struct FftShape;
         static constexpr int H = (P_ + T_ - 1) / T_;        /* stage-2 transforms per lane */       \
         static constexpr int R = H * T_;                    /* registers (complex) per lane, >= P */ \
         static constexpr int TPW = 64 / T_;                 /* transforms per wave */               \
-        static constexpr int LS = P_ | 1;                   /* LDS row stride (doubles): odd, so that the \
-                                                               T lanes of an exchange hit distinct banks */  \
+        static constexpr int LS = fft_lds_stride(P_, T_);   /* LDS row stride (doubles) */          \
         static constexpr bool kExact = (P_ % T_ == 0);      /* k = t + T e on exit */               \
         static constexpr bool kFull = (TPW * T_ == 64);     /* every lane of a wave works */        \
         static constexpr bool kPlain = kExact && kFull;     /* the power-of-two shapes */           \

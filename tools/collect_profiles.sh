@@ -53,3 +53,13 @@ for N in $CONFIGS; do
   esac
 done
 tail -c 600 $OUT/${TAG}_bench*.json
+# BASELINE config 5's per-GPU share (8 independent 256^2 fields x 256 walkers each), the
+# small-ensemble timeline and the device-resident sampler's trace
+python3 bench.py --fields 8 --walkers 256 --no-cpu --no-example > $OUT/${TAG}_bench_fields8.json 2>/dev/null || true
+cd /tmp
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_small -o small -- python3 $R/tools/trace_small.py > /dev/null 2>&1 || true
+python3 $R/tools/trace_small.py --analyse $R/gpurun_out/${TAG}_small/small_kernel_trace.csv > $OUT/${TAG}_small_ensemble_timeline.txt 2>&1 || true
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_sampler -o s256 -- python3 $R/tests/profile_sampler.py 256 300 > $OUT/${TAG}_sampler_256.txt 2>/dev/null || true
+cp $R/gpurun_out/${TAG}_sampler/s256_kernel_stats.csv $OUT/${TAG}_sampler_256_kernel_stats.csv 2>/dev/null || true
+cd $R
+cat $OUT/${TAG}_small_ensemble_timeline.txt
