@@ -123,6 +123,15 @@ def test_device_sampler_reproduces_host_sampler(tmp_path):
     more_h = list(host.sample(out_h[-1][0], lnprob0=out_h[-1][1], iterations=6, thin=2))
     more_d = list(dev.sample(out_d[-1][0], lnprob0=out_d[-1][1], iterations=6, thin=2))
     assert dev.chain.shape == (40, 28, model.num_params) and np.array_equal(dev.chain, host.chain)
+    # resuming from ANY yielded (pos, lnprob, rstate) continues the same chain, although the
+    # device sampler draws the next block's random numbers ahead of time
+    for stop in (3, 7, 10):                       # inside a block, at a block edge, in the next
+        pos, lnp, rstate = out_d[stop - 1]
+        again = DeviceEnsembleSampler(40, model, block=7)
+        list(again.sample(pos, lnprob0=lnp, rstate0=rstate, iterations=25 - stop))
+        assert np.array_equal(again.chain, host.chain[:, stop:25]), stop
+        rstate_h = out_h[stop - 1][2]             # (the host loop yields its arrays by reference)
+        assert all(np.array_equal(a, b) for a, b in zip(rstate, rstate_h))
     # replaying one captured iteration as a hipGraph (option "graph") gives the same chain
     model.engine.set_option('graph', 1)
     launches = model.engine.get_option('graph_launches')
