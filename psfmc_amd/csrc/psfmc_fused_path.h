@@ -111,9 +111,16 @@ __device__ __forceinline__ int t_elem(int y, int c, int rg_log2) {
     const int rg = 1 << rg_log2;
     return (((y >> rg_log2) * 2 + c) << rg_log2) + (y & (rg - 1));
 }
-// column length of the layout: ny rounded up to a whole number of row groups
+// column length of the layout: ny rounded up to a whole number of row groups.  (PSFMC_T_PAD=1 adds
+// a spare group where the distance between kx columns would be a multiple of 4 KB -- tried against
+// the 1.42x fetch of k_rows_inv<1024>, where a row wave touches 32 kx columns 32 KB apart per
+// instruction: no change at 256^2, 512^2 or 1024^2, so it is not a set-conflict effect; off.)
+#ifndef PSFMC_T_PAD
+#define PSFMC_T_PAD 0
+#endif
 __host__ __device__ __forceinline__ int t_col_len(int ny, int rg_log2) {
-    return ((ny + (1 << rg_log2) - 1) >> rg_log2) << rg_log2;
+    const int len = ((ny + (1 << rg_log2) - 1) >> rg_log2) << rg_log2;
+    return (PSFMC_T_PAD && (len & 127) == 0) ? len + (1 << rg_log2) : len;
 }
 
 // packed, pre-permuted field arrays for rows_inv: pix[(yg*P + e)*64 + lane] =
@@ -311,7 +318,7 @@ k_cols(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restric
     constexpr int TM = PSFMC_TW_MODE_COLS;
     cd tw[TwRegs<NY, TM>::value];
     load_twiddles<NY, TM>(tw, twy, t, twl, lane);
-    const int nyp = S::kPlain ? NY : t_col_len(NY, rg_log2);         // column length of the layout
+    const int nyp = t_col_len(NY, rg_log2);                          // column length of the layout
     const int rg_mask = (1 << rg_log2) - 1;
     const int n_cols = n_w * 2 * nxh;
     const int n_groups = (n_cols + FPB - 1) / FPB;
@@ -468,6 +475,7 @@ k_cols3(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restri
     const int rg = 1 << rg_log2;
     const int e0 = t_elem(t, 0, rg_log2);              // offset of y = t; y = 64 a + t adds 128 a
     const int n_cols = n_w * 2 * nxh;
+    const int nyp = t_col_len(NY, rg_log2);
     const GroupRange gr = xcd_group_range((n_cols + WPB - 1) / WPB);
     for (int grp = gr.first; grp < gr.end; grp += gr.step) {
         const int col = grp * WPB + wave;
@@ -475,7 +483,7 @@ k_cols3(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restri
         const int pr = col >> 1, c = col & 1;           // kx * n_w + walker, component
         const int kx = pr / n_w, w = pr - kx * n_w;
         if (skip && skip[w]) continue;                   // wave-uniform
-        cd* base = Tbuf + ((size_t)w * nxh + kx) * 2 * NY + c * rg + e0;
+        cd* base = Tbuf + ((size_t)w * nxh + kx) * 2 * nyp + c * rg + e0;
         cd v[R1];
 #pragma unroll
         for (int a = 0; a < R1; ++a) v[a] = base[128 * a];
