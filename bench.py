@@ -348,8 +348,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--walkers', type=int, default=4096, help='walkers per batch (per GPU)')
     ap.add_argument('--batches', type=int, default=0,
-                    help='batches per step (0: enough for ~26 ms per step, so that the default 20 '
-                         'steps time >= 0.5 s: 8 at 256^2 x 4096 walkers)')
+                    help='batches per step (0: enough for ~31 ms per step, so that the default 20 '
+                         'steps time >= 0.6 s: 10 at 256^2 x 4096 walkers)')
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--sersic', type=int, default=1)
     ap.add_argument('--backend', default=os.environ.get('PSFMC_BACKEND', 'fused'))
@@ -381,8 +381,8 @@ def main():
                          'run plain `python bench.py --gpus N`)' % (args.gpus, world, args.gpus))
     if args.batches <= 0:
         # ~3.3 ms per 4096-walker batch at 256^2 on one MI355X; scale by the bytes of a walker
-        per_batch_ms = 3.3 * (args.walkers / 4096.0) * (args.size / 256.0) ** 2 * max(args.fields, 1)
-        args.batches = max(1, min(64, int(np.ceil(26.0 / per_batch_ms))))
+        per_batch_ms = 3.1 * (args.walkers / 4096.0) * (args.size / 256.0) ** 2 * max(args.fields, 1)
+        args.batches = max(1, min(64, int(np.ceil(31.0 / per_batch_ms))))
     # the all-cores CPU baseline runs first, in child processes, before this process
     # touches the GPU (rank 0, N = 1 only)
     multi = None

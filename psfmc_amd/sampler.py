@@ -332,6 +332,32 @@ class DeviceEnsembleSampler(EnsembleSampler):
             torch.cuda.current_stream(rg.device).synchronize()
             return eng.stretch_close(nacc, stream)
 
+    def _state_snapshotter(self):
+        """A cheap `get_state()` for the per-iteration snapshots: `RandomState.get_state` costs
+        ~50 us (it would double the host time per iteration); the MT19937 key and position are
+        copied straight from the bit generator's state block (1 us), the Gaussian cache -- which
+        `rand` / `randint` never touch -- is taken from one full call.  Falls back to `get_state`
+        if the bit generator does not expose its state the expected way."""
+        rs = self._random
+        full = rs.get_state()
+        try:
+            import ctypes
+            bg = rs._bit_generator
+            if type(bg).__name__ != 'MT19937':
+                return rs.get_state
+            block = (ctypes.c_uint32 * 625).from_address(bg.ctypes.state_address)
+            view = np.frombuffer(block, dtype=np.uint32)
+            if not (np.array_equal(view[:624], full[1]) and int(view[624]) == full[2]):
+                return rs.get_state
+        except Exception:
+            return rs.get_state
+        tail = tuple(full[3:])
+
+        def snap():
+            a = view.copy()
+            return ('MT19937', a[:624], int(a[624])) + tail
+        return snap
+
     def _draw(self, n_iter):
         """Random numbers of n_iter iterations in emcee's order (per half-step:
         rand(Ns) -> z, randint(Nc, Ns) -> partner, rand(Ns) -> ln u)."""
@@ -340,12 +366,13 @@ class DeviceEnsembleSampler(EnsembleSampler):
         partner = np.empty((n_iter, 2, half), dtype=np.int32)
         log_u = np.empty((n_iter, 2, half))
         states = []                     # generator state after each iteration's draws
+        snap = self._state_snapshotter()
         for it in range(n_iter):
             for h in range(2):
                 z[it, h] = ((self.a - 1.0) * self._random.rand(half) + 1) ** 2.0 / self.a
                 partner[it, h] = self._random.randint(half, size=(half,))
                 log_u[it, h] = np.log(self._random.rand(half))
-            states.append(self._random.get_state())
+            states.append(snap())
         return (z, (self.dim - 1.0) * np.log(z), partner, log_u), states
 
     def sample(self, p0, lnprob0=None, rstate0=None, blobs0=None, iterations=1, thin=1,
