@@ -424,12 +424,14 @@ class DeviceEnsembleSampler(EnsembleSampler):
             # per-block bookkeeping in whole-array operations: at a few hundred microseconds
             # per iteration on the GPU, per-iteration numpy calls here were 10 % of the run
             if storechain:
-                kept = np.arange(done, done + n)
-                kept = kept[kept % thin == 0]
-                if len(kept):
-                    ind = i0 + kept // thin
-                    self._chain[:, ind, :] = chain[:, kept - done, :]
-                    self._lnprob[:, ind] = lnchain[:, kept - done]
+                # kept iterations of this block: (done + i) % thin == 0 -- an arithmetic
+                # progression, copied with slices (index arrays made this 1.6 ms per block)
+                first = (-done) % thin
+                if first < n:
+                    count = (n - first + thin - 1) // thin
+                    dst = i0 + (done + first) // thin
+                    self._chain[:, dst:dst + count, :] = chain[:, first::thin, :]
+                    self._lnprob[:, dst:dst + count] = lnchain[:, first::thin]
             # counters advance with the block (the device reports acceptances per block), so
             # `acceptance_fraction` is consistent whenever the consumer looks; the yielded
             # generator state is the one right after iteration j's draws, so that
