@@ -23,3 +23,17 @@ for n_w in (64, 256):
     print('%4d walkers: draw(64) %.2f ms, stretch_run(64 iterations) %.2f ms = %.3f ms/iter, sample(640) %.3f ms/iter'
           % (n_w, t_draw * 1e3, min(ts) * 1e3, min(ts) * 1e3 / 64, t_all * 1e3 / 640))
     m.close()
+
+# where the host time of sample() goes (256 walkers)
+import cProfile, pstats
+m = helpers.build_model('synth256', case, tempfile.mkdtemp(), max_walkers=256)
+np.random.seed(1)
+p0 = m.init_params_from_priors(256)
+s = DeviceEnsembleSampler(256, m, block=64)
+lnp = m.log_posterior_batch(p0)
+list(s.sample(p0, lnprob0=lnp, iterations=64))
+pr = cProfile.Profile(); pr.enable()
+list(s.sample(p0, lnprob0=lnp, iterations=640))
+pr.disable()
+pstats.Stats(pr).sort_stats('cumulative').print_stats(14)
+m.close()
