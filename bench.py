@@ -38,6 +38,9 @@ import time
 
 import numpy as np
 
+# the host driver only supports dmabuf IPC: RCCL needs this before the HIP runtime starts
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, 'tools')):
     if p not in sys.path:

@@ -166,6 +166,25 @@ def test_native_errors_are_reported(models):
         model.engine.set_option('no_such_option', 1)
 
 
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_caller_rows_with_a_wild_psf_index_are_clamped(models, backend):
+    """The last column of a caller row indexes the kernel spectra on the device; the public
+    row entry points round and clamp it to [0, n_psf) instead of reading out of bounds
+    (the raw-vector path never gets there: an index outside the prior's support is -inf)."""
+    case, model = models('edge', backend)                    # two PSFs
+    fin = np.flatnonzero(np.isfinite(case['lnprior']))[:6]
+    rows = model.derived_rows(case['params'][fin])
+    base = {k: model.engine.loglike(np.column_stack([rows[:, :-1], np.full(len(rows), float(k))]))
+            for k in (0, 1)}
+    assert not np.array_equal(base[0], base[1])
+    for wild, want in ((7.0, 1), (1e300, 1), (-3.0, 0), (np.nan, 0), (0.4, 0), (0.6, 1), (np.inf, 1)):
+        r = rows.copy()
+        r[:, -1] = wild
+        assert np.array_equal(model.engine.loglike(r), base[want]), wild
+        imgs = model.engine.images(r[:1], ('convolved_model',))
+        assert np.isfinite(imgs['convolved_model']).all()
+
+
 def test_device_math():
     """The rasteriser's hand-written fp64 log2 / exp2 / reciprocals vs numpy."""
     from psfmc_amd import engine
