@@ -4,10 +4,11 @@ brightness modelling.  Public names mirror the reference package `psfMC`.
 """
 from .models import MultiComponentModel
 from .batch import BatchLogPosterior
-from .sampler import EnsembleSampler
+from .sampler import EnsembleSampler, DeviceEnsembleSampler
+from .parallel import RankGroup, ShardedLogPosterior
 from .fitting import model_galaxy_mcmc
 from .database import load_database
 
 __version__ = '0.1.0'
-__all__ = ['MultiComponentModel', 'BatchLogPosterior', 'EnsembleSampler', 'model_galaxy_mcmc',
-           'load_database']
+__all__ = ['MultiComponentModel', 'BatchLogPosterior', 'EnsembleSampler', 'DeviceEnsembleSampler',
+           'RankGroup', 'ShardedLogPosterior', 'model_galaxy_mcmc', 'load_database']
