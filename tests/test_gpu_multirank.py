@@ -18,7 +18,7 @@ import synth_field
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-N_WALK, N_ITER = 48, 5
+N_ITER = 5
 
 WORKER = r'''
 import os, sys
@@ -37,7 +37,7 @@ case = helpers.load_case('synth256')
 work = os.path.join(out, 'w%d' % rank)
 os.makedirs(work)
 model = helpers.build_model('synth256', case, work, backend='fused', max_walkers=128)
-# (a) sharded evaluation of the golden vectors (65 walkers over 2 ranks: blocks of 33 and 32)
+# (a) sharded evaluation of the golden vectors (65 walkers: uneven blocks)
 sharded = ShardedLogPosterior(model)
 lnp = sharded(case['params'])
 np.save(os.path.join(out, 'lnp%d.npy' % rank), lnp)
@@ -68,7 +68,8 @@ dist.destroy_process_group()
 '''
 
 
-def test_two_ranks_reproduce_one_rank(tmp_path):
+@pytest.mark.parametrize('world,N_WALK', [(2, 48), (3, 40)])      # 40 walkers on 3 ranks: blocks of 7, 7, 6
+def test_ranks_reproduce_one_rank(tmp_path, world, N_WALK):
     from psfmc_amd import model_galaxy_mcmc, fits_io
     from psfmc_amd.database import load_database
     from psfmc_amd.sampler import DeviceEnsembleSampler
@@ -81,14 +82,15 @@ def test_two_ranks_reproduce_one_rank(tmp_path):
         port = s.getsockname()[1]
     env = dict(os.environ, OMP_NUM_THREADS='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     subprocess.check_call(
-        [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+        [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % world,
          '--master-addr', '127.0.0.1', '--master-port', str(port), str(script), ROOT, str(out)],
         env=env, timeout=600)
 
     case = helpers.load_case('synth256')
     # (a) gathered log-posteriors: identical on both ranks, equal to the reference's
-    l0, l1 = np.load(out / 'lnp0.npy'), np.load(out / 'lnp1.npy')
-    assert np.array_equal(l0, l1)
+    l0 = np.load(out / 'lnp0.npy')
+    for r in range(1, world):
+        assert np.array_equal(l0, np.load(out / ('lnp%d.npy' % r)))
     assert helpers.rel_err(l0, case['lnprob']) <= 1e-6
     single = tmp_path / 'single'
     single.mkdir()
@@ -100,16 +102,18 @@ def test_two_ranks_reproduce_one_rank(tmp_path):
     samp.random_state = np.random.RandomState(123).get_state()
     for _ in samp.sample(p0, iterations=N_ITER):
         pass
-    for r in (0, 1):
+    for r in range(world):
         assert np.array_equal(np.load(out / ('chain%d.npy' % r)), samp.chain), r
         assert np.array_equal(np.load(out / ('lnchain%d.npy' % r)), samp.lnprobability), r
         assert np.array_equal(np.load(out / ('nacc%d.npy' % r)), samp.naccepted), r
     assert samp.naccepted.sum() > 0
     post = model.collect_posterior_images()
-    for r in (0, 1):
+    from psfmc_amd.parallel import shard_bounds
+    for r in range(world):
         got = np.load(out / ('post%d.npz' % r))
         assert int(got['count']) == N_WALK * N_ITER == model.accumulated_samples
-        assert int(got['own']) == N_WALK * N_ITER // 2          # each rank summed its half of the walkers
+        lo, hi = shard_bounds(N_WALK, world, r)
+        assert int(got['own']) == (hi - lo) * N_ITER            # each rank summed its block of the walkers
         for kind, img in post.items():
             scale = np.abs(img[np.isfinite(img)]).max()
             assert np.abs(got[kind] - img).max() <= 1e-12 * scale, (r, kind)
@@ -121,7 +125,8 @@ def test_two_ranks_reproduce_one_rank(tmp_path):
                               random_state=5, quiet=True, write_fits=('convolved_model',), group=None)
     m.close()
     ref = np.asarray(db['lnprobability'])
-    assert np.array_equal(np.load(out / 'dbln0.npy'), ref) and np.array_equal(np.load(out / 'dbln1.npy'), ref)
+    for r in range(world):
+        assert np.array_equal(np.load(out / ('dbln%d.npy' % r)), ref), r
     two = load_database(str(out / 'mcmc' / 'run_db.fits'))
     for name in db.colnames:
         assert np.array_equal(two[name], db[name]), name
