@@ -41,6 +41,12 @@ namespace psfmc {
 #define PSFMC_ROW_WAVES 0          /* 0 = choose per shape */
 #endif
 constexpr int kColThreads = 256;     // column kernel: 4 waves, persistent
+#ifndef PSFMC_COLS_PRIO
+#define PSFMC_COLS_PRIO 3     /* measured: 512^2 +1.7 %, 1024^2 +0.8 %, 256^2 unchanged */
+#endif
+#ifndef PSFMC_INV_PRIO
+#define PSFMC_INV_PRIO 0
+#endif
 #ifndef PSFMC_COLS_PREFETCH
 #define PSFMC_COLS_PREFETCH 1         /* register double-buffering of the column loads */
 #endif
@@ -307,6 +313,11 @@ k_cols(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restric
     constexpr int P = S::P, T = S::T, R = S::R, TPW = S::TPW;
     constexpr int FPB = col_ffts_per_block<NY>();
     extern __shared__ __align__(16) double smem[];
+#if PSFMC_COLS_PRIO
+    // the memory-bound kernel's waves go first where they share a SIMD with the VALU-bound row
+    // waves of the other in-flight pass: their loads and stores get out sooner
+    __builtin_amdgcn_s_setprio(PSFMC_COLS_PRIO);
+#endif
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fl = lane / T, t = lane % T;
     const bool slot_on = S::kFull || fl < TPW;                       // not an idle tail lane
@@ -461,6 +472,9 @@ k_cols3(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restri
     constexpr int R1 = Fft3Shape<NY>::R1;
     constexpr int WPB = kColThreads / 64;
     extern __shared__ __align__(16) double smem[];
+#if PSFMC_COLS_PRIO
+    __builtin_amdgcn_s_setprio(PSFMC_COLS_PRIO);
+#endif
     const int t = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double* lds = smem + (size_t)wave * fft3_lds_doubles<NY>();
     cd w1[fft3_w1_regs<NY>()], w2[8];
@@ -527,6 +541,9 @@ k_rows_inv(const cd* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
     constexpr int NXH = NX / 2 + 1;
     constexpr int RGL2 = layout_rg_log2<NX>(), RGL = 1 << RGL2;
     extern __shared__ __align__(16) double smem[];
+#if PSFMC_INV_PRIO
+    __builtin_amdgcn_s_setprio(PSFMC_INV_PRIO);
+#endif
 
     const int w = blockIdx.y;
     if (skip && skip[w]) return;
