@@ -529,6 +529,30 @@ def main():
                 model.log_posterior_batch(theta)
             line['host_path_evals_per_s'] = args.walkers * 5 / (time.perf_counter() - t0)
             line['small_ensembles'] = small_ensembles(eng, args, torch, dev, theta_dev[0], out[0], stream)
+            if args.backend == 'fused' and args.size in (64, 128, 256, 512, 1024):
+                # opt-in storage mode, NOT the headline: complex64 half-spectra between the kernels,
+                # fp64 arithmetic (include/psfmc_hip.h "storage_f32")
+                ref64 = out[0].cpu().numpy()
+                eng.set_option('storage_f32', 1)
+                for _ in range(2):
+                    one_batch()
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    one_batch()
+                torch.cuda.synchronize(dev)
+                rate = args.walkers * 10 / (time.perf_counter() - t0)
+                got32 = out[0].cpu().numpy()
+                fin = np.isfinite(ref64)
+                line['storage_f32_option'] = {
+                    'evals_per_s': rate, 'max_rel_diff_vs_f64': float(np.max(np.abs(got32[fin] - ref64[fin]) /
+                                                                             np.abs(ref64[fin]))),
+                    'max_abs_diff_vs_f64': float(np.max(np.abs(got32[fin] - ref64[fin]))),
+                    'note': 'opt-in: complex64 storage of the intermediate half-spectra, fp64 arithmetic; '
+                            'not an fp64 result and not the headline'}
+                eng.set_option('storage_f32', 0)
+                one_batch()
+                torch.cuda.synchronize(dev)
         if world == 1 and not args.no_example:
             ex = example_model_rate()
             if ex:

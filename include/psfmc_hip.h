@@ -267,7 +267,11 @@ int psfmc_get_spectra(psfmc_ctx* ctx, double* psf_spec, double* var_spec);
 
 /* tuning knobs: "chunk_walkers" (walkers per internal pass), "streams" (passes in
  * flight, 1..4), "cols_grid", "profile" (1: time every kernel with HIP events; read
- * back with get_option "prof_ms_rows_fwd" / "prof_n_rows_fwd", ..._cols, ..._rows_inv) */
+ * back with get_option "prof_ms_rows_fwd" / "prof_n_rows_fwd", ..._cols, ..._rows_inv).
+ * "storage_f32" (0 / 1, default 0): keep the fused path's intermediate half-spectra as
+ * complex64 while every operation stays fp64 -- half the memory traffic; the log-posterior is
+ * then good to ~1e-7 relative, the class of the reference's own float32 raw-model accumulator
+ * (psfMC/models.py:249), not an fp64 result.  Power-of-two sides, fused back end only. */
 int psfmc_set_option(psfmc_ctx* ctx, const char* key, double value);
 double psfmc_get_option(const psfmc_ctx* ctx, const char* key);
 

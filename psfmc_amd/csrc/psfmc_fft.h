@@ -44,6 +44,18 @@ __device__ __forceinline__ cd cconj(cd a) { return cd{a.x, -a.y}; }
 #ifndef PSFMC_NT_LOADS
 #define PSFMC_NT_LOADS 0      /* measured: hurts k_rows_inv (its mirrored re-reads want the cache), neutral elsewhere */
 #endif
+// Optional single-precision STORAGE of the intermediate half-spectra (arithmetic stays fp64):
+// a T element as two floats.  Converts implicitly on store, explicitly on load.
+struct cf {
+    float x, y;
+    cf() = default;
+    __device__ __forceinline__ cf(cd v) : x((float)v.x), y((float)v.y) {}
+};
+__device__ __forceinline__ cd load_stream(const cf* p) {
+    const cf v = *p;
+    return cd{(double)v.x, (double)v.y};
+}
+
 typedef double psfmc_v2d __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ cd load_stream(const cd* p) {
 #if PSFMC_NT_LOADS

@@ -92,8 +92,16 @@ template <int NY> constexpr size_t fused_col_lds_bytes() {
 #define PSFMC_GEN_R_2WAVES 16     /* general shapes with up to this many registers are compiled for 2 waves per SIMD
                                      (20 spills: k_cols<300> 102 us instead of 77, k_cols<320> 88 instead of 53) */
 #endif
+#ifndef PSFMC_PLAIN_COL_WAVES
+#define PSFMC_PLAIN_COL_WAVES 2
+#endif
 template <int N> constexpr int fused_min_waves() {
     return FftShape<N>::kPlain ? (FftShape<N>::R > 16 ? 1 : 2) : (FftShape<N>::R > PSFMC_GEN_R_2WAVES ? 1 : 2);
+}
+// the column kernel's own bound (experiments: more waves per SIMD instead of the register
+// double-buffering)
+template <int N> constexpr int fused_col_min_waves() {
+    return (FftShape<N>::kPlain && FftShape<N>::R <= 16) ? PSFMC_PLAIN_COL_WAVES : fused_min_waves<N>();
 }
 
 // Address = wave-uniform base (scalar registers) + 32-bit byte offset per lane: the form
@@ -165,10 +173,10 @@ __global__ void k_pack_field(const double* __restrict__ sci, const double* __res
 //   FROM_IMAGE = true : z = img0 + i img_scale[w] img1 from memory (PSF spectra at setup)
 // raw_out (optional): [n][ny][nx] copy of the raw model (psfmc_eval_images)
 // ---------------------------------------------------------------------------
-template <int NX, bool FROM_IMAGE>
+template <int NX, bool FROM_IMAGE, typename TS = cd>
 __global__ void __launch_bounds__(row_threads<NX>(), fused_min_waves<NX>())
 k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
-           const cd* __restrict__ twx, cd* __restrict__ Tbuf, int n_ps, int n_sersic, int ny,
+           const cd* __restrict__ twx, TS* __restrict__ Tbuf, int n_ps, int n_sersic, int ny,
            int ps_only, const double* __restrict__ img, const double* __restrict__ img_scale,
            double* __restrict__ raw_out) {
     using S = FftShape<NX>;
@@ -220,8 +228,9 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
     fft_wave<NX, -1>(v, tw, twx, t, xbuf, twl, lane_on);
 
     cd* ubuf = reinterpret_cast<cd*>(xbuf);
-    cd* wbase = Tbuf + (size_t)w * 2 * NXH * nyp;                    // wave-uniform
-    const unsigned kstride = 2u * (unsigned)nyp * kCd;               // bytes between kx columns
+    TS* wbase = Tbuf + (size_t)w * 2 * NXH * nyp;                    // wave-uniform
+    constexpr unsigned kEl = sizeof(TS);                             // bytes of a T element
+    const unsigned kstride = 2u * (unsigned)nyp * kEl;               // bytes between kx columns
     if constexpr (S::kPlain) {
         // Untangle.  Lane t holds Z[k], k = t + T e.  Z[NX - k] is held by lane
         // (T - t) % T at e' = P-1-e (t != 0) or P-e (t == 0), i.e. in the upper half of
@@ -232,13 +241,13 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
         wave_lds_sync();
         const int tm = (T - t) % T;
         const int shift = t ? P - 1 : P;
-        const unsigned off0 = (unsigned)t_elem(iy, 0, RGL2) * kCd + (unsigned)t * kstride;
+        const unsigned off0 = (unsigned)t_elem(iy, 0, RGL2) * kEl + (unsigned)t * kstride;
 #pragma unroll
         for (int e = 0; e < P / 2; ++e) {
             const cd zk = v[e];
             cd zm = (e == 0 && t == 0) ? zk                       // k = 0 is its own mirror
                                        : ubuf[(shift - e - P / 2) * T + tm];
-            cd* o = at_bytes(wbase, off0 + (unsigned)(T * e) * kstride);
+            TS* o = at_bytes(wbase, off0 + (unsigned)(T * e) * kstride);
             // TWICE the spectra of raw and of mu raw^2: the 1/2 of the untangling is a power of
             // two and rides on the kernel spectra (k_scale_kernel_spectrum), bit for bit the same
             o[0] = cd{zk.x + zm.x, zk.y - zm.y};
@@ -246,7 +255,7 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
         }
         if (t == 0) {                                           // Nyquist column, its own mirror
             const cd z = v[P / 2];
-            cd* o = at_bytes(wbase, off0 + (unsigned)(NX / 2) * kstride);
+            TS* o = at_bytes(wbase, off0 + (unsigned)(NX / 2) * kstride);
             o[0] = cd{z.x + z.x, 0.0};
             o[RGL] = cd{z.y + z.y, 0.0};
         }
@@ -261,14 +270,14 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
             if (lane_on && fft_slot_valid<NX>(t, e) && 2 * k > NX) ubuf[NX - k] = v[e];
         }
         wave_lds_sync();
-        const unsigned off_row = (unsigned)t_elem(row_on ? iy : 0, 0, RGL2) * kCd;
+        const unsigned off_row = (unsigned)t_elem(row_on ? iy : 0, 0, RGL2) * kEl;
 #pragma unroll
         for (int e = 0; e < R; ++e) {
             const int k = fft_k_of<NX>(t, e);
             if (row_on && fft_slot_valid<NX>(t, e) && 2 * k <= NX) {
                 const cd zk = v[e];
                 const cd zm = (k == 0 || 2 * k == NX) ? zk : ubuf[k];
-                cd* o = at_bytes(wbase, off_row + (unsigned)k * kstride);
+                TS* o = at_bytes(wbase, off_row + (unsigned)k * kstride);
                 o[0] = cd{zk.x + zm.x, zk.y - zm.y};
                 o[RGL] = cd{zk.y + zm.y, zm.x - zk.x};
             }
@@ -304,9 +313,9 @@ __device__ __forceinline__ GroupRange xcd_group_range(int n_groups) {
 //   CONVOLVE = true : FFT_y, * Kt[psf][kx][c][.], IFFT_y (the hot path)
 //   CONVOLVE = false: FFT_y only (PSF spectra at setup)
 // ---------------------------------------------------------------------------
-template <int NY, bool CONVOLVE>
-__global__ void __launch_bounds__(kColThreads, fused_min_waves<NY>())
-k_cols(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restrict__ prep,
+template <int NY, bool CONVOLVE, typename TS = cd>
+__global__ void __launch_bounds__(kColThreads, fused_col_min_waves<NY>())
+k_cols(TS* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restrict__ prep,
        const uint8_t* __restrict__ skip, const cd* __restrict__ twy, int plen, int nxh, int n_w,
        int rg_log2) {
     using S = FftShape<NY>;
@@ -340,7 +349,7 @@ k_cols(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restric
     // masked.  Zero-filling their registers instead cost 32 moves per group in every lane.
     // Returns the column's base: element (y, c) sits at base[2 y - (y & rg_mask)] (t_elem with
     // the component's offset folded into the base).
-    auto locate = [&](int grp, int& w, int& kx, int& c, bool& active) -> cd* {
+    auto locate = [&](int grp, int& w, int& kx, int& c, bool& active) -> TS* {
         int col = grp * FPB + s;
         active = slot_on && col < n_cols;
         col = col < n_cols ? col : n_cols - 1;
@@ -362,14 +371,14 @@ k_cols(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restric
     // (general shapes: only those compiled for one wave per SIMD have the registers for it)
     constexpr bool PF = PSFMC_COLS_PREFETCH && (S::kPlain ? R <= 16 : (R > PSFMC_GEN_R_2WAVES && R <= 20));
     struct Slot {
-        cd* base;
+        TS* base;
         int w, kx, c;
         bool active;
     };
     auto load_group = [&](int grp, cd (&dst)[R], Slot& sl) {
         sl.base = locate(grp, sl.w, sl.kx, sl.c, sl.active);
         if constexpr (S::kPlain) {
-            const cd* b0 = sl.base + row_off(t);
+            const TS* b0 = sl.base + row_off(t);
 #pragma unroll
             for (int a = 0; a < P; ++a) dst[a] = load_stream(b0 + 2 * T * a);
         } else {
@@ -407,7 +416,7 @@ k_cols(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restric
         }
         if (sl.active) {
             if constexpr (S::kPlain) {
-                cd* b0 = sl.base + row_off(t);
+                TS* b0 = sl.base + row_off(t);
 #pragma unroll
                 for (int e = 0; e < R; ++e) b0[2 * T * e] = v[e];
             } else {
@@ -464,9 +473,9 @@ template <int NY> constexpr size_t fused_col3_lds_bytes() {
 #ifndef PSFMC_COLS3_WAVES
 #define PSFMC_COLS3_WAVES 2     /* measured at 1024 (before the shared LDS twiddle table: 150 us now): 1 or 2 -> 178 us, 3 -> 273 us, 4 -> 374 us (spills) */
 #endif
-template <int NY, bool CONVOLVE>
+template <int NY, bool CONVOLVE, typename TS = cd>
 __global__ void __launch_bounds__(kColThreads, Fft3Shape<NY>::R1 > 8 ? PSFMC_COLS3_WAVES : 2)
-k_cols3(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restrict__ prep,
+k_cols3(TS* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restrict__ prep,
         const uint8_t* __restrict__ skip, const cd* __restrict__ twy, int plen, int nxh, int n_w,
         int rg_log2) {
     constexpr int R1 = Fft3Shape<NY>::R1;
@@ -497,10 +506,10 @@ k_cols3(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restri
         const int pr = col >> 1, c = col & 1;           // kx * n_w + walker, component
         const int kx = pr / n_w, w = pr - kx * n_w;
         if (skip && skip[w]) continue;                   // wave-uniform
-        cd* base = Tbuf + ((size_t)w * nxh + kx) * 2 * nyp + c * rg + e0;
+        TS* base = Tbuf + ((size_t)w * nxh + kx) * 2 * nyp + c * rg + e0;
         cd v[R1];
 #pragma unroll
-        for (int a = 0; a < R1; ++a) v[a] = base[128 * a];
+        for (int a = 0; a < R1; ++a) v[a] = load_stream(base + 128 * a);
         fft_wave3<NY, -1>(v, w1, w2, twy, t, lds, w1s);
         if constexpr (CONVOLVE) {
             // keep the kernel-spectrum loads (and the next column's) out of the transform's
@@ -530,9 +539,9 @@ k_cols3(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restri
 // partial[w][yg] = sum over the wave's good pixels of the chi^2 term.
 // conv_out / var_out (optional): [n][ny][nx] images (psfmc_eval_images)
 // ---------------------------------------------------------------------------
-template <int NX>
+template <int NX, typename TS = cd>
 __global__ void __launch_bounds__(row_threads<NX>(), fused_min_waves<NX>())
-k_rows_inv(const cd* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const cd* __restrict__ twx,
+k_rows_inv(const TS* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const cd* __restrict__ twx,
            const FieldPx* __restrict__ field, double* __restrict__ partial, int ny,
            const double* __restrict__ prep, int plen,
            double* __restrict__ conv_out, double* __restrict__ var_out) {
@@ -558,8 +567,9 @@ k_rows_inv(const cd* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
     const bool row_on = S::kPlain || (lane_on && iy < ny);
     const int nyp = t_col_len(ny, RGL2);
     const int nyg = S::kPlain ? (int)gridDim.x * row_waves<NX>() : (ny + RG - 1) / RG;
-    const cd* wbase = Tbuf + (size_t)w * 2 * NXH * nyp;             // wave-uniform
-    const unsigned kstride = 2u * (unsigned)nyp * kCd;               // bytes between kx columns
+    const TS* wbase = Tbuf + (size_t)w * 2 * NXH * nyp;             // wave-uniform
+    constexpr unsigned kEl = sizeof(TS);                             // bytes of a T element
+    const unsigned kstride = 2u * (unsigned)nyp * kEl;               // bytes between kx columns
 
     // Y[k], k = T a + t:  k <= NX/2: G[k] + i H[k];  else conj(G[NX-k]) + i conj(H[NX-k]).
     // Every (G, H) pair is loaded once, by the lane that owns k <= NX/2; that lane also
@@ -573,16 +583,16 @@ k_rows_inv(const cd* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
     if constexpr (S::kPlain) {
         // the owner of NX - k is lane (T - t) % T at a' = P-1-a (t != 0) or P-a (t == 0);
         // mbuf is [P/2][T] complex
-        const unsigned off0 = (unsigned)t_elem(iy, 0, RGL2) * kCd + (unsigned)t * kstride;
+        const unsigned off0 = (unsigned)t_elem(iy, 0, RGL2) * kEl + (unsigned)t * kstride;
 #pragma unroll
         for (int a = 0; a < P / 2; ++a) {
-            const cd* p = at_bytes(wbase, off0 + (unsigned)(T * a) * kstride);
+            const TS* p = at_bytes(wbase, off0 + (unsigned)(T * a) * kstride);
             const cd g = load_stream(p), h = load_stream(p + RGL);
             v[a] = cd{g.x - h.y, g.y + h.x};
             mbuf[a * T + t] = cd{g.x + h.y, h.x - g.y};
         }
         {   // Nyquist column k = NX/2 (lane 0 only); the other lanes take a mirror for a = P/2
-            const cd* p = at_bytes(wbase, off0 + (unsigned)(NX / 2) * kstride);   // t == 0: kx = NX/2
+            const TS* p = at_bytes(wbase, off0 + (unsigned)(NX / 2) * kstride);   // t == 0: kx = NX/2
             cd g = cd{0.0, 0.0}, h = cd{0.0, 0.0};
             if (t == 0) { g = load_stream(p); h = load_stream(p + RGL); }
             v[P / 2] = cd{g.x - h.y, g.y + h.x};
@@ -600,7 +610,7 @@ k_rows_inv(const cd* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
     } else {
         // general shapes: the mirror of k goes to LDS slot k (0 < k < NX/2), the owner of
         // k' > NX/2 reads slot NX - k'
-        const unsigned off_row = (unsigned)t_elem(row_on ? iy : 0, 0, RGL2) * kCd;
+        const unsigned off_row = (unsigned)t_elem(row_on ? iy : 0, 0, RGL2) * kEl;
 #pragma unroll
         for (int a = 0; a < P; ++a) {
             const int k = T * a + t;
@@ -608,7 +618,7 @@ k_rows_inv(const cd* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
                 const bool low = 2 * k <= NX;
                 cd g = cd{0.0, 0.0}, h = cd{0.0, 0.0};
                 if (low && row_on) {
-                    const cd* p = at_bytes(wbase, off_row + (unsigned)k * kstride);
+                    const TS* p = at_bytes(wbase, off_row + (unsigned)k * kstride);
                     g = load_stream(p);
                     h = load_stream(p + RGL);
                 }

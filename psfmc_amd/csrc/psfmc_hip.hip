@@ -134,6 +134,8 @@ struct psfmc_ctx {
     hipStream_t side[kMaxStreams] = {nullptr, nullptr, nullptr, nullptr};   // side[0] unused
     hipEvent_t ev_fork = nullptr, ev_join[kMaxStreams] = {nullptr, nullptr, nullptr, nullptr};
     int n_streams = 2;
+    bool t_f32 = false;       // T stored as complex64 (set_option "storage_f32"); arithmetic stays fp64
+    bool plain_shape = false; // both sides power-of-two shapes (what storage_f32 is built for)
     bool cols3 = true;        // ny >= 512: column kernel on the wave-wide three-stage engine
     bool use_graph = false;   // psfmc_stretch_run replays a captured iteration (set_option "graph"; measured: no gain,
                               // the iteration is kernel-time- not launch-bound)
@@ -224,9 +226,22 @@ static int alloc_work(psfmc_ctx* c) {
     c->single_cap = 2 * c->chunk < c->max_walkers ? 2 * c->chunk : c->max_walkers;
     if (c->single_cap < c->chunk) c->single_cap = c->chunk;
     for (int i = 0; i < c->n_streams; ++i)
-        HIP_TRY(hipMalloc(&c->d_Ts[i], (size_t)(i ? c->chunk : c->single_cap) * 2 * c->nxh * c->nyp * sizeof(cd)));
+        HIP_TRY(hipMalloc(&c->d_Ts[i], (size_t)(i ? c->chunk : c->single_cap) * 2 * c->nxh * c->nyp *
+                                           (c->t_f32 ? sizeof(cf) : sizeof(cd))));
     c->d_T = c->d_Ts[0];
     return PSFMC_OK;
+}
+
+// Walkers per internal pass of the fused path: the transposed half-spectra of one pass
+// (two passes in flight, together just under the 256 MiB Infinity Cache: measured
+// best at 256^2 -- 104..120 walkers; 136 and more fall off -- see DESIGN.md).
+// Never rounded UP past that budget: 32 walkers at 512^2 (2 x 135 MB) ran 6 % slower than
+// 24, 16 at 1024^2 8 % slower than 6 (gpurun_out r2i sweep).
+static int fused_pass_walkers(const psfmc_ctx* c) {
+    const double per_walker = 2.0 * c->nxh * c->nyp * (c->t_f32 ? 8.0 : 16.0);
+    const int fit = (int)(112.0 * 1048576.0 / per_walker);
+    int chunk = fit >= 64 ? ((fit + 4) & ~7) : fit >= 16 ? (fit & ~7) : (fit & ~1);
+    return chunk < 4 ? 4 : chunk;
 }
 
 static bool fused_side(int n) {
@@ -247,28 +262,41 @@ static int row_shape_for(int nx, RowShape* out) {
 // ---------------------------------------------------------------------------
 // fused path launchers
 // ---------------------------------------------------------------------------
-template <int NX, bool FROM_IMAGE>
-static int launch_rows_fwd(psfmc_ctx* c, int n, const double* prep, const uint8_t* skip, cd* Tbuf,
+// TS = the T element type: cd (complex128) or cf (complex64 STORAGE, set_option "storage_f32";
+// built for the power-of-two shapes only)
+template <int N, typename TS> constexpr bool storage_built() { return sizeof(TS) == sizeof(cd) || FftShape<N>::kPlain; }
+
+template <int NX, bool FROM_IMAGE, typename TS = cd>
+static int launch_rows_fwd(psfmc_ctx* c, int n, const double* prep, const uint8_t* skip, void* Tvoid,
                            int ps_only, const double* img, const double* img_scale, double* raw_out,
                            hipStream_t st) {
+  if constexpr (!storage_built<NX, TS>()) {
+    return fail(PSFMC_EINVAL, "single-precision storage is built for power-of-two sides only");
+  } else {
+    TS* Tbuf = static_cast<TS*>(Tvoid);
     constexpr size_t lds = fused_row_lds_bytes<NX>();
     if constexpr (lds > 64 * 1024) {
         static thread_local int attr_device = -1;
         if (attr_device != c->device) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows_fwd<NX, FROM_IMAGE>),
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows_fwd<NX, FROM_IMAGE, TS>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_device = c->device;
         }
     }
-    hipLaunchKernelGGL((k_rows_fwd<NX, FROM_IMAGE>), dim3((c->nblk + row_waves<NX>() - 1) / row_waves<NX>(), n),
+    hipLaunchKernelGGL((k_rows_fwd<NX, FROM_IMAGE, TS>), dim3((c->nblk + row_waves<NX>() - 1) / row_waves<NX>(), n),
                        dim3(row_threads<NX>()), lds, st, prep, skip, c->d_twx, Tbuf, c->n_ps, c->n_sersic,
                        c->ny, ps_only, img, img_scale, raw_out);
     return PSFMC_OK;
+  }
 }
 
-template <int NY, bool CONVOLVE>
-static int launch_cols(psfmc_ctx* c, cd* Tbuf, int n_w, const double* prep, const uint8_t* skip,
+template <int NY, bool CONVOLVE, typename TS = cd>
+static int launch_cols(psfmc_ctx* c, void* Tvoid, int n_w, const double* prep, const uint8_t* skip,
                        hipStream_t st) {
+  if constexpr (!storage_built<NY, TS>()) {
+    return fail(PSFMC_EINVAL, "single-precision storage is built for power-of-two sides only");
+  } else {
+    TS* Tbuf = static_cast<TS*>(Tvoid);
     const int n_cols = n_w * 2 * c->nxh;
     if constexpr (NY == 512 || NY == 1024) {          // long power-of-two columns: wave-wide three-stage engine
         if (c->cols3) {
@@ -276,7 +304,7 @@ static int launch_cols(psfmc_ctx* c, cd* Tbuf, int n_w, const double* prep, cons
             const int per_block = kColThreads / 64;
             const int blocks = (n_cols + per_block - 1) / per_block;
             const int grid3 = blocks < 4 * c->cols_grid ? blocks : 4 * c->cols_grid;
-            hipLaunchKernelGGL((k_cols3<NY, CONVOLVE>), dim3(grid3), dim3(kColThreads), lds3, st, Tbuf,
+            hipLaunchKernelGGL((k_cols3<NY, CONVOLVE, TS>), dim3(grid3), dim3(kColThreads), lds3, st, Tbuf,
                                c->d_Kt, prep, skip, c->d_twy, c->plen, c->nxh, n_w, c->rg_log2);
             return PSFMC_OK;
         }
@@ -284,33 +312,39 @@ static int launch_cols(psfmc_ctx* c, cd* Tbuf, int n_w, const double* prep, cons
     constexpr size_t lds = fused_col_lds_bytes<NY>();
     static thread_local int attr_device = -1;          // raise the dynamic-LDS limit once per device
     if (attr_device != c->device) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cols<NY, CONVOLVE>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cols<NY, CONVOLVE, TS>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_device = c->device;
     }
     const int groups = (n_cols + col_ffts_per_block<NY>() - 1) / col_ffts_per_block<NY>();
     const int grid = groups < c->cols_grid ? groups : c->cols_grid;
-    hipLaunchKernelGGL((k_cols<NY, CONVOLVE>), dim3(grid), dim3(kColThreads), lds, st, Tbuf, c->d_Kt,
+    hipLaunchKernelGGL((k_cols<NY, CONVOLVE, TS>), dim3(grid), dim3(kColThreads), lds, st, Tbuf, c->d_Kt,
                        prep, skip, c->d_twy, c->plen, c->nxh, n_w, c->rg_log2);
     return PSFMC_OK;
+  }
 }
 
-template <int NX>
-static int launch_rows_inv(psfmc_ctx* c, int n, const cd* Tbuf, const double* prep, const uint8_t* skip,
+template <int NX, typename TS = cd>
+static int launch_rows_inv(psfmc_ctx* c, int n, const void* Tvoid, const double* prep, const uint8_t* skip,
                            double* partial, double* conv_out, double* var_out, hipStream_t st) {
+  if constexpr (!storage_built<NX, TS>()) {
+    return fail(PSFMC_EINVAL, "single-precision storage is built for power-of-two sides only");
+  } else {
+    const TS* Tbuf = static_cast<const TS*>(Tvoid);
     constexpr size_t lds = fused_row_lds_bytes<NX>();
     if constexpr (lds > 64 * 1024) {
         static thread_local int attr_device = -1;
         if (attr_device != c->device) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows_inv<NX>),
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows_inv<NX, TS>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_device = c->device;
         }
     }
-    hipLaunchKernelGGL((k_rows_inv<NX>), dim3((c->nblk + row_waves<NX>() - 1) / row_waves<NX>(), n), dim3(row_threads<NX>()), lds, st,
+    hipLaunchKernelGGL((k_rows_inv<NX, TS>), dim3((c->nblk + row_waves<NX>() - 1) / row_waves<NX>(), n), dim3(row_threads<NX>()), lds, st,
                        Tbuf, skip, c->d_twx, c->d_field, partial, c->ny, prep, c->plen, conv_out,
                        var_out);
     return PSFMC_OK;
+  }
 }
 
 template <int NX> static int pack_field(psfmc_ctx* c) {
@@ -354,18 +388,31 @@ static int fused_forward(psfmc_ctx* c, int n, cd* Tbuf, const double* prep, cons
                          int ps_only, double* raw_out, hipStream_t st) {
     {
         ProfScope ps(c, PROF_ROWS_FWD, st);
-        DISPATCH_LEN(c->nx, RC_TRY((launch_rows_fwd<N_, false>(c, n, prep, skip, Tbuf, ps_only, nullptr,
-                                                               nullptr, raw_out, st))));
+        if (c->t_f32) {
+            DISPATCH_LEN(c->nx, RC_TRY((launch_rows_fwd<N_, false, cf>(c, n, prep, skip, Tbuf, ps_only, nullptr,
+                                                                       nullptr, raw_out, st))));
+        } else {
+            DISPATCH_LEN(c->nx, RC_TRY((launch_rows_fwd<N_, false>(c, n, prep, skip, Tbuf, ps_only, nullptr,
+                                                                   nullptr, raw_out, st))));
+        }
     }
     ProfScope ps(c, PROF_COLS, st);
-    DISPATCH_LEN(c->ny, RC_TRY((launch_cols<N_, true>(c, Tbuf, n, prep, skip, st))));
+    if (c->t_f32) {
+        DISPATCH_LEN(c->ny, RC_TRY((launch_cols<N_, true, cf>(c, Tbuf, n, prep, skip, st))));
+    } else {
+        DISPATCH_LEN(c->ny, RC_TRY((launch_cols<N_, true>(c, Tbuf, n, prep, skip, st))));
+    }
     return PSFMC_OK;
 }
 
 static int fused_inverse(psfmc_ctx* c, int n, const cd* Tbuf, const double* prep, const uint8_t* skip,
                          double* partial, double* conv_out, double* var_out, hipStream_t st) {
     ProfScope ps(c, PROF_ROWS_INV, st);
-    DISPATCH_LEN(c->nx, RC_TRY((launch_rows_inv<N_>(c, n, Tbuf, prep, skip, partial, conv_out, var_out, st))));
+    if (c->t_f32) {
+        DISPATCH_LEN(c->nx, RC_TRY((launch_rows_inv<N_, cf>(c, n, Tbuf, prep, skip, partial, conv_out, var_out, st))));
+    } else {
+        DISPATCH_LEN(c->nx, RC_TRY((launch_rows_inv<N_>(c, n, Tbuf, prep, skip, partial, conv_out, var_out, st))));
+    }
     return PSFMC_OK;
 }
 
@@ -555,17 +602,11 @@ extern "C" int psfmc_ctx_create(psfmc_ctx** out, int device, int ny, int nx, con
         c->nblk = row_tiles;
         c->rg_log2 = rs.rg_log2;
         c->nyp = t_col_len(ny, c->rg_log2);
+        RowShape cs{};
+        RC_TRY(row_shape_for(ny, &cs));
+        c->plain_shape = rs.plain && cs.plain;
         c->cols_grid = prop.multiProcessorCount * 2;
-        // walkers per internal pass: the transposed half-spectra of one pass
-        // (two passes in flight, together just under the 256 MiB Infinity Cache: measured
-        // best at 256^2 -- 104..120 walkers; 136 and more fall off -- see DESIGN.md)
-        // Never rounded UP past that budget: 32 walkers at 512^2 (2 x 135 MB) ran 6 % slower than
-        // 24, 16 at 1024^2 8 % slower than 6 (gpurun_out r2i sweep).
-        const double per_walker = 2.0 * c->nxh * c->nyp * 16.0;
-        const int fit = (int)(112.0 * 1048576.0 / per_walker);
-        int chunk = fit >= 64 ? ((fit + 4) & ~7) : fit >= 16 ? (fit & ~7) : (fit & ~1);
-        if (chunk < 4) chunk = 4;
-        c->chunk = chunk;
+        c->chunk = fused_pass_walkers(c);
     } else {
         c->nblk = (c->S + 1023) / 1024;
         if (c->nblk > 64) c->nblk = 64;
@@ -634,6 +675,24 @@ extern "C" int psfmc_set_option(psfmc_ctx* c, const char* key, double value) {
         c->img_cap = 0;
         return alloc_work(c);
     }
+    if (!strcmp(key, "storage_f32")) {
+        // keep the intermediate half-spectra as complex64 (arithmetic stays fp64): half the
+        // traffic of every kernel, ~1e-7 relative error in the log-posterior -- the class of the
+        // reference's own float32 raw model (psfMC/models.py:249), not an fp64 result
+        const bool on = value != 0;
+        if (on && (c->backend != PSFMC_BACKEND_FUSED || !c->plain_shape))
+            return fail(PSFMC_EINVAL, "storage_f32 needs the fused back end and power-of-two sides");
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipDeviceSynchronize());
+        c->t_f32 = on;
+        c->chunk = fused_pass_walkers(c);
+        if (c->chunk > c->max_walkers) c->chunk = c->max_walkers;
+        if (c->d_img0) { (void)hipFree(c->d_img0); c->d_img0 = nullptr; }
+        if (c->d_img1) { (void)hipFree(c->d_img1); c->d_img1 = nullptr; }
+        if (c->d_rawstage) { (void)hipFree(c->d_rawstage); c->d_rawstage = nullptr; }
+        c->img_cap = 0;
+        return alloc_work(c);
+    }
     if (!strcmp(key, "cols_grid")) {
         if (value < 1) return fail(PSFMC_EINVAL, "cols_grid must be >= 1");
         c->cols_grid = (int)value;
@@ -682,6 +741,7 @@ extern "C" double psfmc_get_option(const psfmc_ctx* cc, const char* key) {
     }
     if (!strcmp(key, "row_group")) return 1 << c->rg_log2;
     if (!strcmp(key, "partials_per_walker")) return c->nblk;
+    if (!strcmp(key, "storage_f32")) return c->t_f32 ? 1.0 : 0.0;
     if (!strcmp(key, "graph_launches")) return (double)c->graph_launches;
     if (!strcmp(key, "chunk_walkers")) return c->chunk;
     if (!strcmp(key, "backend")) return c->backend;

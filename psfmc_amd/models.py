@@ -55,9 +55,13 @@ class MultiComponentModel(object):
     on first use.  backend: 'fused' (hand-written FFT kernels; sides from
     `engine.FUSED_SIDES`: the powers of two 64...1024 and the even 5-smooth sides in
     between), 'hipfft' (any even size) or 'auto' (fused whenever the shape allows).
+    storage: 'f64' (default) or 'f32' -- keep the intermediate half-spectra of the fused path as
+    complex64 while all arithmetic stays fp64: half the memory traffic, log-posteriors good to
+    ~1e-7 relative (the class of the reference's own float32 raw model, models.py:249) instead
+    of ~1e-15; power-of-two sides only.
     """
 
-    def __init__(self, components, device=0, backend='auto', max_walkers=4096):
+    def __init__(self, components, device=0, backend='auto', max_walkers=4096, storage='f64'):
         np.seterr(divide='ignore')
         if isinstance(components, str):
             try:
@@ -102,7 +106,9 @@ class MultiComponentModel(object):
         if backend == 'auto':
             ny, nx = config.obs_data.shape
             backend = 'fused' if engine.fused_supports(ny, nx) else 'hipfft'
-        self._device, self._backend = device, backend
+        if storage not in ('f64', 'f32'):
+            raise ValueError("storage must be 'f64' or 'f32'")
+        self._device, self._backend, self._storage = device, backend, storage
         self._max_walkers = int(max_walkers)
         self._engine = None
 
@@ -123,6 +129,8 @@ class MultiComponentModel(object):
                 n_ps=len(self._ps), n_sersic=len(self._sersic),
                 max_walkers=self._max_walkers, device=self._device,
                 backend=self._backend)
+            if self._storage == 'f32':
+                self._engine.set_option('storage_f32', 1)
             self._register_layout(self._engine)
         return self._engine
 

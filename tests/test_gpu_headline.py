@@ -120,3 +120,44 @@ def test_device_group_splits_walkers_over_devices(tmp_path):
         grp.logpost_theta(np.tile(case['params'], (3, 1)))            # 195 > max_walkers
     grp.close()
     model.close()
+
+
+@pytest.mark.parametrize('name', ['synth256', 'example'])
+def test_single_precision_storage_option(tmp_path, name):
+    """storage='f32' (complex64 half-spectra between the kernels, fp64 arithmetic): the
+    log-posterior stays within the reference's own float32 class -- a few 1e-7 relative, far
+    inside BASELINE's 1e-5 -- non-finite cases are unchanged, results stay bitwise independent
+    of the batch; shapes it is not built for are refused."""
+    case = helpers.load_case(name)
+    full = helpers.build_model(name, case, tmp_path, backend='fused', max_walkers=128)
+    (tmp_path / 'f32').mkdir()
+    from psfmc_amd import MultiComponentModel
+    half = MultiComponentModel(helpers.write_case_files(name, case, tmp_path / 'f32'), backend='fused',
+                               max_walkers=128, storage='f32')
+    assert half.engine.get_option('storage_f32') == 1 and full.engine.get_option('storage_f32') == 0
+    got64 = full.log_posterior_batch(case['params'])
+    got32 = half.log_posterior_batch(case['params'])
+    assert helpers.rel_err(got32, case['lnprob']) <= 5e-6                     # vs the reference
+    err = helpers.rel_err(got32, got64)
+    assert 0 < err <= 5e-6                                                    # it IS a different rounding
+    fin = np.isfinite(got64)
+    near = fin & (np.abs(got64) < 1e6)           # walkers near the mode (the prior draws sit at -5e6)
+    assert np.abs(got32[near] - got64[near]).max() <= 0.05                    # observed 1e-4 ... 1e-2
+    perm = np.random.RandomState(3).permutation(len(got32))
+    assert np.array_equal(half.log_posterior_batch(case['params'][perm]), got32[perm])
+    assert np.array_equal(half.log_posterior_batch(case['params'][5:9]), got32[5:9])
+    imgs = half.sample_images(case['params'][:1], ('convolved_model',))
+    ref = full.sample_images(case['params'][:1], ('convolved_model',))
+    scale = np.abs(ref['convolved_model']).max()
+    assert np.abs(imgs['convolved_model'] - ref['convolved_model']).max() <= 2e-6 * scale
+    full.close()
+    half.close()
+
+
+def test_single_precision_storage_is_refused_for_general_sides():
+    from test_gpu_fullsize import make_model
+    from psfmc_amd import engine
+    model, _ = make_model(200, 1, 'fused', max_walkers=8)
+    with pytest.raises(engine.NativeError):
+        model.engine.set_option('storage_f32', 1)
+    model.close()
