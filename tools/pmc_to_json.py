@@ -41,7 +41,7 @@ wr = {c: optional('wrreq', 'TCC_EA0_WRREQ' + c + '_sum') for c in ('', '_64B')}
 table = {}
 for k in sorted(set(fetch) | set(write)):
     if not any(s in k for s in ('k_rows_fwd<%d, false' % side, 'k_cols<%d, true' % side,
-                                'k_cols3<%d, true' % side, 'k_rows_inv<%d>' % side)):
+                                'k_cols3<%d, true' % side, 'k_rows_inv<%d' % side)):
         continue
     f_kib, w_kib = fetch.get(k, 0.0), write.get(k, 0.0)
     table[k] = {'FETCH_SIZE_KiB_per_launch': f_kib, 'WRITE_SIZE_KiB_per_launch': w_kib,

@@ -31,7 +31,7 @@ for name in ['sq1','sq2','fetch','write','rdreq','wrreq']:
         agg[k][r['Counter_Name']] += float(r['Counter_Value'])
         cnt[(k, r['Counter_Name'])] += 1
     for k in sorted(agg):
-        if k.startswith(('k_rows_fwd<', 'k_rows_inv<', 'k_theta_prep', 'k_finish')) and 'true>' not in k \
-                or k.startswith('k_cols') and k.endswith('true>'):
+        if k.startswith(('k_rows_fwd<', 'k_rows_inv<', 'k_theta_prep', 'k_finish')) and ', true' not in k \
+                or k.startswith('k_cols') and ', true' in k:
             print(name, k, {c: '%.4g' % (v / cnt[(k, c)]) for c, v in agg[k].items()})
 PY
