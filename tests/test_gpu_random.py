@@ -170,3 +170,33 @@ def test_general_sides_match_oracle(shape):
         assert np.abs(psf_spec[k] - field.psf_spec[k]).max() <= 1e-13 * np.abs(field.psf_spec[k]).max()
         assert np.abs(var_spec[k] - field.var_spec[k]).max() <= 1e-13 * np.abs(field.var_spec[k]).max()
     model.close()
+
+
+@pytest.mark.parametrize('n_side', [96, 100, 120, 150, 180, 200, 250, 300, 384, 500, 640, 900])
+def test_general_sides_with_distinct_walkers(n_side):
+    """A batch of DISTINCT walkers (prior draws and near-truth) on square general-side fields:
+    the fused kernels against the hipFFT back end (independent arithmetic), the oracle on two
+    walkers, and bitwise independence of batch order and composition -- the column kernel's
+    kx-major work order, idle lanes and spare slots must not leak between walkers."""
+    from test_gpu_fullsize import make_model
+    n_sersic = 2 if n_side <= 300 else 1
+    n_w = 24 if n_side <= 500 else 10
+    model, fld = make_model(n_side, n_sersic, 'fused', max_walkers=n_w)
+    ref, _ = make_model(n_side, n_sersic, 'hipfft', max_walkers=n_w)
+    theta = np.vstack([synth_field.draw_walkers(n_side, n_sersic, n_w // 2, seed=n_side),
+                       synth_field.draw_walkers(n_side, n_sersic, n_w - n_w // 2, seed=n_side + 1,
+                                                near_truth=fld['truth'])])
+    got = model.log_posterior_batch(theta)
+    assert np.isfinite(got).all()
+    assert helpers.rel_err(got, ref.log_posterior_batch(theta)) <= 1e-11
+    field = orc.make_field(fld['sci'], fld['ivm'], [fld['psf']], [fld['psf_ivm']], mag_zp=fld['mag_zp'])
+    prior = model.log_priors_batch(theta[[0, n_w - 1]])
+    for i, p in zip((0, n_w - 1), prior):
+        want = helpers.oracle_loglike(field, helpers.synth_layout(n_sersic), theta[i]) + p
+        assert abs(got[i] - want) <= 1e-10 * abs(want), (n_side, i)
+    perm = np.random.RandomState(n_side).permutation(n_w)
+    assert np.array_equal(model.log_posterior_batch(theta[perm]), got[perm])
+    assert np.array_equal(model.log_posterior_batch(theta[2:5]), got[2:5])
+    assert np.array_equal(model.log_posterior_batch(theta[-1:]), got[-1:])
+    model.close()
+    ref.close()
