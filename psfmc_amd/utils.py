@@ -76,7 +76,10 @@ def mask_from_file(mask_file, obs_hdr, shape):
 
 
 def region_filter(region_file, shape):
-    """Boolean image, True inside the fitting region of a ds9 region file."""
+    """Boolean image, True inside the fitting region of a ds9 region file (the reference
+    hands the file to pyregion, utils.py:92-95; parity unpinned -- pyregion is absent here).
+    Shapes: circle, ellipse and box (with position angle), annulus, polygon; `-shape` excludes;
+    image / physical coordinates only."""
     import re
     yy, xx = np.mgrid[0:shape[0], 0:shape[1]].astype(np.float64)
     inside = np.zeros(shape, dtype=bool)
@@ -89,24 +92,42 @@ def region_filter(region_file, shape):
             if line.lower() in ('image', 'physical', 'fk5', 'icrs', 'galactic', 'j2000', 'fk4'):
                 system = line.lower()
                 continue
-            m = re.match(r'^(?:(\w+)\s*;\s*)?([+-]?)\s*(circle|box|ellipse)\s*\(([^)]*)\)', line, re.I)
+            m = re.match(r'^(?:(\w+)\s*;\s*)?([+-]?)\s*(circle|box|ellipse|annulus|polygon)\s*\(([^)]*)\)',
+                         line, re.I)
             if not m:
                 raise ValueError('unsupported region line: ' + line)
             if (m.group(1) or system).lower() not in ('image', 'physical'):
                 raise ValueError('only image coordinates are supported, got ' + (m.group(1) or system))
             args = [float(v.strip().rstrip('"\'')) for v in m.group(4).split(',')]
             kind = m.group(3).lower()
-            dx, dy = xx - (args[0] - 1.0), yy - (args[1] - 1.0)
-            if kind == 'circle':
-                sel = dx * dx + dy * dy <= args[2] ** 2
-            elif kind == 'box':
-                if len(args) > 4 and args[4] != 0:
-                    raise ValueError('rotated boxes are not supported')
-                sel = (np.abs(dx) <= args[2] / 2) & (np.abs(dy) <= args[3] / 2)
+            if kind == 'polygon':
+                if len(args) < 6 or len(args) % 2:
+                    raise ValueError('polygon needs at least three x,y pairs: ' + line)
+                # even-odd rule on pixel centres (ds9 coordinates are 1-based)
+                px, py = np.array(args[0::2]) - 1.0, np.array(args[1::2]) - 1.0
+                sel = np.zeros(shape, dtype=bool)
+                for k in range(len(px)):
+                    x1, y1, x2, y2 = px[k], py[k], px[(k + 1) % len(px)], py[(k + 1) % len(px)]
+                    if y1 == y2:
+                        continue
+                    crosses = ((y1 > yy) != (y2 > yy)) & (xx < x1 + (yy - y1) * (x2 - x1) / (y2 - y1))
+                    sel ^= crosses
             else:
-                if len(args) > 4 and args[4] != 0:
-                    raise ValueError('rotated ellipses are not supported')
-                sel = (dx / args[2]) ** 2 + (dy / args[3]) ** 2 <= 1.0
+                dx, dy = xx - (args[0] - 1.0), yy - (args[1] - 1.0)
+                if kind == 'circle':
+                    sel = dx * dx + dy * dy <= args[2] ** 2
+                elif kind == 'annulus':
+                    r2 = dx * dx + dy * dy
+                    sel = (r2 >= args[2] ** 2) & (r2 <= args[3] ** 2)
+                else:
+                    # box / ellipse: optional position angle, degrees counter-clockwise from +x
+                    ang = np.deg2rad(args[4]) if len(args) > 4 else 0.0
+                    u = dx * np.cos(ang) + dy * np.sin(ang)
+                    v = -dx * np.sin(ang) + dy * np.cos(ang)
+                    if kind == 'box':
+                        sel = (np.abs(u) <= args[2] / 2) & (np.abs(v) <= args[3] / 2)
+                    else:
+                        sel = (u / args[2]) ** 2 + (v / args[3]) ** 2 <= 1.0
             inside = (inside & ~sel) if m.group(2) == '-' else (inside | sel)
             n_shapes += 1
     if n_shapes == 0:

@@ -191,6 +191,15 @@ def test_ds9_region_mask(tmp_path):
     ex.write_text('image\ncircle(64.540771,64.079391,55.620614)\n-circle(111.37667,58.936343,11.905084)\n')
     keep = region_filter(str(ex), (128, 128))
     assert keep[63, 63] and not keep[0, 0] and not keep[58, 110]
+    # rotated ellipse / box, annulus, polygon (hand-computed on pixel centres; ds9 is 1-based)
+    more = tmp_path / 'more.reg'
+    more.write_text('image\nellipse(33,33,20,5,90)\n-annulus(33,33,0,2)\npolygon(5,5,15,5,15,15,5,15)\n'
+                    'box(50,12,10,2,45)\n')
+    m = region_filter(str(more), (64, 64))
+    assert m[32 + 15, 32] and not m[32, 32 + 15]          # the long axis points along y after 90 degrees
+    assert not m[32, 32] and not m[33, 32] and m[36, 32]  # the centre is cut out by the annulus
+    assert m[9, 9] and m[4, 4] and m[13, 13] and not m[15, 15] and not m[9, 20]   # square polygon
+    assert m[11 + 3, 49 + 3] and not m[11 + 3, 49 - 3]    # the box lies along the +x +y diagonal
     # unsupported content -> ignored with a warning, like the reference without pyregion
     other = tmp_path / 'o.reg'
     other.write_text('fk5\ncircle(10:00:00,+02:00:00,5")\n')
