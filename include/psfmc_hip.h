@@ -46,9 +46,8 @@ typedef struct psfmc_ctx psfmc_ctx;
 #define PSFMC_BACKEND_FUSED   0  /* hand-written LDS FFT fused with rasteriser / spectral multiply / chi^2.
                                     Sides: the powers of two 64..1024 and the even 5-smooth sides 96 100 120
                                     144 150 160 180 192 200 240 250 288 300 320 360 384 400 480 500 576 600
-                                    640 720 768 800 900 960 (nx and ny independently; with a power-of-two nx,
-                                    ny must be a multiple of 8, of 4 for nx = 256 or 512); psfmc_ctx_create
-                                    returns PSFMC_EINVAL for any other shape */
+                                    640 720 768 800 900 960 (nx and ny independently, any combination);
+                                    psfmc_ctx_create returns PSFMC_EINVAL for any other shape */
 #define PSFMC_BACKEND_HIPFFT  1  /* batched hipFFT D2Z/Z2D between separate kernels: any even shape
                                     (psfMC/utils.py:25-32 accepts those); also the cross-check path */
 

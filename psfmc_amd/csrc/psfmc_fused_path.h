@@ -55,8 +55,11 @@ template <int NX> constexpr int row_group() { return FftShape<NX>::TPW; }       
 // rows that share a contiguous run of T per kx (the "RG" of the layout comment above): the rows
 // of one wave for the power-of-two shapes, 4 otherwise (ny is rounded up to a multiple of it in
 // the layout; the spare rows are never read)
-template <int NX> constexpr int layout_rg_log2() {
-    return FftShape<NX>::kPlain ? __builtin_ctz(FftShape<NX>::TPW) : 2;
+// FAST = the unguarded row kernels of the power-of-two shapes (whole workgroups of rows only);
+// the same shapes also build with FAST = false -- the guarded general code path -- for images whose
+// ny is not a whole number of such workgroups
+template <int NX, bool FAST = FftShape<NX>::kPlain> constexpr int layout_rg_log2() {
+    return FAST ? __builtin_ctz(FftShape<NX>::TPW) : 2;
 }
 // General shapes: a wave's RG rows need not be a whole number of the layout's 4-row groups
 // (RG = 6 for T = 10, 3 for T = 20, 5 for T = 12): as many consecutive waves as make one (12 or
@@ -66,19 +69,19 @@ template <int NX> constexpr int layout_rg_log2() {
 #ifndef PSFMC_GEN_ROW_WAVES
 #define PSFMC_GEN_ROW_WAVES 1
 #endif
-template <int NX> constexpr int row_waves() {
+template <int NX, bool FAST = FftShape<NX>::kPlain> constexpr int row_waves() {
     if (PSFMC_ROW_WAVES) return PSFMC_ROW_WAVES;
-    if (FftShape<NX>::kPlain) return row_group<NX>() >= 4 ? 1 : 4;
+    if (FAST) return row_group<NX>() >= 4 ? 1 : 4;
     constexpr int rg = row_group<NX>();
     return !PSFMC_GEN_ROW_WAVES ? 1 : (rg % 4 == 0 ? 1 : rg % 2 == 0 ? 2 : 4);
 }
-template <int NX> constexpr int row_threads() { return 64 * row_waves<NX>(); }
+template <int NX, bool FAST = FftShape<NX>::kPlain> constexpr int row_threads() { return 64 * row_waves<NX, FAST>(); }
 // per wave: the exchange regions of its RG transforms, then its twiddle table
 template <int NX> constexpr size_t fused_row_wave_lds_doubles() {
     return (size_t)row_group<NX>() * fft_lds_elems<NX>() + 2 * (size_t)fft_tw_lds_elems<NX>();
 }
-template <int NX> constexpr size_t fused_row_lds_bytes() {
-    return (size_t)row_waves<NX>() * fused_row_wave_lds_doubles<NX>() * sizeof(double);
+template <int NX, bool FAST = FftShape<NX>::kPlain> constexpr size_t fused_row_lds_bytes() {
+    return (size_t)row_waves<NX, FAST>() * fused_row_wave_lds_doubles<NX>() * sizeof(double);
 }
 template <int NY> constexpr int col_ffts_per_block() { return (kColThreads / 64) * FftShape<NY>::TPW; }
 template <int NY> constexpr size_t fused_col_wave_lds_doubles() {
@@ -173,8 +176,8 @@ __global__ void k_pack_field(const double* __restrict__ sci, const double* __res
 //   FROM_IMAGE = true : z = img0 + i img_scale[w] img1 from memory (PSF spectra at setup)
 // raw_out (optional): [n][ny][nx] copy of the raw model (psfmc_eval_images)
 // ---------------------------------------------------------------------------
-template <int NX, bool FROM_IMAGE, typename TS = cd>
-__global__ void __launch_bounds__(row_threads<NX>(), fused_min_waves<NX>())
+template <int NX, bool FROM_IMAGE, typename TS = cd, bool FAST = FftShape<NX>::kPlain>
+__global__ void __launch_bounds__((row_threads<NX, FAST>()), fused_min_waves<NX>())
 k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
            const cd* __restrict__ twx, TS* __restrict__ Tbuf, int n_ps, int n_sersic, int ny,
            int ps_only, const double* __restrict__ img, const double* __restrict__ img_scale,
@@ -182,19 +185,19 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
     using S = FftShape<NX>;
     constexpr int P = S::P, T = S::T, R = S::R, RG = row_group<NX>();
     constexpr int NXH = NX / 2 + 1;
-    constexpr int RGL2 = layout_rg_log2<NX>(), RGL = 1 << RGL2;       // rows per layout group
+    constexpr int RGL2 = layout_rg_log2<NX, FAST>(), RGL = 1 << RGL2;       // rows per layout group
     extern __shared__ __align__(16) double smem[];
     const int w = blockIdx.y;
     if (skip && skip[w]) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int f = lane / T, t = lane % T;
-    const int yg = blockIdx.x * row_waves<NX>() + wave;
-    if constexpr (!S::kPlain)
+    const int yg = blockIdx.x * row_waves<NX, FAST>() + wave;
+    if constexpr (!FAST)
         if (yg * RG >= ny) return;                                    // wave-uniform: past the last row group
     const bool lane_on = S::kFull || f < RG;                          // not one of the idle tail lanes
     const int fe = S::kFull ? f : (f < RG ? f : RG - 1);              // LDS region (idle lanes alias the last)
     const int iy = yg * RG + f;
-    const bool row_on = S::kPlain || (lane_on && iy < ny);            // this lane's row exists
+    const bool row_on = FAST || (lane_on && iy < ny);            // this lane's row exists
     const int nyp = t_col_len(ny, RGL2);
     const size_t Spx = (size_t)ny * NX;
 
@@ -231,7 +234,7 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
     TS* wbase = Tbuf + (size_t)w * 2 * NXH * nyp;                    // wave-uniform
     constexpr unsigned kEl = sizeof(TS);                             // bytes of a T element
     const unsigned kstride = 2u * (unsigned)nyp * kEl;               // bytes between kx columns
-    if constexpr (S::kPlain) {
+    if constexpr (FAST) {
         // Untangle.  Lane t holds Z[k], k = t + T e.  Z[NX - k] is held by lane
         // (T - t) % T at e' = P-1-e (t != 0) or P-e (t == 0), i.e. in the upper half of
         // its registers: pass the upper halves through LDS (wave-local; the N/2 complex
@@ -539,8 +542,8 @@ k_cols3(TS* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restri
 // partial[w][yg] = sum over the wave's good pixels of the chi^2 term.
 // conv_out / var_out (optional): [n][ny][nx] images (psfmc_eval_images)
 // ---------------------------------------------------------------------------
-template <int NX, typename TS = cd>
-__global__ void __launch_bounds__(row_threads<NX>(), fused_min_waves<NX>())
+template <int NX, typename TS = cd, bool FAST = FftShape<NX>::kPlain>
+__global__ void __launch_bounds__((row_threads<NX, FAST>()), fused_min_waves<NX>())
 k_rows_inv(const TS* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const cd* __restrict__ twx,
            const FieldPx* __restrict__ field, double* __restrict__ partial, int ny,
            const double* __restrict__ prep, int plen,
@@ -548,7 +551,7 @@ k_rows_inv(const TS* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
     using S = FftShape<NX>;
     constexpr int P = S::P, T = S::T, R = S::R, RG = row_group<NX>();
     constexpr int NXH = NX / 2 + 1;
-    constexpr int RGL2 = layout_rg_log2<NX>(), RGL = 1 << RGL2;
+    constexpr int RGL2 = layout_rg_log2<NX, FAST>(), RGL = 1 << RGL2;
     extern __shared__ __align__(16) double smem[];
 #if PSFMC_INV_PRIO
     __builtin_amdgcn_s_setprio(PSFMC_INV_PRIO);
@@ -558,15 +561,15 @@ k_rows_inv(const TS* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
     if (skip && skip[w]) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int f = lane / T, t = lane % T;
-    const int yg = blockIdx.x * row_waves<NX>() + wave;
-    if constexpr (!S::kPlain)
+    const int yg = blockIdx.x * row_waves<NX, FAST>() + wave;
+    if constexpr (!FAST)
         if (yg * RG >= ny) return;                                    // wave-uniform
     const bool lane_on = S::kFull || f < RG;
     const int fe = S::kFull ? f : (f < RG ? f : RG - 1);
     const int iy = yg * RG + f;
-    const bool row_on = S::kPlain || (lane_on && iy < ny);
+    const bool row_on = FAST || (lane_on && iy < ny);
     const int nyp = t_col_len(ny, RGL2);
-    const int nyg = S::kPlain ? (int)gridDim.x * row_waves<NX>() : (ny + RG - 1) / RG;
+    const int nyg = FAST ? (int)gridDim.x * row_waves<NX, FAST>() : (ny + RG - 1) / RG;
     const TS* wbase = Tbuf + (size_t)w * 2 * NXH * nyp;             // wave-uniform
     constexpr unsigned kEl = sizeof(TS);                             // bytes of a T element
     const unsigned kstride = 2u * (unsigned)nyp * kEl;               // bytes between kx columns
@@ -580,7 +583,7 @@ k_rows_inv(const TS* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
     cd v[R];
 #pragma unroll
     for (int a = P; a < R; ++a) v[a] = cd{0.0, 0.0};
-    if constexpr (S::kPlain) {
+    if constexpr (FAST) {
         // the owner of NX - k is lane (T - t) % T at a' = P-1-a (t != 0) or P-a (t == 0);
         // mbuf is [P/2][T] complex
         const unsigned off0 = (unsigned)t_elem(iy, 0, RGL2) * kEl + (unsigned)t * kstride;

@@ -136,6 +136,7 @@ struct psfmc_ctx {
     int n_streams = 2;
     bool t_f32 = false;       // T stored as complex64 (set_option "storage_f32"); arithmetic stays fp64
     bool plain_shape = false; // both sides power-of-two shapes (what storage_f32 is built for)
+    bool row_fast = false;    // nx a power-of-two shape and ny a whole number of its row workgroups
     bool cols3 = true;        // ny >= 512: column kernel on the wave-wide three-stage engine
     bool use_graph = false;   // psfmc_stretch_run replays a captured iteration (set_option "graph"; measured: no gain,
                               // the iteration is kernel-time- not launch-bound)
@@ -252,10 +253,10 @@ static bool fused_side(int n) {
 }
 
 // per-side constants of the row kernels
-struct RowShape { int rg, waves, rg_log2, regs; bool plain; };
+struct RowShape { int rg, fast_waves, fast_rg_log2, regs; bool plain; };
 static int row_shape_for(int nx, RowShape* out) {
-    DISPATCH_LEN(nx, (*out = RowShape{row_group<N_>(), row_waves<N_>(), layout_rg_log2<N_>(), FftShape<N_>::R,
-                                      FftShape<N_>::kPlain}));
+    DISPATCH_LEN(nx, (*out = RowShape{row_group<N_>(), row_waves<N_, true>(), layout_rg_log2<N_, true>(),
+                                      FftShape<N_>::R, FftShape<N_>::kPlain}));
     return PSFMC_OK;
 }
 
@@ -266,28 +267,48 @@ static int row_shape_for(int nx, RowShape* out) {
 // built for the power-of-two shapes only)
 template <int N, typename TS> constexpr bool storage_built() { return sizeof(TS) == sizeof(cd) || FftShape<N>::kPlain; }
 
-template <int NX, bool FROM_IMAGE, typename TS = cd>
-static int launch_rows_fwd(psfmc_ctx* c, int n, const double* prep, const uint8_t* skip, void* Tvoid,
-                           int ps_only, const double* img, const double* img_scale, double* raw_out,
-                           hipStream_t st) {
-  if constexpr (!storage_built<NX, TS>()) {
-    return fail(PSFMC_EINVAL, "single-precision storage is built for power-of-two sides only");
-  } else {
-    TS* Tbuf = static_cast<TS*>(Tvoid);
-    constexpr size_t lds = fused_row_lds_bytes<NX>();
+template <int NX, bool FROM_IMAGE, typename TS, bool FAST>
+static int launch_rows_fwd_impl(psfmc_ctx* c, int n, const double* prep, const uint8_t* skip, TS* Tbuf,
+                                int ps_only, const double* img, const double* img_scale, double* raw_out,
+                                hipStream_t st) {
+    constexpr size_t lds = fused_row_lds_bytes<NX, FAST>();
     if constexpr (lds > 64 * 1024) {
         static thread_local int attr_device = -1;
         if (attr_device != c->device) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows_fwd<NX, FROM_IMAGE, TS>),
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows_fwd<NX, FROM_IMAGE, TS, FAST>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_device = c->device;
         }
     }
-    hipLaunchKernelGGL((k_rows_fwd<NX, FROM_IMAGE, TS>), dim3((c->nblk + row_waves<NX>() - 1) / row_waves<NX>(), n),
-                       dim3(row_threads<NX>()), lds, st, prep, skip, c->d_twx, Tbuf, c->n_ps, c->n_sersic,
+    constexpr int waves = row_waves<NX, FAST>();
+    hipLaunchKernelGGL((k_rows_fwd<NX, FROM_IMAGE, TS, FAST>), dim3((c->nblk + waves - 1) / waves, n),
+                       dim3((row_threads<NX, FAST>())), lds, st, prep, skip, c->d_twx, Tbuf, c->n_ps, c->n_sersic,
                        c->ny, ps_only, img, img_scale, raw_out);
     return PSFMC_OK;
-  }
+}
+
+// c->row_fast: the unguarded power-of-two row kernels (ny a whole number of their workgroups);
+// otherwise the guarded general code path of the same shape
+template <int NX, bool FROM_IMAGE, typename TS = cd>
+static int launch_rows_fwd(psfmc_ctx* c, int n, const double* prep, const uint8_t* skip, void* Tvoid,
+                           int ps_only, const double* img, const double* img_scale, double* raw_out,
+                           hipStream_t st) {
+    if constexpr (!storage_built<NX, TS>()) {
+        return fail(PSFMC_EINVAL, "single-precision storage is built for power-of-two sides only");
+    } else {
+        TS* Tbuf = static_cast<TS*>(Tvoid);
+        if constexpr (FftShape<NX>::kPlain) {
+            if (c->row_fast)
+                return launch_rows_fwd_impl<NX, FROM_IMAGE, TS, true>(c, n, prep, skip, Tbuf, ps_only, img,
+                                                                      img_scale, raw_out, st);
+        }
+        if constexpr (sizeof(TS) == sizeof(cd)) {
+            return launch_rows_fwd_impl<NX, FROM_IMAGE, TS, false>(c, n, prep, skip, Tbuf, ps_only, img,
+                                                                   img_scale, raw_out, st);
+        } else {
+            return fail(PSFMC_EINVAL, "single-precision storage needs the unguarded row kernels");
+        }
+    }
 }
 
 template <int NY, bool CONVOLVE, typename TS = cd>
@@ -324,27 +345,42 @@ static int launch_cols(psfmc_ctx* c, void* Tvoid, int n_w, const double* prep, c
   }
 }
 
-template <int NX, typename TS = cd>
-static int launch_rows_inv(psfmc_ctx* c, int n, const void* Tvoid, const double* prep, const uint8_t* skip,
-                           double* partial, double* conv_out, double* var_out, hipStream_t st) {
-  if constexpr (!storage_built<NX, TS>()) {
-    return fail(PSFMC_EINVAL, "single-precision storage is built for power-of-two sides only");
-  } else {
-    const TS* Tbuf = static_cast<const TS*>(Tvoid);
-    constexpr size_t lds = fused_row_lds_bytes<NX>();
+template <int NX, typename TS, bool FAST>
+static int launch_rows_inv_impl(psfmc_ctx* c, int n, const TS* Tbuf, const double* prep, const uint8_t* skip,
+                                double* partial, double* conv_out, double* var_out, hipStream_t st) {
+    constexpr size_t lds = fused_row_lds_bytes<NX, FAST>();
     if constexpr (lds > 64 * 1024) {
         static thread_local int attr_device = -1;
         if (attr_device != c->device) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows_inv<NX, TS>),
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows_inv<NX, TS, FAST>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_device = c->device;
         }
     }
-    hipLaunchKernelGGL((k_rows_inv<NX, TS>), dim3((c->nblk + row_waves<NX>() - 1) / row_waves<NX>(), n), dim3(row_threads<NX>()), lds, st,
-                       Tbuf, skip, c->d_twx, c->d_field, partial, c->ny, prep, c->plen, conv_out,
-                       var_out);
+    constexpr int waves = row_waves<NX, FAST>();
+    hipLaunchKernelGGL((k_rows_inv<NX, TS, FAST>), dim3((c->nblk + waves - 1) / waves, n),
+                       dim3((row_threads<NX, FAST>())), lds, st, Tbuf, skip, c->d_twx, c->d_field, partial, c->ny,
+                       prep, c->plen, conv_out, var_out);
     return PSFMC_OK;
-  }
+}
+
+template <int NX, typename TS = cd>
+static int launch_rows_inv(psfmc_ctx* c, int n, const void* Tvoid, const double* prep, const uint8_t* skip,
+                           double* partial, double* conv_out, double* var_out, hipStream_t st) {
+    if constexpr (!storage_built<NX, TS>()) {
+        return fail(PSFMC_EINVAL, "single-precision storage is built for power-of-two sides only");
+    } else {
+        const TS* Tbuf = static_cast<const TS*>(Tvoid);
+        if constexpr (FftShape<NX>::kPlain) {
+            if (c->row_fast)
+                return launch_rows_inv_impl<NX, TS, true>(c, n, Tbuf, prep, skip, partial, conv_out, var_out, st);
+        }
+        if constexpr (sizeof(TS) == sizeof(cd)) {
+            return launch_rows_inv_impl<NX, TS, false>(c, n, Tbuf, prep, skip, partial, conv_out, var_out, st);
+        } else {
+            return fail(PSFMC_EINVAL, "single-precision storage needs the unguarded row kernels");
+        }
+    }
 }
 
 template <int NX> static int pack_field(psfmc_ctx* c) {
@@ -573,10 +609,6 @@ extern "C" int psfmc_ctx_create(psfmc_ctx** out, int device, int ny, int nx, con
             return fail(PSFMC_EINVAL, "fused backend: sides must be among " PSFMC_FUSED_SIDES " (got %d x %d)",
                         ny, nx);
         RC_TRY(row_shape_for(nx, &rs));
-        // the power-of-two row kernels run without row guards: whole workgroups of rows only
-        if (rs.plain && ny % (rs.rg * rs.waves))
-            return fail(PSFMC_EINVAL, "fused backend: ny=%d must be a multiple of %d for nx=%d", ny,
-                        rs.rg * rs.waves, nx);
         row_tiles = (ny + rs.rg - 1) / rs.rg;
     }
 
@@ -600,7 +632,10 @@ extern "C" int psfmc_ctx_create(psfmc_ctx** out, int device, int ny, int nx, con
     c->nyp = ny;
     if (backend == PSFMC_BACKEND_FUSED) {
         c->nblk = row_tiles;
-        c->rg_log2 = rs.rg_log2;
+        // the power-of-two row kernels run without row guards: whole workgroups of rows only;
+        // any other ny takes the guarded code path of the same shape (layout groups of 4 rows)
+        c->row_fast = rs.plain && ny % (rs.rg * rs.fast_waves) == 0;
+        c->rg_log2 = c->row_fast ? rs.fast_rg_log2 : 2;
         c->nyp = t_col_len(ny, c->rg_log2);
         RowShape cs{};
         RC_TRY(row_shape_for(ny, &cs));
@@ -680,7 +715,7 @@ extern "C" int psfmc_set_option(psfmc_ctx* c, const char* key, double value) {
         // traffic of every kernel, ~1e-7 relative error in the log-posterior -- the class of the
         // reference's own float32 raw model (psfMC/models.py:249), not an fp64 result
         const bool on = value != 0;
-        if (on && (c->backend != PSFMC_BACKEND_FUSED || !c->plain_shape))
+        if (on && (c->backend != PSFMC_BACKEND_FUSED || !c->plain_shape || !c->row_fast))
             return fail(PSFMC_EINVAL, "storage_f32 needs the fused back end and power-of-two sides");
         HIP_TRY(hipSetDevice(c->device));
         HIP_TRY(hipDeviceSynchronize());

@@ -17,15 +17,13 @@ ROW_SKY, ROW_PS, ROW_SERSIC = 1, 4, 9
 # sides the fused kernels are built for (psfmc_amd/csrc/psfmc_fft.h FftShape)
 FUSED_SIDES = (64, 96, 100, 120, 128, 144, 150, 160, 180, 192, 200, 240, 250, 256, 288, 300, 320, 360,
                384, 400, 480, 500, 512, 576, 600, 640, 720, 768, 800, 900, 960, 1024)
-# rows per workgroup of the power-of-two row kernels (they run without row guards)
-_PLAIN_ROW_BLOCK = {64: 8, 128: 8, 256: 4, 512: 4, 1024: 8}
 
 
 def fused_supports(ny, nx):
-    """Whether psfmc_ctx_create accepts this image shape for the fused back end."""
-    if ny not in FUSED_SIDES or nx not in FUSED_SIDES:
-        return False
-    return nx not in _PLAIN_ROW_BLOCK or ny % _PLAIN_ROW_BLOCK[nx] == 0
+    """Whether psfmc_ctx_create accepts this image shape for the fused back end: both sides
+    from FUSED_SIDES, in any combination."""
+    return ny in FUSED_SIDES and nx in FUSED_SIDES
+
 
 _LIB_NAME = 'libpsfmc_hip.so'
 _lib = None

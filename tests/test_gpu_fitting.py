@@ -16,7 +16,8 @@ def test_model_galaxy_mcmc_example(tmp_path):
     from psfmc_amd import model_galaxy_mcmc, load_database, fits_io, MultiComponentModel
     src = os.path.join(helpers.GOLDEN, 'example')
     for name in os.listdir(src):
-        shutil.copy(os.path.join(src, name), tmp_path)
+        if os.path.isfile(os.path.join(src, name)):       # a stray __pycache__ is not a fixture
+            shutil.copy(os.path.join(src, name), tmp_path)
     model_file = str(tmp_path / 'model_example.py')
     out = str(tmp_path / 'out_example')
     np.random.seed(42)                                   # prior draws use the global numpy RNG

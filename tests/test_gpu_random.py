@@ -126,11 +126,12 @@ def general_shapes():
     from psfmc_amd import engine
     n = len(GENERAL_SIDES)
     shapes = [(GENERAL_SIDES[i], GENERAL_SIDES[(5 * i + 3) % n]) for i in range(n)]
-    shapes += [(200, 200), (300, 300), (500, 500), (256, 200), (200, 256), (96, 512), (1024, 120), (160, 64), (150, 96)]
+    shapes += [(200, 200), (300, 300), (500, 500), (256, 200), (200, 256), (96, 512), (1024, 120), (160, 64), (150, 96),
+               # a power-of-two nx whose unguarded row kernels do not divide ny: the guarded variant
+               (150, 64), (100, 128), (150, 256), (250, 512), (500, 1024), (96, 1024)]
     assert all(engine.fused_supports(ny, nx) for ny, nx in shapes)
-    # the power-of-two row kernels take whole workgroups of rows only: such shapes (and any side
-    # with a prime factor > 5) go to the hipFFT back end under backend='auto'
-    assert not engine.fused_supports(150, 64) and not engine.fused_supports(140, 140)
+    # a side with a prime factor > 5 goes to the hipFFT back end under backend='auto'
+    assert not engine.fused_supports(140, 140) and not engine.fused_supports(256, 90)
     return shapes
 
 
