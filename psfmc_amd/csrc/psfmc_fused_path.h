@@ -213,8 +213,17 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
     } else {
         const double* wprep = prep + (size_t)w * prep_len(n_ps, n_sersic);   // wave-uniform
         const double mu = wprep[kPrepMu];
+        // the rasteriser's log2 table borrows the start of the wave's transform exchange region,
+        // which is idle until the transform begins
+        static_assert((size_t)RG * fft_lds_elems<NX>() * sizeof(double) >= (size_t)kLogTabBytes, "exchange region too small");
+        double* log_tab = smem + (size_t)wave * fused_row_wave_lds_doubles<NX>();
+        if (!ps_only) {
+            load_log_table(log_tab, lane);
+            wave_lds_sync();
+        }
         double r[P];
-        raster_row<P, T>(wprep, n_ps, n_sersic, t, iy, ps_only != 0, r);
+        raster_row<P, T>(wprep, n_ps, n_sersic, t, iy, ps_only != 0, log_tab, r);
+        wave_lds_sync();
 #pragma unroll
         for (int k = 0; k < P; ++k) v[k] = cd{r[k], mu * r[k] * r[k]};
         if (raw_out && row_on) {

@@ -1663,15 +1663,18 @@ extern "C" int psfmc_group_eval_theta(psfmc_group* g, int W, const double* theta
 // diagnostic: device elementary functions on host arrays
 // ---------------------------------------------------------------------------
 __global__ void k_debug_math(int op, int n, const double* __restrict__ in, double* __restrict__ out) {
+    __shared__ __align__(16) double tab[4][kLogTabBytes / sizeof(double)];   // one copy per wave, as in k_rows_fwd
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    load_log_table(tab[threadIdx.x >> 6], threadIdx.x & 63);
+    wave_lds_sync();
     if (i >= n) return;
     const double x = in[i];
     out[i] = op == 0 ? fast_log2(x) : op == 1 ? fast_exp2(x) : op == 2 ? fast_rcp(x) : op == 3 ? fast_rcp1(x)
-                                                                              : fast_exp2_noclamp(x);
+             : op == 4 ? fast_exp2_noclamp(x) : fast_log2_tab(x, tab[threadIdx.x >> 6]);
 }
 
 extern "C" int psfmc_debug_math(int device, int op, int n, const double* in, double* out) {
-    if (n < 0 || op < 0 || op > 4 || (n > 0 && (!in || !out))) return fail(PSFMC_EINVAL, "bad argument");
+    if (n < 0 || op < 0 || op > 5 || (n > 0 && (!in || !out))) return fail(PSFMC_EINVAL, "bad argument");
     if (n == 0) return PSFMC_OK;
     HIP_TRY(hipSetDevice(device));
     double *d_in = nullptr, *d_out = nullptr;

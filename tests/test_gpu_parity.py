@@ -198,6 +198,13 @@ def test_device_math():
     nz = close & (ref != 0)
     assert np.max(np.abs(got[nz] - ref[nz]) / np.abs(ref[nz])) <= 1e-15
     assert engine.debug_math('log2', np.array([1.0]))[0] == 0.0
+    # the rasteriser's table-driven log2: ABSOLUTE accuracy is its contract (it feeds 2^(p log2 x)):
+    # one ulp of the result's magnitude (observed 2.2e-16 scaled, the same as the table-free log2)
+    edges = 2.0 ** rng.randint(-30, 30, 512) * (1.0 + rng.randint(0, 128, 512) / 128.0)     # table cell borders
+    xt = np.concatenate([x, edges, np.nextafter(edges, 0), np.nextafter(edges, np.inf)])
+    got = engine.debug_math('log2_tab', xt)
+    ref = np.log2(xt.astype(np.longdouble)).astype(np.float64)
+    assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)) <= 2.3e-16
 
     y = np.concatenate([rng.uniform(-60, 60, 20000), rng.uniform(-1075, -1000, 200),
                         [0.0, 1.0, -1.0, 0.5, -0.5, 1023.0, -1074.0, -1100.0, -5000.0, -np.inf]])
