@@ -158,6 +158,27 @@ def kernel_profile(eng, args, one_batch, torch, dev, reps):
     return out
 
 
+def sweep_ceiling(engine, device, nbytes, walkers, rate_gpu, reps=20):
+    """What this GPU gives the data flow of one pass at best: three plain sweeps (the library's
+    psfmc_debug_sweep kernels, no arithmetic) over a buffer the size of one pass's transposed
+    half-spectra T -- written once (k_rows_fwd), read and written back in place (k_cols), read
+    once (k_rows_inv).  Their summed time is a floor for the three-kernel pass on this box;
+    `step_over_floor` compares the timed step with it."""
+    out = {'buffer_bytes': nbytes, 'walkers_per_pass': walkers}
+    floor_us = 0.0
+    for name, passes in (('write', 1), ('read_write', 2), ('read', 1)):
+        us = engine.debug_sweep(name, nbytes, reps, device)
+        out[name + '_us'] = us
+        out[name + '_GBps'] = passes * nbytes / us / 1e3
+        floor_us += us
+    out['pass_floor_us'] = floor_us
+    out['step_us_per_pass'] = walkers / rate_gpu * 1e6
+    out['step_over_floor'] = out['step_us_per_pass'] / floor_us
+    out['note'] = ('plain write / in-place read-modify-write / read sweeps over one pass of T (which the '
+                   'library sizes for the Infinity Cache), timed with HIP events inside the library')
+    return out
+
+
 def small_ensembles(eng, args, torch, dev, theta_dev, out_dev, stream):
     """Half-steps of the reference's default ensembles (chains = 2 P + 2, psfMC/fitting.py:
     52-53 -> 11 and 19 walkers per half-step for 10 / 18 parameters) and a few more: device
@@ -529,6 +550,11 @@ def main():
                 model.log_posterior_batch(theta)
             line['host_path_evals_per_s'] = args.walkers * 5 / (time.perf_counter() - t0)
             line['small_ensembles'] = small_ensembles(eng, args, torch, dev, theta_dev[0], out[0], stream)
+            if args.backend == 'fused':
+                per_pass = eng.pass_size(args.walkers)
+                t_bytes = 2 * (args.size // 2 + 1) * args.size * 16
+                from psfmc_amd import engine as engine_mod
+                line['sweep_ceiling'] = sweep_ceiling(engine_mod, local, t_bytes * per_pass, per_pass, rate_gpu)
             if args.backend == 'fused' and args.size in (64, 128, 256, 512, 1024):
                 # opt-in storage mode, NOT the headline: complex64 half-spectra between the kernels,
                 # fp64 arithmetic (include/psfmc_hip.h "storage_f32")

@@ -281,6 +281,14 @@ double psfmc_get_option(const psfmc_ctx* ctx, const char* key);
  */
 int psfmc_debug_math(int device, int op, int n, const double* in, double* out);
 
+/*
+ * Diagnostic hook: time `reps` plain sweeps over a scratch buffer of nbytes (>= 1 MiB) -- mode 0
+ * every byte written once, 1 read and written back in place, 2 read once: the memory traffic of
+ * the three kernels of a pass without their arithmetic.  *us_per_sweep = average microseconds.
+ * bench.py reports them beside the timed step ("sweep_ceiling").
+ */
+int psfmc_debug_sweep(int device, int mode, size_t nbytes, int reps, double* us_per_sweep);
+
 /* message of the last failing call on this thread ("" if none) */
 const char* psfmc_last_error(void);
 

@@ -1673,6 +1673,60 @@ __global__ void k_debug_math(int op, int n, const double* __restrict__ in, doubl
              : op == 4 ? fast_exp2_noclamp(x) : fast_log2_tab(x, tab[threadIdx.x >> 6]);
 }
 
+// ---------------------------------------------------------------------------
+// Diagnostic: the plain memory sweeps the three kernels of a pass correspond to (no arithmetic),
+// timed with HIP events -- what this GPU gives the data flow at best.  mode 0: every 16 bytes
+// written once (k_rows_fwd), 1: read and written back in place (k_cols), 2: read once (k_rows_inv).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_sweep(double2* __restrict__ buf, size_t n, int mode, double* __restrict__ sink) {
+    const size_t stride = (size_t)gridDim.x * 1024;
+    double s = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i + 768 < n; i += stride) {
+        if (mode == 0) {
+            const double2 v = {1.0, 2.0};
+            buf[i] = v; buf[i + 256] = v; buf[i + 512] = v; buf[i + 768] = v;
+        } else {
+            double2 a = buf[i], b = buf[i + 256], c = buf[i + 512], d = buf[i + 768];
+            if (mode == 1) {
+                a.x += 1.0; b.x += 1.0; c.x += 1.0; d.x += 1.0;
+                buf[i] = a; buf[i + 256] = b; buf[i + 512] = c; buf[i + 768] = d;
+            } else {
+                s += a.x + b.x + c.x + d.x;
+            }
+        }
+    }
+    if (s == 12345.678) sink[0] = s;            // keeps the loads of mode 2
+}
+
+extern "C" int psfmc_debug_sweep(int device, int mode, size_t nbytes, int reps, double* us_per_sweep) {
+    if (mode < 0 || mode > 2 || nbytes < (1u << 20) || reps < 1 || !us_per_sweep) return fail(PSFMC_EINVAL, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    double2* buf = nullptr;
+    double* sink = nullptr;
+    HIP_TRY(hipMalloc(&buf, nbytes));
+    int rc = PSFMC_OK;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (hipMalloc(&sink, 64) != hipSuccess || hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+        rc = fail(PSFMC_ENOMEM, "hipMalloc / hipEventCreate");
+    } else {
+        (void)hipMemset(buf, 0, nbytes);
+        const size_t n = nbytes / sizeof(double2);
+        for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k_sweep, dim3(2048), dim3(256), 0, 0, buf, n, mode, sink);
+        (void)hipEventRecord(a, 0);
+        for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_sweep, dim3(2048), dim3(256), 0, 0, buf, n, mode, sink);
+        (void)hipEventRecord(b, 0);
+        float ms = 0.f;
+        if (hipEventSynchronize(b) != hipSuccess || hipEventElapsedTime(&ms, a, b) != hipSuccess)
+            rc = fail(PSFMC_EHIP, "sweep failed: %s", hipGetErrorString(hipGetLastError()));
+        *us_per_sweep = (double)ms * 1e3 / reps;
+    }
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+    if (sink) (void)hipFree(sink);
+    (void)hipFree(buf);
+    return rc;
+}
+
 extern "C" int psfmc_debug_math(int device, int op, int n, const double* in, double* out) {
     if (n < 0 || op < 0 || op > 5 || (n > 0 && (!in || !out))) return fail(PSFMC_EINVAL, "bad argument");
     if (n == 0) return PSFMC_OK;

@@ -146,6 +146,8 @@ def load_library():
     lib.psfmc_group_eval_theta.argtypes = [vp, ci, _c_double_p, _c_double_p, _c_double_p]
     lib.psfmc_debug_math.restype = ci
     lib.psfmc_debug_math.argtypes = [ci, ci, ci, _c_double_p, _c_double_p]
+    lib.psfmc_debug_sweep.restype = ci
+    lib.psfmc_debug_sweep.argtypes = [ci, ci, ctypes.c_size_t, ci, _c_double_p]
     if lib.psfmc_abi_version() != 1:
         raise ImportError('libpsfmc_hip ABI version mismatch')
     _lib = lib
@@ -171,6 +173,18 @@ def debug_math(op, values, device=0):
     if rc != 0:
         raise NativeError(rc, lib.psfmc_last_error().decode('utf-8', 'replace'))
     return out.reshape(np.shape(values))
+
+
+def debug_sweep(mode, nbytes, reps=20, device=0):
+    """Average microseconds of a plain memory sweep over `nbytes` of scratch ('write', 'read_write',
+    'read'): the traffic of the three kernels of a pass without their arithmetic (measurement hook)."""
+    lib = load_library()
+    us = ctypes.c_double(0.0)
+    rc = lib.psfmc_debug_sweep(int(device), {'write': 0, 'read_write': 1, 'read': 2}[mode], int(nbytes), int(reps),
+                               ctypes.byref(us))
+    if rc != 0:
+        raise NativeError(rc, lib.psfmc_last_error().decode('utf-8', 'replace'))
+    return us.value
 
 
 class Context(object):
