@@ -277,7 +277,7 @@ double psfmc_get_option(const psfmc_ctx* ctx, const char* key);
 /*
  * Diagnostic hook: evaluate one of the library's fp64 device functions on n host
  * values (op 0 log2, 1 exp2, 2 reciprocal, 3 single-Newton reciprocal, 4 exp2 without
- * clamp, 5 the rasteriser's table-driven log2) so tests can check the hand-written elementary functions of the rasteriser against numpy.
+ * clamp, 5 the rasteriser's table-driven log2, 6 exp2 with the lower clamp only) so tests can check the hand-written elementary functions of the rasteriser against numpy.
  */
 int psfmc_debug_math(int device, int op, int n, const double* in, double* out);
 

@@ -239,30 +239,31 @@ __device__ __forceinline__ double fast_log2(double x) {
     return __builtin_fma(s, p, (double)e);
 }
 
-// log2(x) for the rasteriser, x > 0 finite: x = 2^e m, m in [1/2, 1); the top seven fraction bits
-// of m pick {a_j, b_j} from a 128-entry table in LDS with |m a_j - 1| <= 2^-8 and b_j = -log2(a_j):
+// log2(x) for the rasteriser, x > 0 finite: x = 2^e m, m in [1/2, 1); the top eight fraction bits
+// of m pick {a_j, b_j} from a 256-entry table in LDS with |m a_j - 1| <= 2^-9 and b_j = -log2(a_j):
 //   log2(x) = e + b_j + log2(1 + r),  r = fma(m, a_j, -1)  (one rounding)
-// 14 instructions and one 16-byte LDS read against the 27 instructions of fast_log2.  ABSOLUTE
+// 13 instructions and one 16-byte LDS read against the 27 instructions of fast_log2.  ABSOLUTE
 // accuracy ~1e-16 + one rounding of the sum, which is what its only consumer, 2^(p log2 rho^2),
 // needs (no relative accuracy near x = 1).  (The same table read from global memory made the
 // rasteriser slower, see fast_log2.)  psfmc_log_table.h is generated by tools/gen_log_table.py.
-constexpr int kLogTabBytes = 128 * 16;
-// copy the table into a wave's LDS (lanes 0..63 bring two entries each); converged call
+constexpr int kLogTabBytes = 256 * 16;
+// copy the table into a wave's LDS (lanes 0..63 bring four entries each); converged call
 __device__ __forceinline__ void load_log_table(double* __restrict__ lds, int lane) {
     const double2* src = reinterpret_cast<const double2*>(&kLog2Tab[0][0]);
     double2* dst = reinterpret_cast<double2*>(lds);
-    const double2 a = src[lane], b = src[lane + 64];
+    const double2 a = src[lane], b = src[lane + 64], c = src[lane + 128], d = src[lane + 192];
     dst[lane] = a;
     dst[lane + 64] = b;
+    dst[lane + 128] = c;
+    dst[lane + 192] = d;
 }
 __device__ __forceinline__ double fast_log2_tab(double x, const double* __restrict__ tab) {
     const int e = __builtin_amdgcn_frexp_exp(x);
     const double m = __builtin_amdgcn_frexp_mant(x);            // [0.5, 1)
-    const unsigned off = ((unsigned)__double2hiint(m) >> 9) & 0x7f0u;   // 16 j
+    const unsigned off = ((unsigned)__double2hiint(m) >> 8) & 0xff0u;   // 16 j
     const double2 ab = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(tab) + off);
     const double r = __builtin_fma(m, ab.x, -1.0);
-    double p = kLog2Poly[5];
-    p = __builtin_fma(p, r, kLog2Poly[4]);
+    double p = kLog2Poly[4];
     p = __builtin_fma(p, r, kLog2Poly[3]);
     p = __builtin_fma(p, r, kLog2Poly[2]);
     p = __builtin_fma(p, r, kLog2Poly[1]);
@@ -283,6 +284,15 @@ __device__ __forceinline__ double fast_exp2_noclamp(double y) {
 // brightness factor need not carry it.
 __device__ __forceinline__ double fast_exp2(double y) {
     y = __builtin_fmin(__builtin_fmax(y, -1100.0), 1100.0);
+    const double n = __builtin_rint(y);
+    return __builtin_amdgcn_ldexp(fast_exp2_poly(y - n), (int)n);
+}
+
+// 2^y for the rasteriser's brightness factor: y = kappa log2(e) (1 - t) is bounded above by the walker's
+// kappa log2(e) (<= a few hundred: the result may legitimately overflow to inf like the reference's exp),
+// so only the lower clamp is needed (-inf and NaN give 0 as in fast_exp2)
+__device__ __forceinline__ double fast_exp2_floor(double y) {
+    y = __builtin_fmax(y, -1100.0);
     const double n = __builtin_rint(y);
     return __builtin_amdgcn_ldexp(fast_exp2_poly(y - n), (int)n);
 }
@@ -363,7 +373,7 @@ __device__ __forceinline__ void raster_row(const double* __restrict__ prep, int 
             const double rho2 = __builtin_fma(u, u, v * v);
             const double d2 = __builtin_fma(dx, dx, dy2);
             const double tt = fast_exp2_noclamp(pw * fast_log2_tab(rho2, log_tab));
-            const double sb = fast_exp2(__builtin_fma(nkl, tt, -nkl));
+            const double sb = fast_exp2_floor(__builtin_fma(nkl, tt, -nkl));
             // g^2 q / 12 = (gk t)^2 / rho2 * rho2 / d2: the elliptical radius cancels
             const double gt = gk * tt;
             r[k] = __builtin_fma(sbeff * sb, __builtin_fma(gt * gt, fast_rcp1(d2), 1.0), r[k]);

@@ -1670,7 +1670,7 @@ __global__ void k_debug_math(int op, int n, const double* __restrict__ in, doubl
     if (i >= n) return;
     const double x = in[i];
     out[i] = op == 0 ? fast_log2(x) : op == 1 ? fast_exp2(x) : op == 2 ? fast_rcp(x) : op == 3 ? fast_rcp1(x)
-             : op == 4 ? fast_exp2_noclamp(x) : fast_log2_tab(x, tab[threadIdx.x >> 6]);
+             : op == 4 ? fast_exp2_noclamp(x) : op == 5 ? fast_log2_tab(x, tab[threadIdx.x >> 6]) : fast_exp2_floor(x);
 }
 
 // ---------------------------------------------------------------------------
@@ -1728,7 +1728,7 @@ extern "C" int psfmc_debug_sweep(int device, int mode, size_t nbytes, int reps, 
 }
 
 extern "C" int psfmc_debug_math(int device, int op, int n, const double* in, double* out) {
-    if (n < 0 || op < 0 || op > 5 || (n > 0 && (!in || !out))) return fail(PSFMC_EINVAL, "bad argument");
+    if (n < 0 || op < 0 || op > 6 || (n > 0 && (!in || !out))) return fail(PSFMC_EINVAL, "bad argument");
     if (n == 0) return PSFMC_OK;
     HIP_TRY(hipSetDevice(device));
     double *d_in = nullptr, *d_out = nullptr;

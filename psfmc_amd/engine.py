@@ -164,9 +164,9 @@ def _f64(arr):
 
 def debug_math(op, values, device=0):
     """Evaluate a device elementary function ('log2', 'exp2', 'rcp', 'rcp1',
-    'exp2_noclamp', 'log2_tab') on an array (test hook for the rasteriser's hand-written fp64 math)."""
+    'exp2_noclamp', 'log2_tab', 'exp2_floor') on an array (test hook for the rasteriser's hand-written fp64 math)."""
     lib = load_library()
-    code = {'log2': 0, 'exp2': 1, 'rcp': 2, 'rcp1': 3, 'exp2_noclamp': 4, 'log2_tab': 5}[op]
+    code = {'log2': 0, 'exp2': 1, 'rcp': 2, 'rcp1': 3, 'exp2_noclamp': 4, 'log2_tab': 5, 'exp2_floor': 6}[op]
     x = _f64(np.ravel(values))
     out = np.empty_like(x)
     rc = lib.psfmc_debug_math(int(device), code, x.size, _dp(x), _dp(out))

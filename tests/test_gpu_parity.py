@@ -200,7 +200,7 @@ def test_device_math():
     assert engine.debug_math('log2', np.array([1.0]))[0] == 0.0
     # the rasteriser's table-driven log2: ABSOLUTE accuracy is its contract (it feeds 2^(p log2 x)):
     # one ulp of the result's magnitude (observed 2.2e-16 scaled, the same as the table-free log2)
-    edges = 2.0 ** rng.randint(-30, 30, 512) * (1.0 + rng.randint(0, 128, 512) / 128.0)     # table cell borders
+    edges = 2.0 ** rng.randint(-30, 30, 512) * (1.0 + rng.randint(0, 256, 512) / 256.0)     # table cell borders
     xt = np.concatenate([x, edges, np.nextafter(edges, 0), np.nextafter(edges, np.inf)])
     got = engine.debug_math('log2_tab', xt)
     ref = np.log2(xt.astype(np.longdouble)).astype(np.float64)
@@ -219,6 +219,9 @@ def test_device_math():
     fin = np.abs(y) < 1000
     assert np.array_equal(engine.debug_math('exp2_noclamp', y[fin]), got[fin])
     assert np.isnan(engine.debug_math('exp2_noclamp', np.array([np.nan]))[0])
+    # the brightness factor's variant (lower clamp only): the same bits up to overflow, inf beyond
+    assert np.array_equal(engine.debug_math('exp2_floor', y), got)
+    assert engine.debug_math('exp2_floor', np.array([1500.0, np.nan])).tolist() == [np.inf, 0.0]
 
     z = 10.0 ** rng.uniform(-200, 200, 20000)
     assert np.max(np.abs(engine.debug_math('rcp', z) * z - 1.0)) <= 4e-16

@@ -20,18 +20,9 @@ run write WRITE_SIZE
 # guide's FETCH_SIZE x 2 rule (which assumes every read request is a 128-B one)
 run rdreq TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum
 run wrreq TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum
-python3 - <<PY
-import csv, glob, collections
-for name in ['sq1','sq2','fetch','write','rdreq','wrreq']:
-    files = glob.glob('$OUT/%s/*/*counter_collection.csv' % name)
-    if not files: print(name, 'no output'); continue
-    agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
-    for r in csv.DictReader(open(files[0])):
-        k = r['Kernel_Name'].split('(')[0].replace('void psfmc::','')
-        agg[k][r['Counter_Name']] += float(r['Counter_Value'])
-        cnt[(k, r['Counter_Name'])] += 1
-    for k in sorted(agg):
-        if k.startswith(('k_rows_fwd<', 'k_rows_inv<', 'k_theta_prep', 'k_finish')) and ', true' not in k \
-                or k.startswith('k_cols') and ', true' in k:
-            print(name, k, {c: '%.4g' % (v / cnt[(k, c)]) for c, v in agg[k].items()})
-PY
+args=""
+for name in sq1 sq2 fetch write rdreq wrreq; do
+  f=$(ls $OUT/$name/*/*counter_collection.csv 2>/dev/null | head -1)
+  args="$args $name=${f:-missing}"
+done
+python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $args
