@@ -134,6 +134,8 @@ struct psfmc_ctx {
     hipStream_t side[kMaxStreams] = {nullptr, nullptr, nullptr, nullptr};   // side[0] unused
     hipEvent_t ev_fork = nullptr, ev_join[kMaxStreams] = {nullptr, nullptr, nullptr, nullptr};
     int n_streams = 2;
+    int stagger = 0;          // the second lane starts one forward-row kernel late (run_pipeline); set per shape
+    hipEvent_t ev_stagger = nullptr;
     bool t_f32 = false;       // T stored as complex64 (set_option "storage_f32"); arithmetic stays fp64
     bool plain_shape = false; // both sides power-of-two shapes (what storage_f32 is built for)
     bool row_fast = false;    // nx a power-of-two shape and ny a whole number of its row workgroups
@@ -420,18 +422,20 @@ static void prof_collect(psfmc_ctx* c) {
 
 // rasterise + both convolutions of `n` walkers; results stay in d_T (spectral
 // rows after the column pass).  rows_inv is launched by the caller.
-static int fused_forward(psfmc_ctx* c, int n, cd* Tbuf, const double* prep, const uint8_t* skip,
-                         int ps_only, double* raw_out, hipStream_t st) {
-    {
-        ProfScope ps(c, PROF_ROWS_FWD, st);
-        if (c->t_f32) {
-            DISPATCH_LEN(c->nx, RC_TRY((launch_rows_fwd<N_, false, cf>(c, n, prep, skip, Tbuf, ps_only, nullptr,
-                                                                       nullptr, raw_out, st))));
-        } else {
-            DISPATCH_LEN(c->nx, RC_TRY((launch_rows_fwd<N_, false>(c, n, prep, skip, Tbuf, ps_only, nullptr,
+static int fused_rows_fwd(psfmc_ctx* c, int n, cd* Tbuf, const double* prep, const uint8_t* skip,
+                          int ps_only, double* raw_out, hipStream_t st) {
+    ProfScope ps(c, PROF_ROWS_FWD, st);
+    if (c->t_f32) {
+        DISPATCH_LEN(c->nx, RC_TRY((launch_rows_fwd<N_, false, cf>(c, n, prep, skip, Tbuf, ps_only, nullptr,
                                                                    nullptr, raw_out, st))));
-        }
+    } else {
+        DISPATCH_LEN(c->nx, RC_TRY((launch_rows_fwd<N_, false>(c, n, prep, skip, Tbuf, ps_only, nullptr,
+                                                               nullptr, raw_out, st))));
     }
+    return PSFMC_OK;
+}
+
+static int fused_cols(psfmc_ctx* c, int n, cd* Tbuf, const double* prep, const uint8_t* skip, hipStream_t st) {
     ProfScope ps(c, PROF_COLS, st);
     if (c->t_f32) {
         DISPATCH_LEN(c->ny, RC_TRY((launch_cols<N_, true, cf>(c, Tbuf, n, prep, skip, st))));
@@ -439,6 +443,12 @@ static int fused_forward(psfmc_ctx* c, int n, cd* Tbuf, const double* prep, cons
         DISPATCH_LEN(c->ny, RC_TRY((launch_cols<N_, true>(c, Tbuf, n, prep, skip, st))));
     }
     return PSFMC_OK;
+}
+
+static int fused_forward(psfmc_ctx* c, int n, cd* Tbuf, const double* prep, const uint8_t* skip,
+                         int ps_only, double* raw_out, hipStream_t st) {
+    RC_TRY(fused_rows_fwd(c, n, Tbuf, prep, skip, ps_only, raw_out, st));
+    return fused_cols(c, n, Tbuf, prep, skip, st);
 }
 
 static int fused_inverse(psfmc_ctx* c, int n, const cd* Tbuf, const double* prep, const uint8_t* skip,
@@ -513,6 +523,7 @@ static int ctx_init(psfmc_ctx* c, const double* sci, const double* obs_var, cons
                     int psf_ny, int psf_nx, const double* psf, const double* psf_var) {
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_stagger, hipEventDisableTiming));
     for (int i = 1; i < psfmc_ctx::kMaxStreams; ++i) {
         HIP_TRY(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
@@ -642,6 +653,10 @@ extern "C" int psfmc_ctx_create(psfmc_ctx** out, int device, int ny, int nx, con
         c->plain_shape = rs.plain && cs.plain;
         c->cols_grid = prop.multiProcessorCount * 2;
         c->chunk = fused_pass_walkers(c);
+        // measured (gpurun_out/stag*_quick.txt, same-box A/B): 64^2 +2.7 %, 128^2 +1.7 %, 256^2 +4.6 %
+        // (+3.8 % with two Sersics); 384^2 -0.4 %, 512^2 -1.3...-2.5 %, 1024^2 0, 200^2 -1.6 %, 300^2 -7.7 %,
+        // 400^2 -10.6 %: on for the small power-of-two shapes only
+        c->stagger = (c->plain_shape && c->row_fast && nx <= 256 && ny <= 256) ? 1 : 0;
     } else {
         c->nblk = (c->S + 1023) / 1024;
         if (c->nblk > 64) c->nblk = 64;
@@ -690,6 +705,7 @@ extern "C" int psfmc_ctx_destroy(psfmc_ctx* c) {
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_stagger) (void)hipEventDestroy(c->ev_stagger);
     delete c;
     return PSFMC_OK;
 }
@@ -731,6 +747,10 @@ extern "C" int psfmc_set_option(psfmc_ctx* c, const char* key, double value) {
     if (!strcmp(key, "cols_grid")) {
         if (value < 1) return fail(PSFMC_EINVAL, "cols_grid must be >= 1");
         c->cols_grid = (int)value;
+        return PSFMC_OK;
+    }
+    if (!strcmp(key, "stagger")) {
+        c->stagger = (int)value;
         return PSFMC_OK;
     }
     if (!strcmp(key, "cols3")) {
@@ -783,6 +803,7 @@ extern "C" double psfmc_get_option(const psfmc_ctx* cc, const char* key) {
     if (!strcmp(key, "max_walkers")) return c->max_walkers;
     if (!strcmp(key, "cols_grid")) return c->cols_grid;
     if (!strcmp(key, "streams")) return c->n_streams;
+    if (!strcmp(key, "stagger")) return c->stagger;
     return NAN;
 }
 
@@ -860,7 +881,19 @@ static int run_pipeline(psfmc_ctx* c, int W, const uint8_t* d_skip, hipStream_t 
             const int lane = pass % lanes;
             hipStream_t s = lane ? c->side[lane] : st;
             cd* Tbuf = c->d_Ts[lane];
-            RC_TRY(fused_forward(c, n, Tbuf, prep, skip, 0, nullptr, s));
+            if (c->stagger && lanes == 2 && npass >= 8 && pass == 0) {
+                // start the second lane one forward-row kernel late, so that its VALU-bound kernel
+                // meets this lane's memory-bound ones instead of this lane's own copy of it (the idle
+                // start costs about half a kernel per batch: worth it from ~8 passes on; 4 passes of
+                // 64 walkers ran 249 instead of 235 us with it)
+                RC_TRY(fused_rows_fwd(c, n, Tbuf, prep, skip, 0, nullptr, s));
+                if (c->stagger > 1) RC_TRY(fused_cols(c, n, Tbuf, prep, skip, s));
+                HIP_TRY(hipEventRecord(c->ev_stagger, s));
+                HIP_TRY(hipStreamWaitEvent(c->side[1], c->ev_stagger, 0));
+                if (c->stagger == 1) RC_TRY(fused_cols(c, n, Tbuf, prep, skip, s));
+            } else {
+                RC_TRY(fused_forward(c, n, Tbuf, prep, skip, 0, nullptr, s));
+            }
             RC_TRY(fused_inverse(c, n, Tbuf, prep, skip, partial, nullptr, nullptr, s));
         } else {
             RC_TRY(hipfft_convolve(c, n, prep, skip, st, 0));
