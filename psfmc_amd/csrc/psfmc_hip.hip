@@ -135,7 +135,7 @@ struct psfmc_ctx {
     hipEvent_t ev_fork = nullptr, ev_join[kMaxStreams] = {nullptr, nullptr, nullptr, nullptr};
     int n_streams = 2;
     int stagger = 0;          // the second lane starts one forward-row kernel late (run_pipeline); set per shape
-    hipEvent_t ev_stagger = nullptr;
+    hipEvent_t ev_stagger[kMaxStreams] = {nullptr, nullptr, nullptr, nullptr};
     bool t_f32 = false;       // T stored as complex64 (set_option "storage_f32"); arithmetic stays fp64
     bool plain_shape = false; // both sides power-of-two shapes (what storage_f32 is built for)
     bool row_fast = false;    // nx a power-of-two shape and ny a whole number of its row workgroups
@@ -523,7 +523,7 @@ static int ctx_init(psfmc_ctx* c, const double* sci, const double* obs_var, cons
                     int psf_ny, int psf_nx, const double* psf, const double* psf_var) {
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&c->ev_stagger, hipEventDisableTiming));
+    for (int i = 0; i < psfmc_ctx::kMaxStreams; ++i) HIP_TRY(hipEventCreateWithFlags(&c->ev_stagger[i], hipEventDisableTiming));
     for (int i = 1; i < psfmc_ctx::kMaxStreams; ++i) {
         HIP_TRY(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
@@ -705,7 +705,8 @@ extern "C" int psfmc_ctx_destroy(psfmc_ctx* c) {
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_stagger) (void)hipEventDestroy(c->ev_stagger);
+    for (int i = 0; i < psfmc_ctx::kMaxStreams; ++i)
+        if (c->ev_stagger[i]) (void)hipEventDestroy(c->ev_stagger[i]);
     delete c;
     return PSFMC_OK;
 }
@@ -881,16 +882,15 @@ static int run_pipeline(psfmc_ctx* c, int W, const uint8_t* d_skip, hipStream_t 
             const int lane = pass % lanes;
             hipStream_t s = lane ? c->side[lane] : st;
             cd* Tbuf = c->d_Ts[lane];
-            if (c->stagger && lanes == 2 && npass >= 8 && pass == 0) {
-                // start the second lane one forward-row kernel late, so that its VALU-bound kernel
+            if (c->stagger && lanes >= 2 && npass >= 8 && pass < lanes - 1) {
+                // start the next lane one forward-row kernel late, so that its VALU-bound kernel
                 // meets this lane's memory-bound ones instead of this lane's own copy of it (the idle
                 // start costs about half a kernel per batch: worth it from ~8 passes on; 4 passes of
                 // 64 walkers ran 249 instead of 235 us with it)
                 RC_TRY(fused_rows_fwd(c, n, Tbuf, prep, skip, 0, nullptr, s));
-                if (c->stagger > 1) RC_TRY(fused_cols(c, n, Tbuf, prep, skip, s));
-                HIP_TRY(hipEventRecord(c->ev_stagger, s));
-                HIP_TRY(hipStreamWaitEvent(c->side[1], c->ev_stagger, 0));
-                if (c->stagger == 1) RC_TRY(fused_cols(c, n, Tbuf, prep, skip, s));
+                HIP_TRY(hipEventRecord(c->ev_stagger[pass], s));
+                HIP_TRY(hipStreamWaitEvent(c->side[pass + 1], c->ev_stagger[pass], 0));
+                RC_TRY(fused_cols(c, n, Tbuf, prep, skip, s));
             } else {
                 RC_TRY(fused_forward(c, n, Tbuf, prep, skip, 0, nullptr, s));
             }
