@@ -288,7 +288,11 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
             const int k = fft_k_of<NX>(t, e);
             if (row_on && fft_slot_valid<NX>(t, e) && 2 * k <= NX) {
                 const cd zk = v[e];
-                const cd zm = (k == 0 || 2 * k == NX) ? zk : ubuf[k];
+                // (a select between the register and the LDS slot itself became a pointer select
+                // through scratch and a flat load: read a valid slot always, select the value)
+                const bool self = k == 0 || 2 * k == NX;
+                cd zm = ubuf[self ? 1 : k];
+                if (self) zm = zk;
                 TS* o = at_bytes(wbase, off_row + (unsigned)k * kstride);
                 o[0] = cd{zk.x + zm.x, zk.y - zm.y};
                 o[RGL] = cd{zk.y + zm.y, zm.x - zk.x};
@@ -438,7 +442,32 @@ k_cols(TS* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restric
             }
         }
     };
-    if constexpr (PF) {
+    if constexpr (PF && sizeof(TS) != sizeof(cd)) {
+        // single-precision storage: the next group waits in its raw complex64 form (half the
+        // registers of a second fp64 set, which spilled: 108 bytes of scratch per lane at 256),
+        // and is widened into the one fp64 working set when its turn comes
+        static_assert(S::kPlain, "single-precision storage is built for the power-of-two shapes");
+        TS raw[R];
+        cd v[R];
+        Slot cur{Tbuf, 0, 0, 0, false}, nxt{Tbuf, 0, 0, 0, false};
+        auto load_raw = [&](int grp, Slot& sl) {
+            sl.base = locate(grp, sl.w, sl.kx, sl.c, sl.active);
+            const TS* b0 = sl.base + row_off(t);
+#pragma unroll
+            for (int a = 0; a < P; ++a) raw[a] = b0[2 * T * a];
+        };
+        if (gr.first < gr.end) load_raw(gr.first, nxt);
+        for (int grp = gr.first; grp < gr.end; grp += gr.step) {
+            cur = nxt;
+#pragma unroll
+            for (int a = 0; a < R; ++a) v[a] = cd{(double)raw[a].x, (double)raw[a].y};
+            transform(v, cur, [&] {
+                __builtin_amdgcn_sched_barrier(0);
+                if (grp + gr.step < gr.end) load_raw(grp + gr.step, nxt);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+    } else if constexpr (PF) {
         // two register sets take turns (no copies): while one is transformed the other
         // receives the next group
         cd A[R], B[R];
