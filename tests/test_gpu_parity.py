@@ -185,6 +185,18 @@ def test_caller_rows_with_a_wild_psf_index_are_clamped(models, backend):
         assert np.isfinite(imgs['convolved_model']).all()
 
 
+def test_debug_sweep_reports_plausible_rates():
+    """psfmc_debug_sweep (bench.py's `sweep_ceiling`): the three plain sweeps over 64 MiB finish, and
+    at rates an MI355X can have (between 1 and 30 TB/s: the buffer may sit in the Infinity Cache)."""
+    from psfmc_amd import engine
+    nbytes = 64 << 20
+    for mode, passes in (('write', 1), ('read_write', 2), ('read', 1)):
+        us = engine.debug_sweep(mode, nbytes, reps=5)
+        assert 1e3 < passes * nbytes / us / 1e3 < 3e4, (mode, us)
+    with pytest.raises(engine.NativeError):
+        engine.debug_sweep('read', 1024)                     # below the 1 MiB minimum
+
+
 def test_device_math():
     """The rasteriser's hand-written fp64 log2 / exp2 / reciprocals vs numpy."""
     from psfmc_amd import engine
