@@ -98,6 +98,30 @@ def test_config3_and_config4_share_at_full_batch(n_side, n_sersic, n_w):
     model.close()
 
 
+def test_config5_share_eight_fields_of_256_walkers():
+    """BASELINE config 5's per-GPU share at full size: 8 independent 256^2 fields, one context each,
+    256 walkers per field (`bench.py --fields 8 --walkers 256`): two walkers of every field against
+    the oracle, results independent of the order the fields are evaluated in."""
+    from test_gpu_fullsize import make_model
+    models = [make_model(256, 1, 'fused', max_walkers=256, seed=s) for s in range(8)]
+    thetas = [synth_field.draw_walkers(256, 1, 256, seed=70 + i, near_truth=fld['truth'])
+              for i, (_, fld) in enumerate(models)]
+    outs = [m.log_posterior_batch(t) for (m, _), t in zip(models, thetas)]
+    layout = helpers.synth_layout(1)
+    for (model, fld), theta, got in zip(models, thetas, outs):
+        assert np.isfinite(got).all()
+        field = orc.make_field(fld['sci'], fld['ivm'], [fld['psf']], [fld['psf_ivm']], mag_zp=fld['mag_zp'])
+        pick = [0, 255]
+        prior = model.log_priors_batch(theta[pick])
+        for i, p in zip(pick, prior):
+            want = helpers.oracle_loglike(field, layout, theta[i]) + p
+            assert abs(got[i] - want) <= 1e-10 * abs(want), (i, got[i], want)
+    for k in reversed(range(8)):                         # interleaved contexts do not disturb each other
+        assert np.array_equal(models[k][0].log_posterior_batch(thetas[k]), outs[k])
+    for model, _ in models:
+        model.close()
+
+
 def test_device_group_splits_walkers_over_devices(tmp_path):
     """psfmc_group_* (one process, several devices): with the one GPU of the test box listed
     twice the walkers are split over two contexts; results equal the single context's bit for
