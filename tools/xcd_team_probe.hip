@@ -28,15 +28,21 @@ __device__ __forceinline__ int xcc_id() {
     return (int)(id & 0xf);
 }
 
+// VAR: how a consumer makes sure it sees the team's stores -- 0: plain loads after `buffer_inv sc0`,
+// 1: plain loads after `buffer_inv sc1`, 2: loads with the sc1 (agent-scope) bit, no invalidate;
+// SLEEP: s_sleep argument between polls; LOCAL: poll with a workgroup-scope RMW (performed at the L2)
 // all lanes of the wave call; returns false when the spin cap was hit
+template <int VAR, int SLEEP, bool LOCAL>
 __device__ __forceinline__ bool team_barrier(int* bar, int target, Ctl* ctl, long long& polls) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     bool ok = true;
     if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (LOCAL) __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         long long n = 0;
-        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(2);
+        while ((LOCAL ? __hip_atomic_fetch_add(bar, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                      : __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
+            __builtin_amdgcn_s_sleep(SLEEP);
             if (++n > kSpinCap || __hip_atomic_load(&ctl->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                 __hip_atomic_store(&ctl->abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok = false;
@@ -46,7 +52,8 @@ __device__ __forceinline__ bool team_barrier(int* bar, int target, Ctl* ctl, lon
         polls += n;
     }
     ok = __shfl((int)ok, 0, 64) != 0;
-    asm volatile("buffer_inv sc0" ::: "memory");           // drop this CU's L1 lines
+    if (VAR == 0) asm volatile("buffer_inv sc0" ::: "memory");
+    if (VAR == 1) asm volatile("buffer_inv sc1" ::: "memory");
     return ok;
 }
 
@@ -61,7 +68,15 @@ __device__ __forceinline__ double filler(double x) {
     return a0 + a1 + a2 + a3;
 }
 
-template <bool FILL>
+template <int VAR>
+__device__ __forceinline__ double2 ld(const double2* p) {
+    if (VAR != 2) return *p;
+    double2 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+template <bool FILL, int VAR, int SLEEP, bool LOCAL>
 __global__ __launch_bounds__(64) void k_team(double2* __restrict__ slots, Ctl* ctl, int n_walkers, int teams_per_xcd,
                                              double* sink) {
     extern __shared__ double pad[];
@@ -89,14 +104,14 @@ __global__ __launch_bounds__(64) void k_team(double2* __restrict__ slots, Ctl* c
             const int i = rank * 1024 + k * 64 + lane;
             T[i] = double2{(double)w, (double)i};
         }
-        if (!team_barrier(bar, kTeam * (++gen), ctl, polls)) return;
+        if (!team_barrier<VAR, SLEEP, LOCAL>(bar, kTeam * (++gen), ctl, polls)) return;
         // phase 2: wave `rank` read-modify-writes a "column": 16 elements of every wave's chunk
         double2 v[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int src_wave = k * 4 + (lane >> 4);                       // 0..63
             const int i = src_wave * 1024 + rank * 16 + (lane & 15);
-            v[k] = T[i];
+            v[k] = ld<VAR>(T + i);
         }
         if (FILL) acc += filler<840>(acc);
 #pragma unroll
@@ -106,12 +121,12 @@ __global__ __launch_bounds__(64) void k_team(double2* __restrict__ slots, Ctl* c
             bad += (v[k].x != (double)w) | (v[k].y != (double)i);
             T[i] = double2{v[k].x + 1.0, v[k].y};
         }
-        if (!team_barrier(bar, kTeam * (++gen), ctl, polls)) return;
+        if (!team_barrier<VAR, SLEEP, LOCAL>(bar, kTeam * (++gen), ctl, polls)) return;
         // phase 3: wave `rank` reads its contiguous chunk back
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int i = rank * 1024 + k * 64 + lane;
-            const double2 u = T[i];
+            const double2 u = ld<VAR>(T + i);
             bad += (u.x != (double)w + 1.0) | (u.y != (double)i);
             acc += u.x;
         }
@@ -126,35 +141,42 @@ __global__ __launch_bounds__(64) void k_team(double2* __restrict__ slots, Ctl* c
     if (acc == 1.2345) sink[0] = acc;
 }
 
+template <bool FILL, int VAR, int SLEEP, bool LOCAL>
+static void run(const char* label, double2* slots, Ctl* ctl, double* sink, int n_walkers) {
+    for (int tpx : {1, 2, 4}) {
+        float best = 1e9; Ctl h;
+        for (int rep = 0; rep < 2; ++rep) {
+            hipMemset(ctl, 0, sizeof(Ctl));
+            hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+            hipDeviceSynchronize();
+            hipEventRecord(a);
+            k_team<FILL, VAR, SLEEP, LOCAL><<<8 * tpx * kTeam, 64, 20000>>>(slots, ctl, n_walkers, tpx, sink);
+            hipEventRecord(b);
+            if (hipEventSynchronize(b) != hipSuccess) { printf("launch failed\n"); exit(1); }
+            float ms; hipEventElapsedTime(&ms, a, b);
+            if (ms < best) best = ms;
+            hipMemcpy(&h, ctl, sizeof h, hipMemcpyDeviceToHost);
+        }
+        int teams = 0; for (int x = 0; x < 8; ++x) teams += h.teams_seen[x];
+        printf("%-46s filler %d teams/XCD %d  %8.3f ms = %8.0f walkers/s | teams %d/%d abort %d mismatches %lld polls/barrier %.1f\n",
+               label, (int)FILL, tpx, best, n_walkers / (best * 1e-3), teams, 8 * tpx, h.abort_flag, h.mismatches,
+               (double)h.spin_polls / ((double)teams * kTeam * 2.0 * n_walkers / (8.0 * tpx)));
+    }
+}
+
 int main(int argc, char** argv) {
     double2* slots; Ctl* ctl; double* sink;
     hipMalloc(&slots, (size_t)8 * kMaxTeams * 65536 * sizeof(double2));
     hipMalloc(&ctl, sizeof(Ctl)); hipMalloc(&sink, 64);
-    const int n_walkers = 4096;
-    for (int fill = 0; fill < 2; ++fill)
-        for (int tpx : {1, 2, 3, 4, 6, 8}) {
-            for (int lds_kb : {20, 13}) {
-                if (lds_kb == 13 && tpx < 6) continue;
-                float best = 1e9; Ctl h;
-                for (int rep = 0; rep < 3; ++rep) {
-                    hipMemset(ctl, 0, sizeof(Ctl));
-                    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-                    hipDeviceSynchronize();
-                    hipEventRecord(a);
-                    const int grid = 8 * tpx * kTeam;
-                    if (fill) k_team<true><<<grid, 64, lds_kb * 1000>>>(slots, ctl, n_walkers, tpx, sink);
-                    else k_team<false><<<grid, 64, lds_kb * 1000>>>(slots, ctl, n_walkers, tpx, sink);
-                    hipEventRecord(b);
-                    if (hipEventSynchronize(b) != hipSuccess) { printf("launch failed\n"); return 1; }
-                    float ms; hipEventElapsedTime(&ms, a, b);
-                    if (ms < best) best = ms;
-                    hipMemcpy(&h, ctl, sizeof h, hipMemcpyDeviceToHost);
-                }
-                int teams = 0; for (int x = 0; x < 8; ++x) teams += h.teams_seen[x];
-                printf("filler %d  teams/XCD %d (LDS %2d KB/wave)  %8.3f ms for %d walkers = %8.0f walkers/s  | teams formed %d of %d, abort %d, mismatches %lld, polls/wave/barrier %.1f\n",
-                       fill, tpx, lds_kb, best, n_walkers, n_walkers / (best * 1e-3), teams, 8 * tpx, h.abort_flag, h.mismatches,
-                       (double)h.spin_polls / ((double)teams * kTeam * 2.0 * n_walkers / (8.0 * tpx)));
-            }
-        }
+    const int n = 2048;
+    run<false, 0, 2, false>("plain loads + buffer_inv sc0, agent polls", slots, ctl, sink, n);
+    run<false, 1, 2, false>("plain loads + buffer_inv sc1, agent polls", slots, ctl, sink, n);
+    run<false, 2, 2, false>("sc1 loads, agent polls", slots, ctl, sink, n);
+    run<false, 1, 16, false>("buffer_inv sc1, agent polls, sleep 16", slots, ctl, sink, n);
+    run<false, 1, 2, true>("buffer_inv sc1, L2-local RMW polls", slots, ctl, sink, n);
+    run<false, 1, 16, true>("buffer_inv sc1, L2-local RMW polls, sleep 16", slots, ctl, sink, n);
+    run<false, 2, 16, true>("sc1 loads, L2-local RMW polls, sleep 16", slots, ctl, sink, n);
+    run<true, 1, 16, true>("buffer_inv sc1, L2-local RMW polls, sleep 16", slots, ctl, sink, n);
+    run<true, 2, 16, true>("sc1 loads, L2-local RMW polls, sleep 16", slots, ctl, sink, n);
     return 0;
 }
