@@ -265,7 +265,9 @@ int psfmc_reset_accumulated(psfmc_ctx* ctx);
 int psfmc_get_spectra(psfmc_ctx* ctx, double* psf_spec, double* var_spec);
 
 /* tuning knobs: "chunk_walkers" (walkers per internal pass), "streams" (passes in
- * flight, 1..4), "cols_grid", "profile" (1: time every kernel with HIP events; read
+ * flight, 1..4), "cols_grid", "stagger" (0 / 1: the second pass in flight starts one
+ * forward-row kernel after the first; default per image shape, results do not depend on it),
+ * "profile" (1: time every kernel with HIP events; read
  * back with get_option "prof_ms_rows_fwd" / "prof_n_rows_fwd", ..._cols, ..._rows_inv).
  * "storage_f32" (0 / 1, default 0): keep the fused path's intermediate half-spectra as
  * complex64 while every operation stays fp64 -- half the memory traffic; the log-posterior is
@@ -277,7 +279,8 @@ double psfmc_get_option(const psfmc_ctx* ctx, const char* key);
 /*
  * Diagnostic hook: evaluate one of the library's fp64 device functions on n host
  * values (op 0 log2, 1 exp2, 2 reciprocal, 3 single-Newton reciprocal, 4 exp2 without
- * clamp, 5 the rasteriser's table-driven log2, 6 exp2 with the lower clamp only) so tests can check the hand-written elementary functions of the rasteriser against numpy.
+ * clamp, 5 the rasteriser's table-driven log2, 6 exp2 with the lower clamp only) so tests can
+ * check the hand-written elementary functions of the rasteriser against numpy.
  */
 int psfmc_debug_math(int device, int op, int n, const double* in, double* out);
 
