@@ -188,7 +188,9 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
     constexpr int RGL2 = layout_rg_log2<NX, FAST>(), RGL = 1 << RGL2;       // rows per layout group
     extern __shared__ __align__(16) double smem[];
     const int w = blockIdx.y;
-    if (skip && skip[w]) return;
+    // the skip flag is a (wave-uniform) byte behind a vector load: tested only after the loads that
+    // do not depend on it have been issued, so that its latency is not a serial step of every wave
+    const bool skipped = skip && skip[w];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int f = lane / T, t = lane % T;
     const int yg = blockIdx.x * row_waves<NX, FAST>() + wave;
@@ -205,6 +207,7 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
 #pragma unroll
     for (int k = P; k < R; ++k) v[k] = cd{0.0, 0.0};
     if constexpr (FROM_IMAGE) {
+        if (skipped) return;
         const double* a = img + (size_t)(2 * w) * Spx + (size_t)(row_on ? iy : 0) * NX;
         const double* b = a + Spx;
         const double sc = img_scale[w];
@@ -213,6 +216,7 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
     } else {
         const double* wprep = prep + (size_t)w * prep_len(n_ps, n_sersic);   // wave-uniform
         const double mu = wprep[kPrepMu];
+        if (skipped) return;                          // a skipped walker's record may hold anything
         // the rasteriser's log2 table borrows the start of the wave's transform exchange region,
         // which is idle until the transform begins
         static_assert((size_t)RG * fft_lds_elems<NX>() * sizeof(double) >= (size_t)kLogTabBytes, "exchange region too small");
@@ -546,11 +550,12 @@ k_cols3(TS* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restri
         if (col >= n_cols) continue;                     // wave-uniform
         const int pr = col >> 1, c = col & 1;           // kx * n_w + walker, component
         const int kx = pr / n_w, w = pr - kx * n_w;
-        if (skip && skip[w]) continue;                   // wave-uniform
+        const bool skipped = skip && skip[w];            // wave-uniform; tested once the column's loads are issued
         TS* base = Tbuf + ((size_t)w * nxh + kx) * 2 * nyp + c * rg + e0;
         cd v[R1];
 #pragma unroll
         for (int a = 0; a < R1; ++a) v[a] = load_stream(base + 128 * a);
+        if (skipped) continue;
         fft_wave3<NY, -1>(v, w1, w2, twy, t, lds, w1s);
         if constexpr (CONVOLVE) {
             // keep the kernel-spectrum loads (and the next column's) out of the transform's
@@ -596,6 +601,8 @@ k_rows_inv(const TS* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
 #endif
 
     const int w = blockIdx.y;
+    // (testing the flag only after the loads of T were issued, as k_rows_fwd and k_cols3 do, made
+    // this kernel slower at 512 and 1024 -- 31.5 -> 37.7 us, 34.1 -> 41.6 us -- and left 256 unchanged)
     if (skip && skip[w]) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int f = lane / T, t = lane % T;
