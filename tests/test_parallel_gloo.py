@@ -1,12 +1,13 @@
-"""world_size-2 gloo test of the walker-sharding path (CPU; the rank-local
-evaluator is a stand-in -- the oracle -- because there is no GPU here and the
-product has no CPU path)."""
+"""gloo tests (world sizes 2 and 8 -- the node BASELINE configs 4 and 5 name) of the walker-sharding
+path (CPU; the rank-local evaluator is a stand-in -- the oracle -- because there is no GPU here and
+the product has no CPU path)."""
 import os
 import socket
 import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 import helpers
 from psfmc_amd.parallel import shard_bounds
@@ -56,7 +57,8 @@ def test_shard_bounds_cover_everything():
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_two_rank_all_gather(tmp_path):
+@pytest.mark.parametrize('world', [2, 8])
+def test_rank_group_all_gather(tmp_path, world):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / 'worker.py'
     script.write_text(WORKER % {'root': root, 'out': str(tmp_path)})
@@ -65,19 +67,21 @@ def test_two_rank_all_gather(tmp_path):
         port = s.getsockname()[1]
     env = dict(os.environ, OMP_NUM_THREADS='1')
     subprocess.check_call(
-        [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+        [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % world,
          '--master-addr', '127.0.0.1', '--master-port', str(port), str(script)],
-        env=env, timeout=300)
+        env=env, timeout=600)
     case = helpers.load_case('synth128x2')
-    r0 = np.load(tmp_path / 'rank0.npy')
-    r1 = np.load(tmp_path / 'rank1.npy')
-    assert np.array_equal(r0, r1)                      # every rank has the full vector
-    assert helpers.rel_err(r0, case['loglike_f64'][:7]) <= 1e-12
-    assert np.load(tmp_path / 'calls0.npy').tolist() == [4]
-    assert np.load(tmp_path / 'calls1.npy').tolist() == [3]
-    for r in (0, 1):
+    ranks = [np.load(tmp_path / ('rank%d.npy' % r)) for r in range(world)]
+    for r in ranks[1:]:
+        assert np.array_equal(ranks[0], r)             # every rank has the full vector
+    assert helpers.rel_err(ranks[0], case['loglike_f64'][:7]) <= 1e-12
+    # 7 walkers: contiguous blocks that differ by at most one, ranks past the walkers evaluate nothing
+    want = [shard_bounds(7, world, r) for r in range(world)]
+    for r, (lo, hi) in enumerate(want):
+        assert np.load(tmp_path / ('calls%d.npy' % r)).tolist() == ([hi - lo] if hi > lo else [])
+    for r in range(world):
         prim = np.load(tmp_path / ('prim%d.npz' % r))
-        assert int(prim['world']) == 2 and bool(prim['staged'])
+        assert int(prim['world']) == world and bool(prim['staged'])
         assert np.array_equal(prim['full'], np.arange(11) * 1.5)
-        assert np.array_equal(prim['tot'], np.full(5, 3.0))
+        assert np.array_equal(prim['tot'], np.full(5, world * (world + 1) / 2.0))
         assert int(prim['obj_rank']) == 0 and np.array_equal(prim['obj_state'], np.arange(3))
