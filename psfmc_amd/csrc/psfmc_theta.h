@@ -76,11 +76,17 @@ __device__ inline double gamma_median(double a, double tg) {
     // error of order 1e-18 x and the iteration stops there
     for (int it = 0; it < 12; ++it) {
         const double pre = igam_prefactor(a, x, tg, stirling);    // x^a e^-x / Gamma(a+1)
+        // four terms per round: their reciprocals do not depend on each other, so the dependent chain
+        // is four multiplications instead of four reciprocals (k_theta_prep is latency-bound: one
+        // lane per walker)
         double term = 1.0, sum = 1.0, ap = a;
-        for (int k = 0; k < 2000; ++k) {
-            ap += 1.0;
-            term *= x * fast_rcp(ap);
-            sum += term;
+        for (int k = 0; k < 500; ++k) {
+            const double q1 = x * fast_rcp(ap + 1.0), q2 = x * fast_rcp(ap + 2.0);
+            const double q3 = x * fast_rcp(ap + 3.0), q4 = x * fast_rcp(ap + 4.0);
+            ap += 4.0;
+            const double t1 = term * q1, t2 = t1 * q2, t3 = t2 * q3;
+            term = t3 * q4;
+            sum = (((sum + t1) + t2) + t3) + term;
             if (term < 1e-17 * sum) break;
         }
         const double f = sum * pre - 0.5;
