@@ -46,7 +46,9 @@ typedef struct psfmc_ctx psfmc_ctx;
 #define PSFMC_BACKEND_FUSED   0  /* hand-written LDS FFT fused with rasteriser / spectral multiply / chi^2.
                                     Sides: the powers of two 64..1024 and the even 5-smooth sides 96 100 120
                                     144 150 160 180 192 200 240 250 288 300 320 360 384 400 480 500 576 600
-                                    640 720 768 800 900 960 (nx and ny independently, any combination);
+                                    640 720 768 800 900 960 and, with a factor 7, 84 98 112 126 140 168 196
+                                    210 224 252 280 294 336 350 392 420 448 504 560 630 672 700 784 840 896
+                                    (nx and ny independently, any combination);
                                     psfmc_ctx_create returns PSFMC_EINVAL for any other shape */
 #define PSFMC_BACKEND_HIPFFT  1  /* batched hipFFT D2Z/Z2D between separate kernels: any even shape
                                     (psfMC/utils.py:25-32 accepts those); also the cross-check path */

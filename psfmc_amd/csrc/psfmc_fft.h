@@ -125,6 +125,32 @@ PSFMC_FFT_SHAPE(768, 24, 32)
 PSFMC_FFT_SHAPE(800, 25, 32)
 PSFMC_FFT_SHAPE(900, 30, 30)
 PSFMC_FFT_SHAPE(960, 30, 32)
+// sides with a factor 7 (round 2): the same rules
+PSFMC_FFT_SHAPE(84, 7, 12)
+PSFMC_FFT_SHAPE(98, 7, 14)
+PSFMC_FFT_SHAPE(112, 14, 8)
+PSFMC_FFT_SHAPE(126, 9, 14)
+PSFMC_FFT_SHAPE(140, 10, 14)
+PSFMC_FFT_SHAPE(168, 12, 14)
+PSFMC_FFT_SHAPE(196, 14, 14)
+PSFMC_FFT_SHAPE(210, 14, 15)
+PSFMC_FFT_SHAPE(224, 14, 16)
+PSFMC_FFT_SHAPE(252, 14, 18)
+PSFMC_FFT_SHAPE(280, 14, 20)
+PSFMC_FFT_SHAPE(294, 14, 21)
+PSFMC_FFT_SHAPE(336, 16, 21)
+PSFMC_FFT_SHAPE(350, 14, 25)
+PSFMC_FFT_SHAPE(392, 14, 28)
+PSFMC_FFT_SHAPE(420, 20, 21)
+PSFMC_FFT_SHAPE(448, 16, 28)
+PSFMC_FFT_SHAPE(504, 21, 24)
+PSFMC_FFT_SHAPE(560, 20, 28)
+PSFMC_FFT_SHAPE(630, 21, 30)
+PSFMC_FFT_SHAPE(672, 24, 28)
+PSFMC_FFT_SHAPE(700, 25, 28)
+PSFMC_FFT_SHAPE(784, 28, 28)
+PSFMC_FFT_SHAPE(840, 28, 30)
+PSFMC_FFT_SHAPE(896, 28, 32)
 #undef PSFMC_FFT_SHAPE
 
 // the output index lane t holds in register e, and whether that register holds one at all
@@ -186,8 +212,8 @@ template <int R, int K, int SIGN> __device__ __forceinline__ cd tw_mul(cd v) {
     }
 }
 
-// the radix a length-R codelet splits off first: 5, then 3, then 2
-template <int R> constexpr int dft_radix() { return R % 5 == 0 ? 5 : R % 3 == 0 ? 3 : 2; }
+// the radix a length-R codelet splits off first: 7, then 5, then 3, then 2
+template <int R> constexpr int dft_radix() { return R % 7 == 0 ? 7 : R % 5 == 0 ? 5 : R % 3 == 0 ? 3 : 2; }
 
 // in-register DFT of R points, natural order in and out
 template <int R, int SIGN, int RADIX = dft_radix<R>()> struct Dft;
@@ -272,7 +298,56 @@ template <int R, int SIGN> struct Dft<R, SIGN, 5> {
     }
 };
 
-// radix 2 (what is left once the 5s and 3s are split off: the power-of-two codelets)
+// radix 7: the same scheme; the six twiddled values pair up into sums p_j = a_j + a_(7-j) and
+// differences d_j = a_j - a_(7-j), and X[k + M q], X[k + M (7 - q)] = m_q +- i n_q with
+//   m_q = a_0 + sum_j cos(2 pi j q / 7) p_j,   n_q = SIGN sum_j sin(2 pi j q / 7) d_j
+template <int R, int SIGN> struct Dft<R, SIGN, 7> {
+    static constexpr int M = R / 7;
+    static __device__ __forceinline__ void run(cd (&v)[R]) {
+        cd s[7][M];
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+#pragma unroll
+            for (int i = 0; i < M; ++i) s[j][i] = v[7 * i + j];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) Dft<M, SIGN>::run(s[j]);
+        combine<0>(v, s);
+    }
+    template <int K>
+    static __device__ __forceinline__ void combine(cd (&v)[R], const cd (&s)[7][M]) {
+        if constexpr (K < M) {
+            constexpr double c1 = 0.62348980185873353052500488400423981063;     // cos(2 pi / 7)
+            constexpr double c2 = -0.22252093395631440428890256449679475947;    // cos(4 pi / 7)
+            constexpr double c3 = -0.90096886790241912623610231950744505116;    // cos(6 pi / 7)
+            constexpr double q1 = SIGN * 0.78183148246802980870844452667405775023;   // sin(2 pi / 7)
+            constexpr double q2 = SIGN * 0.97492791218182360701813168299393121723;   // sin(4 pi / 7)
+            constexpr double q3 = SIGN * 0.43388373911755812047576833284835875461;   // sin(6 pi / 7)
+            const cd a0 = s[0][K], a1 = tw_mul<R, K, SIGN>(s[1][K]), a2 = tw_mul<R, 2 * K, SIGN>(s[2][K]),
+                     a3 = tw_mul<R, 3 * K, SIGN>(s[3][K]), a4 = tw_mul<R, 4 * K, SIGN>(s[4][K]),
+                     a5 = tw_mul<R, 5 * K, SIGN>(s[5][K]), a6 = tw_mul<R, 6 * K, SIGN>(s[6][K]);
+            const cd p1 = cadd(a1, a6), p2 = cadd(a2, a5), p3 = cadd(a3, a4);
+            const cd d1 = csub(a1, a6), d2 = csub(a2, a5), d3 = csub(a3, a4);
+            v[K] = cadd(cadd(a0, p1), cadd(p2, p3));
+            auto mix = [](cd base, double x1, cd u1, double x2, cd u2, double x3, cd u3) {
+                return cd{__builtin_fma(x3, u3.x, __builtin_fma(x2, u2.x, __builtin_fma(x1, u1.x, base.x))),
+                          __builtin_fma(x3, u3.y, __builtin_fma(x2, u2.y, __builtin_fma(x1, u1.y, base.y)))};
+            };
+            const cd zero = cd{0.0, 0.0};
+            const cd m1 = mix(a0, c1, p1, c2, p2, c3, p3), n1 = mix(zero, q1, d1, q2, d2, q3, d3);
+            const cd m2 = mix(a0, c2, p1, c3, p2, c1, p3), n2 = mix(zero, q2, d1, -q3, d2, -q1, d3);
+            const cd m3 = mix(a0, c3, p1, c1, p2, c2, p3), n3 = mix(zero, q3, d1, -q1, d2, q2, d3);
+            v[K + M] = cd{m1.x - n1.y, m1.y + n1.x};              // m1 + i n1
+            v[K + 6 * M] = cd{m1.x + n1.y, m1.y - n1.x};
+            v[K + 2 * M] = cd{m2.x - n2.y, m2.y + n2.x};
+            v[K + 5 * M] = cd{m2.x + n2.y, m2.y - n2.x};
+            v[K + 3 * M] = cd{m3.x - n3.y, m3.y + n3.x};
+            v[K + 4 * M] = cd{m3.x + n3.y, m3.y - n3.x};
+            combine<K + 1>(v, s);
+        }
+    }
+};
+
+// radix 2 (what is left once the 7s, 5s and 3s are split off: the power-of-two codelets)
 template <int R, int SIGN> struct Dft<R, SIGN, 2> {
     static __device__ __forceinline__ void run(cd (&v)[R]) {
         cd ev[R / 2], od[R / 2];

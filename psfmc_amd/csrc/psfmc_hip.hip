@@ -60,40 +60,65 @@ static int fail(int code, const char* fmt, ...) {
     } while (0)
 
 // sides the fused kernels are instantiated for (FftShape in psfmc_fft.h): every power of two
-// 64..1024 and the even 5-smooth sides listed there
-#define PSFMC_FUSED_SIDES "64 96 100 120 128 144 150 160 180 192 200 240 250 256 288 300 320 360 384 400 480 500 512 576 600 640 720 768 800 900 960 1024"
+// 64..1024 and the even 5- and 7-smooth sides listed there
+#define PSFMC_FUSED_SIDES "64 84 96 98 100 112 120 126 128 140 144 150 160 168 180 192 196 200 210 224 240 250 252 256 280 288 294 300 320 336 350 360 384 392 400 420 448 480 500 504 512 560 576 600 630 640 672 700 720 768 784 800 840 896 900 960 1024"
 // run BODY with `N_` a compile-time copy of the length n
 #define DISPATCH_LEN(n, BODY) \
     switch (n) { \
         case 64: { constexpr int N_ = 64; BODY; } break; \
+        case 84: { constexpr int N_ = 84; BODY; } break; \
         case 96: { constexpr int N_ = 96; BODY; } break; \
+        case 98: { constexpr int N_ = 98; BODY; } break; \
         case 100: { constexpr int N_ = 100; BODY; } break; \
+        case 112: { constexpr int N_ = 112; BODY; } break; \
         case 120: { constexpr int N_ = 120; BODY; } break; \
+        case 126: { constexpr int N_ = 126; BODY; } break; \
         case 128: { constexpr int N_ = 128; BODY; } break; \
+        case 140: { constexpr int N_ = 140; BODY; } break; \
         case 144: { constexpr int N_ = 144; BODY; } break; \
         case 150: { constexpr int N_ = 150; BODY; } break; \
         case 160: { constexpr int N_ = 160; BODY; } break; \
+        case 168: { constexpr int N_ = 168; BODY; } break; \
         case 180: { constexpr int N_ = 180; BODY; } break; \
         case 192: { constexpr int N_ = 192; BODY; } break; \
+        case 196: { constexpr int N_ = 196; BODY; } break; \
         case 200: { constexpr int N_ = 200; BODY; } break; \
+        case 210: { constexpr int N_ = 210; BODY; } break; \
+        case 224: { constexpr int N_ = 224; BODY; } break; \
         case 240: { constexpr int N_ = 240; BODY; } break; \
         case 250: { constexpr int N_ = 250; BODY; } break; \
+        case 252: { constexpr int N_ = 252; BODY; } break; \
         case 256: { constexpr int N_ = 256; BODY; } break; \
+        case 280: { constexpr int N_ = 280; BODY; } break; \
         case 288: { constexpr int N_ = 288; BODY; } break; \
+        case 294: { constexpr int N_ = 294; BODY; } break; \
         case 300: { constexpr int N_ = 300; BODY; } break; \
         case 320: { constexpr int N_ = 320; BODY; } break; \
+        case 336: { constexpr int N_ = 336; BODY; } break; \
+        case 350: { constexpr int N_ = 350; BODY; } break; \
         case 360: { constexpr int N_ = 360; BODY; } break; \
         case 384: { constexpr int N_ = 384; BODY; } break; \
+        case 392: { constexpr int N_ = 392; BODY; } break; \
         case 400: { constexpr int N_ = 400; BODY; } break; \
+        case 420: { constexpr int N_ = 420; BODY; } break; \
+        case 448: { constexpr int N_ = 448; BODY; } break; \
         case 480: { constexpr int N_ = 480; BODY; } break; \
         case 500: { constexpr int N_ = 500; BODY; } break; \
+        case 504: { constexpr int N_ = 504; BODY; } break; \
         case 512: { constexpr int N_ = 512; BODY; } break; \
+        case 560: { constexpr int N_ = 560; BODY; } break; \
         case 576: { constexpr int N_ = 576; BODY; } break; \
         case 600: { constexpr int N_ = 600; BODY; } break; \
+        case 630: { constexpr int N_ = 630; BODY; } break; \
         case 640: { constexpr int N_ = 640; BODY; } break; \
+        case 672: { constexpr int N_ = 672; BODY; } break; \
+        case 700: { constexpr int N_ = 700; BODY; } break; \
         case 720: { constexpr int N_ = 720; BODY; } break; \
         case 768: { constexpr int N_ = 768; BODY; } break; \
+        case 784: { constexpr int N_ = 784; BODY; } break; \
         case 800: { constexpr int N_ = 800; BODY; } break; \
+        case 840: { constexpr int N_ = 840; BODY; } break; \
+        case 896: { constexpr int N_ = 896; BODY; } break; \
         case 900: { constexpr int N_ = 900; BODY; } break; \
         case 960: { constexpr int N_ = 960; BODY; } break; \
         case 1024: { constexpr int N_ = 1024; BODY; } break; \
@@ -248,7 +273,7 @@ static int fused_pass_walkers(const psfmc_ctx* c) {
 }
 
 static bool fused_side(int n) {
-    static const int sides[] = {64,96,100,120,128,144,150,160,180,192,200,240,250,256,288,300,320,360,384,400,480,500,512,576,600,640,720,768,800,900,960,1024};
+    static const int sides[] = {64,84,96,98,100,112,120,126,128,140,144,150,160,168,180,192,196,200,210,224,240,250,252,256,280,288,294,300,320,336,350,360,384,392,400,420,448,480,500,504,512,560,576,600,630,640,672,700,720,768,784,800,840,896,900,960,1024};
     for (int v : sides)
         if (v == n) return true;
     return false;

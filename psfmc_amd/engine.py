@@ -15,8 +15,10 @@ BACKENDS = {'fused': BACKEND_FUSED, 'hipfft': BACKEND_HIPFFT}
 ROW_SKY, ROW_PS, ROW_SERSIC = 1, 4, 9
 
 # sides the fused kernels are built for (psfmc_amd/csrc/psfmc_fft.h FftShape)
-FUSED_SIDES = (64, 96, 100, 120, 128, 144, 150, 160, 180, 192, 200, 240, 250, 256, 288, 300, 320, 360,
-               384, 400, 480, 500, 512, 576, 600, 640, 720, 768, 800, 900, 960, 1024)
+FUSED_SIDES = (64, 84, 96, 98, 100, 112, 120, 126, 128, 140, 144, 150, 160, 168, 180, 192, 196, 200,
+               210, 224, 240, 250, 252, 256, 280, 288, 294, 300, 320, 336, 350, 360, 384, 392, 400,
+               420, 448, 480, 500, 504, 512, 560, 576, 600, 630, 640, 672, 700, 720, 768, 784, 800,
+               840, 896, 900, 960, 1024)
 
 
 def fused_supports(ny, nx):
