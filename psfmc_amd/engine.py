@@ -21,6 +21,14 @@ FUSED_SIDES = (64, 84, 96, 98, 100, 112, 120, 126, 128, 140, 144, 150, 160, 168,
                840, 896, 900, 960, 1024)
 
 
+def nearest_fused_sides(n):
+    """The supported sides around `n`: (largest side <= n or None, smallest side >= n or None) --
+    for choosing a cut-out size that stays on the fused kernels."""
+    below = [v for v in FUSED_SIDES if v <= n]
+    above = [v for v in FUSED_SIDES if v >= n]
+    return (below[-1] if below else None), (above[0] if above else None)
+
+
 def fused_supports(ny, nx):
     """Whether psfmc_ctx_create accepts this image shape for the fused back end: both sides
     from FUSED_SIDES, in any combination."""

@@ -205,3 +205,12 @@ def test_ds9_region_mask(tmp_path):
     other.write_text('fk5\ncircle(10:00:00,+02:00:00,5")\n')
     with pytest.warns(UserWarning):
         assert mask_from_file(str(other), {}, (8, 8)) is None
+
+
+def test_nearest_fused_sides():
+    from psfmc_amd import engine
+    assert engine.nearest_fused_sides(256) == (256, 256)
+    assert engine.nearest_fused_sides(130) == (128, 140)
+    assert engine.nearest_fused_sides(50) == (None, 64)
+    assert engine.nearest_fused_sides(2000) == (1024, None)
+    assert engine.fused_supports(140, 256) and not engine.fused_supports(130, 256)
