@@ -110,6 +110,23 @@ def test_many_fields_each_with_its_own_context():
         model.close()
 
 
+def test_auto_backend_falls_back_to_hipfft_for_unbuilt_sides():
+    """backend='auto': a side outside the built list (130 = 2 * 5 * 13) runs on the hipFFT back end,
+    a built one (140) on the fused kernels; both against the oracle."""
+    import psfmc_oracle as orc
+    for side, want_backend in ((130, 'hipfft'), (140, 'fused')):
+        model, fld = make_model(side, 1, 'auto', max_walkers=8)
+        assert model._backend == want_backend
+        theta = synth_field.draw_walkers(side, 1, 4, seed=3, near_truth=fld['truth'])
+        got = model.log_posterior_batch(theta)
+        field = orc.make_field(fld['sci'], fld['ivm'], [fld['psf']], [fld['psf_ivm']], mag_zp=fld['mag_zp'])
+        prior = model.log_priors_batch(theta)
+        for t, p, g in zip(theta, prior, got):
+            want = helpers.oracle_loglike(field, helpers.synth_layout(1), t) + p
+            assert abs(g - want) <= 1e-10 * abs(want)
+        model.close()
+
+
 def test_rectangular_and_small_sizes_fused():
     """64 x 128 and 128 x 64: every FFT shape combination the goldens do not hit."""
     from psfmc_amd import MultiComponentModel
