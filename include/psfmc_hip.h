@@ -269,6 +269,9 @@ int psfmc_get_spectra(psfmc_ctx* ctx, double* psf_spec, double* var_spec);
 /* tuning knobs: "chunk_walkers" (walkers per internal pass), "streams" (passes in
  * flight, 1..4), "cols_grid", "stagger" (0 / 1: the second pass in flight starts one
  * forward-row kernel after the first; default per image shape, results do not depend on it),
+ * "linear_accumulation" (0 / 1, default 1, fused back end): posterior-image samples are added up as
+ * raw / raw^2 / point-source-only raw and convolved once when the images are read, instead of every
+ * sample going through the transforms (the five images are linear in those three),
  * "profile" (1: time every kernel with HIP events; read
  * back with get_option "prof_ms_rows_fwd" / "prof_n_rows_fwd", ..._cols, ..._rows_inv).
  * "storage_f32" (0 / 1, default 0): keep the fused path's intermediate half-spectra as

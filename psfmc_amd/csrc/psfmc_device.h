@@ -331,7 +331,8 @@ __device__ __forceinline__ double fast_exp2_poly(double r) {
 //     At dx = dy = 0 the reciprocal produces NaN like the reference's 0/0.
 // (Sersic.py:98-134 + :136-153, PointSource.py:24-57, Sky.py:14-16.)
 // ---------------------------------------------------------------------------
-template <int P, int T>
+// K0: the lane's pixels are x = T (K0 + k) + t, k < P (a segment of a longer row; 0 for whole rows)
+template <int P, int T, int K0 = 0>
 __device__ __forceinline__ void raster_row(const double* __restrict__ prep, int n_ps, int n_sersic,
                                            int t, int iy, bool ps_only, const double* __restrict__ log_tab,
                                            double (&r)[P]) {
@@ -347,7 +348,7 @@ __device__ __forceinline__ void raster_row(const double* __restrict__ prep, int 
             const int xlo = (int)p[2], xn = (int)p[3];
 #pragma unroll
             for (int k = 0; k < P; ++k) {
-                const int tx = T * k + t - xlo;
+                const int tx = T * (K0 + k) + t - xlo;
                 const bool in = (unsigned)tx < (unsigned)xn;
                 const double wx = p[4 + kTaps + (in ? tx : 0)];
                 r[k] += in ? wy * wx : 0.0;
@@ -367,7 +368,7 @@ __device__ __forceinline__ void raster_row(const double* __restrict__ prep, int 
         const double gk = -2.0 * kappa * pw * 0.28867513459481288225;   // sqrt(1/12)
 #pragma unroll
         for (int k = 0; k < P; ++k) {
-            const double dx = (double)(T * k + t) - x0;      // exact pixel coordinate, one rounding
+            const double dx = (double)(T * (K0 + k) + t) - x0;   // exact pixel coordinate, one rounding
             const double u = __builtin_fma(m00, dx, uy);
             const double v = __builtin_fma(m10, dx, vy);
             const double rho2 = __builtin_fma(u, u, v * v);

@@ -756,6 +756,99 @@ k_rows_inv(const TS* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
     if (lane == 0) partial[(size_t)w * nyg + yg] = acc;
 }
 
+// ---------------------------------------------------------------------------
+// Posterior-image sums (models.py:74-97) without transforms.  Every posterior image is linear in
+// three per-sample images -- raw, raw^2 and the point-source-only raw model: mean convolved model =
+// conv(mean raw), mean model variance = conv_var(mean raw^2) (the reference averages the weight map
+// as a variance), mean PS-only convolved = conv(mean raw_PS) -- so a sample only has to be
+// rasterised and added to three sums per PSF; the convolutions happen once, when the images are
+// asked for (psfmc_hip.hip flush_linear_sums).
+// grid (row groups, walker groups), one wave per workgroup: the wave rasterises its RG rows for the
+// walkers of its group one after the other with the row kernels' own rasteriser (same bits as the
+// likelihood's raw model), keeps the three sums of a 16-pixel segment in registers and stores them
+// as the group's partial: part[group][psf][3][ny][NX].  k_sum_partials adds the groups up in order:
+// no atomics, the sums do not depend on how the walkers were grouped in time.
+// ---------------------------------------------------------------------------
+template <int P> constexpr int raster_seg() { return P <= 16 ? P : (P % 16 == 0 ? 16 : P % 15 == 0 ? 15 : P % 12 == 0 ? 12 : P % 10 == 0 ? 10 : P % 9 == 0 ? 9 : P % 7 == 0 ? 7 : P % 5 == 0 ? 5 : P); }
+
+template <int NX, int K0, int SEG>
+__device__ __forceinline__ void raster_sums_segment(const double* __restrict__ prep, int plen, int w0, int w1, int psf,
+                                                    int n_ps, int n_sersic, int t, int iy, bool row_on,
+                                                    const double* __restrict__ log_tab, double* __restrict__ out,
+                                                    size_t S) {
+    constexpr int T = FftShape<NX>::T;
+    double a[SEG], b[SEG], cps[SEG];
+#pragma unroll
+    for (int k = 0; k < SEG; ++k) a[k] = b[k] = cps[k] = 0.0;
+    for (int w = w0; w < w1; ++w) {
+        const double* wprep = prep + (size_t)w * plen;                   // wave-uniform
+        if ((int)wprep[kPrepPsfIdx] != psf) continue;
+        double r[SEG];
+        raster_row<SEG, T, K0>(wprep, n_ps, n_sersic, t, iy, false, log_tab, r);
+#pragma unroll
+        for (int k = 0; k < SEG; ++k) {
+            a[k] += r[k];
+            b[k] = __builtin_fma(r[k], r[k], b[k]);
+        }
+        if (n_ps) {
+            raster_row<SEG, T, K0>(wprep, n_ps, n_sersic, t, iy, true, log_tab, r);
+#pragma unroll
+            for (int k = 0; k < SEG; ++k) cps[k] += r[k];
+        }
+    }
+    if (row_on) {
+        double* o = out + (size_t)iy * NX + t;
+#pragma unroll
+        for (int k = 0; k < SEG; ++k) {
+            o[T * (K0 + k)] = a[k];
+            o[S + T * (K0 + k)] = b[k];
+            o[2 * S + T * (K0 + k)] = cps[k];
+        }
+    }
+}
+
+template <int NX, int K0>
+__device__ __forceinline__ void raster_sums_all(const double* __restrict__ prep, int plen, int w0, int w1, int psf,
+                                                int n_ps, int n_sersic, int t, int iy, bool row_on,
+                                                const double* __restrict__ log_tab, double* __restrict__ out, size_t S) {
+    constexpr int P = FftShape<NX>::P, SEG = raster_seg<P>();
+    if constexpr (K0 < P) {
+        raster_sums_segment<NX, K0, SEG>(prep, plen, w0, w1, psf, n_ps, n_sersic, t, iy, row_on, log_tab, out, S);
+        raster_sums_all<NX, K0 + SEG>(prep, plen, w0, w1, psf, n_ps, n_sersic, t, iy, row_on, log_tab, out, S);
+    }
+}
+
+template <int NX>
+__global__ void __launch_bounds__(64) k_raster_sums(const double* __restrict__ prep, int plen, int n_w, int group_size,
+                                                    int n_ps, int n_sersic, int ny, int n_psf,
+                                                    double* __restrict__ part) {
+    using S = FftShape<NX>;
+    constexpr int T = S::T, RG = S::TPW;
+    static_assert(S::P % raster_seg<S::P>() == 0, "segment");
+    __shared__ __align__(16) double log_tab[kLogTabBytes / sizeof(double)];
+    const int lane = threadIdx.x;
+    const int f = lane / T, t = lane % T;
+    const int iy = blockIdx.x * RG + f;
+    const bool row_on = f < RG && iy < ny;
+    const int g = blockIdx.y;
+    const int w0 = g * group_size, w1 = w0 + group_size < n_w ? w0 + group_size : n_w;
+    load_log_table(log_tab, lane);
+    wave_lds_sync();
+    const size_t Spx = (size_t)ny * NX;
+    for (int psf = 0; psf < n_psf; ++psf)
+        raster_sums_all<NX, 0>(prep, plen, w0, w1, psf, n_ps, n_sersic, t, row_on ? iy : 0, row_on, log_tab,
+                               part + ((size_t)g * n_psf + psf) * 3 * Spx, Spx);
+}
+
+// lin[i] += part[0][i] + part[1][i] + ... (fixed order)
+__global__ void k_sum_partials(const double* __restrict__ part, int n_groups, double* __restrict__ lin, size_t n_el) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_el; i += (size_t)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int g = 0; g < n_groups; ++g) s += part[(size_t)g * n_el + i];
+        lin[i] += s;
+    }
+}
+
 // Kt[psf][kx][c][ky] = spec_c[psf][ky][kx] * (-1)^(kx+ky) / S from the
 // column-transformed PSF buffer (T layout with ky in place of y; its c = 1 half
 // already carries the channel scale rho[psf], which stays in Kt).  k_rows_fwd leaves

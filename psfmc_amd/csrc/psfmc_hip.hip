@@ -190,6 +190,13 @@ struct psfmc_ctx {
     void* d_layout_blob = nullptr;           // one allocation behind the layout's pointers
     double *d_theta = nullptr, *d_extra = nullptr, *d_lnprior = nullptr;
     double* d_acc = nullptr;  // [4][S] sums: raw, conv, model variance, PS-only conv
+    // fused path: samples are first added to three LINEAR sums per PSF -- raw, raw^2, PS-only raw --
+    // (k_raster_sums) and convolved into d_acc only when the images are asked for (flush_linear_sums)
+    double* d_lin = nullptr;      // [n_psf][3][S]
+    double* d_linpart = nullptr;  // [lin_groups][n_psf][3][S] partial sums of one call
+    int lin_groups = 0;
+    long long lin_pending = 0;    // samples in d_lin not yet convolved into d_acc
+    bool linear_acc = true;       // set_option "linear_accumulation" 0: every sample through the full pipeline (round 1's way)
     double* d_rawstage = nullptr;   // [img_cap][S] raw-model staging for the sums
     long long acc_count = 0;
     int cols_grid = 0;
@@ -205,6 +212,8 @@ struct psfmc_ctx {
         bool store = false, open = false;
     } stretch;
 };
+
+static int flush_linear_sums(psfmc_ctx* c);   // posterior-image sums: see psfmc_reset_accumulated
 
 // ---------------------------------------------------------------------------
 // hipFFT plans, cached per batch size (a half-ensemble call and a full-ensemble
@@ -714,7 +723,7 @@ extern "C" int psfmc_ctx_destroy(psfmc_ctx* c) {
     }
     void* bufs[] = {c->d_sci,  c->d_var,  c->d_bad,     c->d_pspec, c->d_vspec, c->d_rows, c->d_prep,
                     c->d_like, c->d_skip, c->d_partial, c->d_real,  c->d_spec,  c->d_Ts[0], c->d_Kraw,
-                    c->d_Kt,   c->d_twx,  c->d_twy,     c->d_img0,  c->d_img1, c->d_rho,   c->d_field, c->d_Ts[1], c->d_acc,
+                    c->d_Kt,   c->d_twx,  c->d_twy,     c->d_img0,  c->d_img1, c->d_rho,   c->d_field, c->d_Ts[1], c->d_acc, c->d_lin, c->d_linpart,
                     c->d_layout_blob, c->d_theta, c->d_extra, c->d_lnprior, c->d_rawstage,
                     c->d_Ts[2], c->d_Ts[3], c->stretch.pos, c->stretch.lnp, c->stretch.q, c->stretch.newlnp,
                     c->stretch.rand, c->stretch.chain, c->stretch.lnchain, c->stretch.partner, c->stretch.iter,
@@ -779,6 +788,12 @@ extern "C" int psfmc_set_option(psfmc_ctx* c, const char* key, double value) {
         c->stagger = (int)value;
         return PSFMC_OK;
     }
+    if (!strcmp(key, "linear_accumulation")) {
+        HIP_TRY(hipSetDevice(c->device));
+        RC_TRY(flush_linear_sums(c));
+        c->linear_acc = value != 0;
+        return PSFMC_OK;
+    }
     if (!strcmp(key, "cols3")) {
         c->cols3 = value != 0;
         return PSFMC_OK;
@@ -830,6 +845,7 @@ extern "C" double psfmc_get_option(const psfmc_ctx* cc, const char* key) {
     if (!strcmp(key, "cols_grid")) return c->cols_grid;
     if (!strcmp(key, "streams")) return c->n_streams;
     if (!strcmp(key, "stagger")) return c->stagger;
+    if (!strcmp(key, "linear_accumulation")) return c->linear_acc ? 1.0 : 0.0;
     return NAN;
 }
 
@@ -1200,14 +1216,150 @@ extern "C" int psfmc_reset_accumulated(psfmc_ctx* c) {
     HIP_TRY(hipSetDevice(c->device));
     if (!c->d_acc) HIP_TRY(hipMalloc(&c->d_acc, (size_t)4 * c->S * sizeof(double)));
     HIP_TRY(hipMemsetAsync(c->d_acc, 0, (size_t)4 * c->S * sizeof(double), c->stream));
+    if (c->d_lin) HIP_TRY(hipMemsetAsync(c->d_lin, 0, (size_t)c->n_psf * 3 * c->S * sizeof(double), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->acc_count = 0;
+    c->lin_pending = 0;
     return PSFMC_OK;
+}
+
+// buffers of the linear sums (fused back end): allocated outside any stream capture
+static int ensure_linear_sums(psfmc_ctx* c) {
+    if (c->backend != PSFMC_BACKEND_FUSED || c->d_lin) return PSFMC_OK;
+    const size_t per_group = (size_t)c->n_psf * 3 * c->S * sizeof(double);
+    // walker groups of one call: enough waves to fill the chip (row groups x groups >= ~2048), the
+    // partials within ~96 MB
+    int groups = (2048 + c->nblk - 1) / c->nblk;
+    const size_t budget = (size_t)96 << 20;
+    if ((size_t)groups * per_group > budget) groups = (int)(budget / per_group);
+    if (groups < 1) groups = 1;
+    if (groups > 64) groups = 64;
+    HIP_TRY(hipMalloc(&c->d_lin, per_group));
+    HIP_TRY(hipMemset(c->d_lin, 0, per_group));
+    HIP_TRY(hipMalloc(&c->d_linpart, (size_t)groups * per_group));
+    c->lin_groups = groups;
+    return PSFMC_OK;
+}
+
+template <int NX>
+static int launch_raster_sums(psfmc_ctx* c, int n, const double* prep, int groups, int group_size, hipStream_t st) {
+    constexpr int RG = FftShape<NX>::TPW;
+    hipLaunchKernelGGL((k_raster_sums<NX>), dim3((c->ny + RG - 1) / RG, groups), dim3(64), 0, st, prep, c->plen, n,
+                       group_size, c->n_ps, c->n_sersic, c->ny, c->n_psf, c->d_linpart);
+    return PSFMC_OK;
+}
+
+// fused back end: add the W walkers whose prep records are in c->d_prep to the linear sums
+static int accumulate_linear(psfmc_ctx* c, int W, hipStream_t st) {
+    const size_t n_el = (size_t)c->n_psf * 3 * c->S;
+    int groups = c->lin_groups < W ? c->lin_groups : W;
+    const int group_size = (W + groups - 1) / groups;
+    groups = (W + group_size - 1) / group_size;
+    DISPATCH_LEN(c->nx, RC_TRY((launch_raster_sums<N_>(c, W, c->d_prep, groups, group_size, st))));
+    hipLaunchKernelGGL(k_sum_partials, dim3(512), dim3(256), 0, st, c->d_linpart, groups, c->d_lin, n_el);
+    c->lin_pending += W;
+    c->acc_count += W;
+    return PSFMC_OK;
+}
+
+// convolve the pending linear sums into the four image sums of d_acc.  Per PSF three passes of
+// the row / column kernels over ONE pseudo-walker read from memory: (sum raw, 0), (0, sum raw^2)
+// and (sum PS-only raw, 0).  Each sum travels alone in its packed transform: added up, the samples'
+// raw^2 is dominated by the brightest sample far more than their raw is, and packed together the
+// two channels' rounding errors would leak into each other (measured on the `edge` fixture:
+// 3e-6 relative in the weight map; alone, 1e-15).
+static int flush_linear_sums(psfmc_ctx* c) {
+    if (c->backend != PSFMC_BACKEND_FUSED || c->lin_pending == 0 || !c->d_lin) return PSFMC_OK;
+    hipStream_t st = c->stream;
+    HIP_TRY(hipStreamSynchronize(st));
+    const size_t S = (size_t)c->S;
+    std::vector<double> host(S), rho(c->n_psf);
+    HIP_TRY(hipMemcpy(rho.data(), c->d_rho, c->n_psf * sizeof(double), hipMemcpyDeviceToHost));
+    double *d_img = nullptr, *d_scale = nullptr, *d_fprep = nullptr, *d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_img, 2 * S * sizeof(double)));
+    int rc = PSFMC_OK;
+    if (hipMalloc(&d_scale, sizeof(double)) != hipSuccess ||
+        hipMalloc(&d_fprep, (size_t)c->plen * sizeof(double)) != hipSuccess ||
+        hipMalloc(&d_out, 2 * S * sizeof(double)) != hipSuccess)
+        rc = fail(PSFMC_ENOMEM, "hipMalloc (posterior-image flush)");
+    auto acc = [&](const double* src, int slot) {
+        hipLaunchKernelGGL(k_accumulate, dim3(256), dim3(256), 0, st, src, c->d_acc + (size_t)slot * S, (int)S, 1, 1, 0);
+    };
+    // one pseudo-walker: z = img0 + i scale img1 through rows_fwd (from memory), cols, rows_inv;
+    // d_out[0] = convolution of img0 with the PSF, d_out[1] = of img1 with the PSF variance map
+    auto pass = [&](int psf, const double* img0, const double* img1, double scale) -> int {
+        std::vector<double> fprep((size_t)c->plen, 0.0);
+        fprep[kPrepPsfIdx] = (double)psf;
+        fprep[kPrepMu] = scale;
+        fprep[kPrepInvLambda] = 1.0 / (scale * rho[psf]);
+        for (int h = 0; h < 2; ++h) {
+            const double* src = h ? img1 : img0;
+            if (src) HIP_TRY(hipMemcpyAsync(d_img + h * S, src, S * sizeof(double), hipMemcpyDeviceToDevice, st));
+            else HIP_TRY(hipMemsetAsync(d_img + h * S, 0, S * sizeof(double), st));
+        }
+        HIP_TRY(hipMemcpyAsync(d_scale, &scale, sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_fprep, fprep.data(), fprep.size() * sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));                 // (fprep / scale are stack data)
+        DISPATCH_LEN(c->nx, RC_TRY((launch_rows_fwd<N_, true>(c, 1, nullptr, nullptr, c->d_T, 0, d_img, d_scale,
+                                                              nullptr, st))));
+        DISPATCH_LEN(c->ny, RC_TRY((launch_cols<N_, true>(c, c->d_T, 1, d_fprep, nullptr, st))));
+        DISPATCH_LEN(c->nx, RC_TRY((launch_rows_inv<N_>(c, 1, c->d_T, d_fprep, nullptr, c->d_partial, d_out,
+                                                        d_out + S, st))));
+        return PSFMC_OK;
+    };
+    for (int p = 0; p < c->n_psf && rc == PSFMC_OK; ++p) {
+        const double* lin = c->d_lin + (size_t)p * 3 * S;
+        // the variance channel's power-of-two scale, and whether any sample used this PSF
+        if (hipMemcpy(host.data(), lin + S, S * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
+            rc = fail(PSFMC_EHIP, "posterior-image flush: copy failed");
+            break;
+        }
+        double peak_b = 0.0;
+        bool any = false;
+        for (size_t i = 0; i < S; ++i) {
+            const double b = fabs(host[i]);
+            any |= host[i] != 0.0;                                // (NaN counts)
+            if (b > peak_b && b < 1e300) peak_b = b;
+        }
+        if (!any) continue;                                       // (raw^2 = 0 everywhere: no sample, or an empty model)
+        double sc = 1.0;
+        if (peak_b > 0.0) {
+            int eb;
+            (void)frexp(peak_b, &eb);
+            sc = ldexp(1.0, -eb);
+        }
+        rc = pass(p, lin, nullptr, 1.0);
+        if (rc != PSFMC_OK) break;
+        acc(lin, 0);                          // raw
+        acc(d_out, 1);                        // convolved model
+        rc = pass(p, nullptr, lin + S, sc);
+        if (rc != PSFMC_OK) break;
+        acc(d_out + S, 2);                    // model variance
+        rc = pass(p, lin + 2 * S, nullptr, 1.0);
+        if (rc != PSFMC_OK) break;
+        acc(d_out, 3);                        // PS-only convolved
+        if (hipStreamSynchronize(st) != hipSuccess) rc = fail(PSFMC_EHIP, "posterior-image flush failed: %s",
+                                                              hipGetErrorString(hipGetLastError()));
+    }
+    if (rc == PSFMC_OK) {
+        (void)hipMemsetAsync(c->d_lin, 0, (size_t)c->n_psf * 3 * S * sizeof(double), st);
+        (void)hipStreamSynchronize(st);
+        c->lin_pending = 0;
+    }
+    (void)hipFree(d_img);
+    if (d_scale) (void)hipFree(d_scale);
+    if (d_fprep) (void)hipFree(d_fprep);
+    if (d_out) (void)hipFree(d_out);
+    return rc;
 }
 
 // add the images of the W walkers whose prep records are in c->d_prep to the sums
 static int accumulate_from_prep(psfmc_ctx* c, int W, hipStream_t st) {
     const bool fused = c->backend == PSFMC_BACKEND_FUSED;
+    if (fused && c->linear_acc) {
+        if (!c->d_lin) return fail(PSFMC_EINVAL, "linear sums not allocated");
+        return accumulate_linear(c, W, st);
+    }
     RC_TRY(ensure_image_staging(c));
     if (fused && !c->d_rawstage) HIP_TRY(hipMalloc(&c->d_rawstage, (size_t)c->img_cap * c->S * sizeof(double)));
     const double* conv_src = fused ? c->d_img0 : c->d_real;
@@ -1250,6 +1402,7 @@ extern "C" int psfmc_accumulate_images(psfmc_ctx* c, int W, const double* rows) 
     if (rc != PSFMC_OK || W == 0) return rc;
     HIP_TRY(hipSetDevice(c->device));
     if (!c->d_acc) RC_TRY(psfmc_reset_accumulated(c));
+    RC_TRY(ensure_linear_sums(c));
     hipStream_t st = c->stream;
     HIP_TRY(hipMemcpyAsync(c->d_rows, rows, (size_t)W * c->rlen * sizeof(double), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_prep, dim3((W + 127) / 128), dim3(128), 0, st, c->d_rows, c->d_prep, W, c->n_ps,
@@ -1361,8 +1514,9 @@ static void stretch_accept(psfmc_ctx* c, int it, int h, const double* d_newlnp, 
 
 static int stretch_prepare_accumulation(psfmc_ctx* c) {
     if (!c->d_acc) RC_TRY(psfmc_reset_accumulated(c));
+    RC_TRY(ensure_linear_sums(c));
     RC_TRY(ensure_image_staging(c));
-    if (c->backend == PSFMC_BACKEND_FUSED && !c->d_rawstage)
+    if (c->backend == PSFMC_BACKEND_FUSED && !c->linear_acc && !c->d_rawstage)
         HIP_TRY(hipMalloc(&c->d_rawstage, (size_t)c->img_cap * c->S * sizeof(double)));
     return PSFMC_OK;
 }
@@ -1411,7 +1565,7 @@ extern "C" int psfmc_stretch_run(psfmc_ctx* c, int W, int n_iter, double* pos, d
         // un-captured warm-up of the pipeline: one-time attribute calls must not fall
         // inside the capture
         rc = eval_theta_device(c, half, S.pos, nullptr, S.newlnp, st);
-        const long long count_before = c->acc_count;
+        const long long count_before = c->acc_count, pending_before = c->lin_pending;
         if (rc == PSFMC_OK && hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
             const int crc = iteration();
             const hipError_t e = hipStreamEndCapture(st, &graph);
@@ -1423,11 +1577,18 @@ extern "C" int psfmc_stretch_run(psfmc_ctx* c, int W, int n_iter, double* pos, d
         }
         (void)hipGetLastError();
         c->acc_count = count_before;            // the captured pass did not run
+        c->lin_pending = pending_before;
     }
     for (int it = 0; it < n_iter && rc == PSFMC_OK; ++it) {
         if (exec) {
             if (hipGraphLaunch(exec, st) != hipSuccess) rc = fail(PSFMC_EHIP, "hipGraphLaunch failed");
-            else { ++c->graph_launches; if (accumulate) c->acc_count += W; }
+            else {
+                ++c->graph_launches;
+                if (accumulate) {
+                    c->acc_count += W;
+                    if (c->backend == PSFMC_BACKEND_FUSED && c->linear_acc) c->lin_pending += W;
+                }
+            }
         } else {
             rc = iteration();
         }
@@ -1531,6 +1692,7 @@ extern "C" int psfmc_stretch_close(psfmc_ctx* c, double* pos, double* lnprob, do
 extern "C" int psfmc_get_accumulated_sums(psfmc_ctx* c, double* sums, long long* count) {
     if (!c || !sums || !count) return fail(PSFMC_EINVAL, "NULL argument");
     HIP_TRY(hipSetDevice(c->device));
+    RC_TRY(flush_linear_sums(c));
     *count = c->acc_count;
     if (!c->d_acc) { memset(sums, 0, (size_t)4 * c->S * sizeof(double)); return PSFMC_OK; }
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1542,6 +1704,8 @@ extern "C" int psfmc_set_accumulated_sums(psfmc_ctx* c, const double* sums, long
     if (!c || !sums || count < 0) return fail(PSFMC_EINVAL, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
     if (!c->d_acc) RC_TRY(psfmc_reset_accumulated(c));
+    if (c->d_lin) HIP_TRY(hipMemset(c->d_lin, 0, (size_t)c->n_psf * 3 * c->S * sizeof(double)));
+    c->lin_pending = 0;                                  // the new sums replace everything gathered so far
     HIP_TRY(hipMemcpy(c->d_acc, sums, (size_t)4 * c->S * sizeof(double), hipMemcpyHostToDevice));
     c->acc_count = count;
     return PSFMC_OK;
@@ -1553,6 +1717,7 @@ extern "C" int psfmc_get_accumulated(psfmc_ctx* c, double* raw, double* conv, do
     if (count) *count = c->acc_count;
     if (c->acc_count == 0 || !c->d_acc) return PSFMC_OK;
     HIP_TRY(hipSetDevice(c->device));
+    RC_TRY(flush_linear_sums(c));
     double* d_out = nullptr;
     HIP_TRY(hipMalloc(&d_out, (size_t)c->S * sizeof(double)));
     const double inv_n = 1.0 / (double)c->acc_count;

@@ -90,7 +90,16 @@ def test_device_accumulation_matches_reference_running_mean(tmp_path, backend):
     for k in want:
         fin = np.isfinite(want[k])
         assert np.array_equal(np.isfinite(got[k]), fin), k
-        assert np.allclose(got[k][fin], want[k][fin], rtol=1e-11, atol=1e-13 * np.abs(want[k][fin]).max()), k
+        # The fused back end adds samples up as raw / raw^2 / PS-only raw and convolves the sums once
+        # (linear: DESIGN section 8), the running mean above is over per-sample convolutions.  On this
+        # fixture (1e4-count point sources) a per-sample packed transform leaks 3.5e-12 of the peak from
+        # its variance channel into the model channel and the weight map is conditioned to a few 1e-6
+        # either way (both measured against the fp64 oracle: the summed form is the closer one).
+        peak = np.abs(want[k][fin]).max()
+        if k == 'composite_ivm':
+            assert np.allclose(got[k][fin], want[k][fin], rtol=1e-5, atol=0), k
+        else:
+            assert np.abs(got[k][fin] - want[k][fin]).max() <= 2e-11 * peak, k
     # host-side accumulation of blobs keeps working and merges with device sums
     model.reset_images()
     model.accumulate_samples(theta[:20])
@@ -156,6 +165,53 @@ def test_device_sampler_reproduces_host_sampler(tmp_path):
     want = model.collect_posterior_images()
     for k in want:      # (device-derived vs host-derived Sersic constants: 1e-14 apart)
         assert np.allclose(got[k], want[k], rtol=1e-11, atol=1e-12 * np.abs(want[k]).max()), k
+    model.close()
+
+
+@pytest.mark.parametrize('name', ['edge', 'synth256'])
+def test_linear_accumulation_against_the_oracle(tmp_path, name):
+    """The fused back end's posterior images -- samples added up as raw / raw^2 / PS-only raw,
+    convolved once when asked for -- against the running mean of the fp64 oracle's per-sample images
+    (models.py:74-97: the weight map averaged as a variance), two PSFs and a mask included (`edge`);
+    and against round 1's way (every sample through the full pipeline, set_option
+    'linear_accumulation' 0)."""
+    import psfmc_oracle as orc
+    case = helpers.load_case(name)
+    model = helpers.build_model(name, case, tmp_path, backend='fused', max_walkers=16)
+    ok = np.isfinite(case['lnprob'])
+    theta = case['params'][ok][:24]
+    field = helpers.oracle_field(case)
+    layout = helpers.LAYOUT[name]
+    sums = {}
+    with np.errstate(all='ignore'):
+        for t in theta:
+            comps, psf = helpers.comps_from_theta(layout, t, name == 'edge')
+            _, imgs = orc.evaluate(field, comps, psf, raw_dtype=np.float64, want_ps_sub=True)
+            for k, v in imgs.items():
+                sums[k] = sums.get(k, 0.0) + (1.0 / v if k == 'composite_ivm' else v)
+        want = {k: (len(theta) / v if k == 'composite_ivm' else v / len(theta)) for k, v in sums.items()}
+    got = {}
+    for linear in (1, 0):
+        model.engine.set_option('linear_accumulation', linear)
+        assert model.engine.get_option('linear_accumulation') == linear
+        model.reset_images()
+        model.accumulate_samples(theta[:5])              # a slice, a flush in between, the rest
+        if linear:
+            model.collect_posterior_images()
+        model.accumulate_samples(theta[5:])
+        assert model.accumulated_samples == len(theta)
+        got[linear] = {k: v.copy() for k, v in model.collect_posterior_images().items()}
+    for k in want:
+        fin = np.isfinite(want[k])
+        peak = np.abs(want[k][fin]).max()
+        for linear in (1, 0):
+            assert np.array_equal(np.isfinite(got[linear][k]), fin), (k, linear)
+        err = np.abs(got[1][k][fin] - want[k][fin]).max() / peak
+        old = np.abs(got[0][k][fin] - want[k][fin]).max() / peak
+        if k == 'composite_ivm':
+            assert err <= 2e-5 and old <= 2e-5, (k, err, old)      # the variance channel's conditioning
+        else:
+            assert err <= 1e-13 and old <= 1e-11, (k, err, old)     # observed 2e-15 / 3.5e-12 on `edge`
     model.close()
 
 
