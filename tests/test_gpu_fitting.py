@@ -165,6 +165,18 @@ def test_device_sampler_reproduces_host_sampler(tmp_path):
     want = model.collect_posterior_images()
     for k in want:      # (device-derived vs host-derived Sersic constants: 1e-14 apart)
         assert np.allclose(got[k], want[k], rtol=1e-11, atol=1e-12 * np.abs(want[k]).max()), k
+    # ... and the same sums when the iteration, accumulation included, is replayed as a hipGraph
+    model.engine.set_option('graph', 1)
+    model.reset_images()
+    launches = model.engine.get_option('graph_launches')
+    gacc = DeviceEnsembleSampler(40, model, block=5, accumulate=True)
+    gacc.random_state = np.random.RandomState(3).get_state()
+    list(gacc.sample(p0, iterations=5))
+    assert model.engine.get_option('graph_launches') > launches and model.accumulated_samples == 200
+    replay = model.collect_posterior_images()
+    for k in got:
+        assert np.array_equal(replay[k], got[k], equal_nan=True), k
+    model.engine.set_option('graph', 0)
     model.close()
 
 
