@@ -323,6 +323,11 @@ def many_fields(args, torch, dist, world, rank, local, dev, gloo):
     engs, thetas, outs = [], [], []
     for model, theta, _ in probs:
         engs.append(model.engine)
+        if args.chunk:
+            model.engine.set_option('chunk_walkers', args.chunk)
+        for kv in args.opt:
+            key, val = kv.split('=')
+            model.engine.set_option(key, float(val))
         thetas.append(torch.from_numpy(theta).to(dev))
         outs.append(torch.empty(args.walkers, dtype=torch.float64, device=dev))
 
