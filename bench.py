@@ -320,6 +320,19 @@ def many_fields(args, torch, dist, world, rank, local, dev, gloo):
     own streams, own walkers); a step evaluates all of them (raw vectors -> log-posterior).
     Fields shard across ranks with no data-path collective."""
     probs = [build_problem(args, local, seed=rank * args.fields + f) for f in range(args.fields)]
+    merged = None
+    if args.fields_merge:
+        # the fields' walkers share ONE context and one batch (psfmc_ctx_create_fields)
+        from psfmc_amd import FieldSet
+        merged = FieldSet([m for m, _, _ in probs], max_walkers=args.fields * args.walkers, device=local)
+        all_theta = torch.from_numpy(np.concatenate([t for _, t, _ in probs])).to(dev)
+        all_out = torch.empty(args.fields * args.walkers, dtype=torch.float64, device=dev)
+        seg_f, seg_n = list(range(args.fields)), [args.walkers] * args.fields
+        if args.chunk:
+            merged.context.set_option('chunk_walkers', args.chunk)
+        for kv in args.opt:
+            key, val = kv.split('=')
+            merged.context.set_option(key, float(val))
     engs, thetas, outs = [], [], []
     for model, theta, _ in probs:
         engs.append(model.engine)
@@ -333,11 +346,22 @@ def many_fields(args, torch, dist, world, rank, local, dev, gloo):
 
     def step():
         for _ in range(args.batches):
+            if merged is not None:
+                merged.context.logpost_theta_device(seg_f, seg_n, all_theta.data_ptr(), all_out.data_ptr(), None)
+                continue
             for eng, t, o in zip(engs, thetas, outs):       # each context enqueues on its own stream
                 eng.logpost_theta_device(args.walkers, t.data_ptr(), 0, o.data_ptr(), None)
 
     elapsed = timed_region(args, torch, dist, world, dev, step, gloo)
     finite = int(sum(int(torch.isfinite(o).sum().item()) for o in outs))
+    agree = None
+    if merged is not None:
+        finite = int(torch.isfinite(all_out).sum().item())
+        # the shared batch against each field's own context, bit for bit
+        for eng, t, o in zip(engs, thetas, outs):
+            eng.logpost_theta_device(args.walkers, t.data_ptr(), 0, o.data_ptr(), None)
+        torch.cuda.synchronize(dev)
+        agree = bool(torch.equal(torch.cat(outs), all_out))
     if rank == 0:
         total = args.walkers * args.fields * args.batches * world * args.steps
         b_eval = algorithmic_bytes_per_eval(args.size)
@@ -356,6 +380,8 @@ def many_fields(args, torch, dist, world, rank, local, dev, gloo):
                                    'HBM -> log-posterior, fp64' % (args.fields, args.size, args.size,
                                                                    args.walkers, args.batches, args.sersic),
                        'fields_per_gpu': args.fields, 'walkers_per_field': args.walkers,
+                       'one_context_for_all_fields': bool(args.fields_merge),
+                       'shared_batch_equals_own_contexts_bitwise': agree,
                        'backend': args.backend, 'parallelism': 'fields sharded x%d' % world},
             'roofline': {'bound': 'hbm', 'achieved': measured * rate_gpu / 1e9 if measured else None,
                          'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
@@ -364,6 +390,8 @@ def many_fields(args, torch, dist, world, rank, local, dev, gloo):
                          'kernel': 'evaluation pipelines of all fields (per GPU), measured PMC bytes per walker',
                          'algorithmic_equiv_GBps': b_eval * rate_gpu / 1e9, 'bytes_note': BYTES_NOTE},
             'finite_logposts': finite}))
+    if merged is not None:
+        merged.context.close()
     for model, _, _ in probs:
         model.close()
     if world > 1:
@@ -374,6 +402,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--fields-merge', type=int, default=1,
+                    help='many-fields mode: 1 = all fields of a GPU in one context and one batch '
+                         '(psfmc_ctx_create_fields), 0 = a context and a batch per field')
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--walkers', type=int, default=4096, help='walkers per batch (per GPU)')
     ap.add_argument('--batches', type=int, default=0,

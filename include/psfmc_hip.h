@@ -163,6 +163,34 @@ int psfmc_eval_theta(psfmc_ctx* ctx, int W, const double* theta, const double* e
 /* device buffers, enqueued on `stream` (NULL = the context's stream), not synchronised */
 int psfmc_eval_theta_device(psfmc_ctx* ctx, int W, const double* d_theta, const double* d_extra_lnprior,
                             double* d_lnprob, void* stream);
+
+/*
+ * Several observed fields of ONE shape in one context (fused back end).  The reference fits one
+ * field per process (psfMC/fitting.py:13-113 builds one MultiComponentModel per model file); a
+ * survey of many small fields -- BASELINE config 5: independent 256 x 256 fields x 256 walkers each
+ * -- then makes many small batches, each paying the fixed cost of a call.  Here the fields' walkers
+ * share the batches: every walker's record carries (field * n_psf + PSF) as its kernel-spectrum index,
+ * the row kernels pick the field's pixels from it, and 8 x 256 walkers run at the rate of one 2048-walker
+ * ensemble.
+ *   sci / obs_var / bad_px  [n_fields][ny][nx];  psf / psf_var  [n_fields][n_psf][psf_ny][psf_nx]
+ *   the same component counts (n_ps, n_sersic) and parameter layout structure for every field;
+ *   psfmc_set_layout (= field 0) first, then psfmc_set_layout_field for fields 1..: own constants, priors
+ *   psfmc_eval_theta[_device]_fields: segment i = seg_count[i] consecutive walkers of field seg_field[i];
+ *   theta [W][n_params], lnprob [W] in segment order, W = sum of the counts <= max_walkers.
+ * Image output, accumulation and the device-resident sampler serve one-field contexts only.
+ */
+int psfmc_ctx_create_fields(psfmc_ctx** out, int device, int ny, int nx, int n_fields, const double* sci,
+                            const double* obs_var, const uint8_t* bad_px, int n_psf, int psf_ny, int psf_nx,
+                            const double* psf, const double* psf_var, int n_ps, int n_sersic, int max_walkers);
+int psfmc_set_layout_field(psfmc_ctx* ctx, int field, int n_sky, int n_params, const int* slot_col,
+                           const double* slot_const, const int* ps_method, const int* sersic_degrees,
+                           double mag_zeropoint, const int* family, const double* p0, const double* p1,
+                           const double* p2);
+int psfmc_eval_theta_fields(psfmc_ctx* ctx, int n_seg, const int* seg_field, const int* seg_count,
+                            const double* theta, const double* extra_lnprior, double* lnprob);
+int psfmc_eval_theta_device_fields(psfmc_ctx* ctx, int n_seg, const int* seg_field, const int* seg_count,
+                                   const double* d_theta, const double* d_extra_lnprior, double* d_lnprob,
+                                   void* stream);
 /* test hook: the derived rows [W][row_len], log-priors [W] and skip flags [W] the device
  * computes for W vectors */
 int psfmc_debug_theta_rows(psfmc_ctx* ctx, int W, const double* theta, double* rows, double* lnprior,

@@ -2,7 +2,7 @@
 psfmc_amd -- MI355X-native batched log-posterior for psfMC-style MCMC surface
 brightness modelling.  Public names mirror the reference package `psfMC`.
 """
-from .models import MultiComponentModel
+from .models import MultiComponentModel, FieldSet
 from .batch import BatchLogPosterior
 from .sampler import EnsembleSampler, DeviceEnsembleSampler
 from .parallel import RankGroup, ShardedLogPosterior
@@ -10,5 +10,5 @@ from .fitting import model_galaxy_mcmc
 from .database import load_database
 
 __version__ = '0.1.0'
-__all__ = ['MultiComponentModel', 'BatchLogPosterior', 'EnsembleSampler', 'DeviceEnsembleSampler',
+__all__ = ['MultiComponentModel', 'FieldSet', 'BatchLogPosterior', 'EnsembleSampler', 'DeviceEnsembleSampler',
            'RankGroup', 'ShardedLogPosterior', 'model_galaxy_mcmc', 'load_database']

@@ -590,7 +590,7 @@ __global__ void __launch_bounds__((row_threads<NX, FAST>()), fused_min_waves<NX>
 k_rows_inv(const TS* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const cd* __restrict__ twx,
            const FieldPx* __restrict__ field, double* __restrict__ partial, int ny,
            const double* __restrict__ prep, int plen,
-           double* __restrict__ conv_out, double* __restrict__ var_out) {
+           double* __restrict__ conv_out, double* __restrict__ var_out, int n_psf_field, unsigned field_stride) {
     using S = FftShape<NX>;
     constexpr int P = S::P, T = S::T, R = S::R, RG = row_group<NX>();
     constexpr int NXH = NX / 2 + 1;
@@ -710,7 +710,10 @@ k_rows_inv(const TS* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
     // reference's log of a non-positive weight.
     // Waves whose pixels are all good (NaN sci marks an excluded pixel, and a register slot
     // that holds no pixel at all) skip the selects.
-    const FieldPx* fbase = field + (size_t)yg * R * 64;              // wave-uniform
+    // contexts that hold several observed fields: the walker's field is the quotient of its
+    // (field * PSFs-per-field + PSF) index; field_stride = packed pixels of one field
+    const int fid = n_psf_field > 0 ? (int)prep[(size_t)w * plen + kPrepPsfIdx] / n_psf_field : 0;
+    const FieldPx* fbase = field + (size_t)fid * field_stride + (size_t)yg * R * 64;   // wave-uniform
     const unsigned foff = (unsigned)lane * (unsigned)sizeof(FieldPx);
     FieldPx px[R];
     bool any_bad = false;

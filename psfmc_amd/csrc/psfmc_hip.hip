@@ -132,7 +132,9 @@ struct psfmc_ctx {
     int device = 0;
     int ny = 0, nx = 0, nxh = 0, S = 0, F = 0;
     int nyp = 0;                  // column length of the T layout: ny rounded up to whole row groups
-    int n_psf = 0, n_ps = 0, n_sersic = 0;
+    int n_psf = 0, n_ps = 0, n_sersic = 0;   // n_psf: kernel spectra in all (fields x PSFs per field)
+    int n_fields = 1, n_psf_field = 0;       // observed fields of this context (psfmc_ctx_create_fields), PSFs of each
+    size_t field_len = 0;                    // packed pixels (FieldPx) of one field
     int max_walkers = 0, chunk = 0, backend = 0;
     int single_cap = 0;                               // walkers T buffer 0 holds (>= chunk)
     int rlen = 0, plen = 0;
@@ -186,6 +188,10 @@ struct psfmc_ctx {
     // raw-vector path (psfmc_set_layout)
     bool has_layout = false;
     ThetaLayout layout{};
+    // fields 1.. of a multi-field context: their own layouts (same structure, own priors / constants)
+    std::vector<ThetaLayout> more_layouts;
+    std::vector<void*> more_blobs;
+    std::vector<char> more_has;
     size_t theta_lds = 0;
     void* d_layout_blob = nullptr;           // one allocation behind the layout's pointers
     double *d_theta = nullptr, *d_extra = nullptr, *d_lnprior = nullptr;
@@ -396,7 +402,7 @@ static int launch_rows_inv_impl(psfmc_ctx* c, int n, const TS* Tbuf, const doubl
     constexpr int waves = row_waves<NX, FAST>();
     hipLaunchKernelGGL((k_rows_inv<NX, TS, FAST>), dim3((c->nblk + waves - 1) / waves, n),
                        dim3((row_threads<NX, FAST>())), lds, st, Tbuf, skip, c->d_twx, c->d_field, partial, c->ny,
-                       prep, c->plen, conv_out, var_out);
+                       prep, c->plen, conv_out, var_out, c->n_fields > 1 ? c->n_psf_field : 0, (unsigned)c->field_len);
     return PSFMC_OK;
 }
 
@@ -419,9 +425,10 @@ static int launch_rows_inv(psfmc_ctx* c, int n, const void* Tvoid, const double*
     }
 }
 
-template <int NX> static int pack_field(psfmc_ctx* c) {
-    hipLaunchKernelGGL((k_pack_field<NX>), dim3(256), dim3(256), 0, c->stream, c->d_sci, c->d_var,
-                       c->d_bad, c->d_field, c->ny);
+template <int NX> static int pack_field(psfmc_ctx* c, int f) {
+    const size_t px = (size_t)f * c->S;
+    hipLaunchKernelGGL((k_pack_field<NX>), dim3(256), dim3(256), 0, c->stream, c->d_sci + px, c->d_var + px,
+                       c->d_bad + px, c->d_field + (size_t)f * c->field_len, c->ny);
     return PSFMC_OK;
 }
 
@@ -562,12 +569,13 @@ static int ctx_init(psfmc_ctx* c, const double* sci, const double* obs_var, cons
         HIP_TRY(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
     }
-    HIP_TRY(hipMalloc(&c->d_sci, c->S * sizeof(double)));
-    HIP_TRY(hipMalloc(&c->d_var, c->S * sizeof(double)));
-    HIP_TRY(hipMalloc(&c->d_bad, c->S));
-    HIP_TRY(hipMemcpy(c->d_sci, sci, c->S * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->d_var, obs_var, c->S * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->d_bad, bad_px, c->S, hipMemcpyHostToDevice));
+    const size_t all_px = (size_t)c->n_fields * c->S;             // [field][ny][nx]
+    HIP_TRY(hipMalloc(&c->d_sci, all_px * sizeof(double)));
+    HIP_TRY(hipMalloc(&c->d_var, all_px * sizeof(double)));
+    HIP_TRY(hipMalloc(&c->d_bad, all_px));
+    HIP_TRY(hipMemcpy(c->d_sci, sci, all_px * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_var, obs_var, all_px * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_bad, bad_px, all_px, hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc(&c->d_rows, (size_t)c->max_walkers * c->rlen * sizeof(double)));
     HIP_TRY(hipMalloc(&c->d_prep, (size_t)c->max_walkers * c->plen * sizeof(double)));
     HIP_TRY(hipMalloc(&c->d_like, (size_t)c->max_walkers * sizeof(double)));
@@ -597,8 +605,9 @@ static int ctx_init(psfmc_ctx* c, const double* sci, const double* obs_var, cons
         HIP_TRY(hipMemcpy(c->d_rho, rho.data(), c->n_psf * sizeof(double), hipMemcpyHostToDevice));
         size_t field_len = 0;
         DISPATCH_LEN(c->nx, field_len = fused_field_len<N_>(c->ny));
-        HIP_TRY(hipMalloc(&c->d_field, field_len * sizeof(FieldPx)));
-        DISPATCH_LEN(c->nx, RC_TRY(pack_field<N_>(c)));
+        c->field_len = field_len;
+        HIP_TRY(hipMalloc(&c->d_field, (size_t)c->n_fields * field_len * sizeof(FieldPx)));
+        for (int f = 0; f < c->n_fields; ++f) DISPATCH_LEN(c->nx, RC_TRY(pack_field<N_>(c, f)));
     }
 
     // centre-padded canvases, interleaved (psf0, var0, psf1, var1, ...)
@@ -630,11 +639,14 @@ static int ctx_init(psfmc_ctx* c, const double* sci, const double* obs_var, cons
     return PSFMC_OK;
 }
 
-extern "C" int psfmc_ctx_create(psfmc_ctx** out, int device, int ny, int nx, const double* sci,
-                                const double* obs_var, const uint8_t* bad_px, int n_psf,
-                                int psf_ny, int psf_nx, const double* psf, const double* psf_var,
-                                int n_ps, int n_sersic, int max_walkers, int backend) {
+static int ctx_create_impl(psfmc_ctx** out, int device, int ny, int nx, int n_fields, const double* sci,
+                           const double* obs_var, const uint8_t* bad_px, int n_psf,
+                           int psf_ny, int psf_nx, const double* psf, const double* psf_var,
+                           int n_ps, int n_sersic, int max_walkers, int backend) {
     if (!out) return fail(PSFMC_EINVAL, "out is NULL");
+    if (n_fields < 1 || n_fields > 4096) return fail(PSFMC_EINVAL, "n_fields out of range");
+    if (n_fields > 1 && backend != PSFMC_BACKEND_FUSED)
+        return fail(PSFMC_EINVAL, "several fields per context need the fused back end");
     *out = nullptr;
     if (!sci || !obs_var || !bad_px || !psf || !psf_var) return fail(PSFMC_EINVAL, "NULL input array");
     if (ny < 2 || nx < 2 || (ny & 1) || (nx & 1))
@@ -670,7 +682,8 @@ extern "C" int psfmc_ctx_create(psfmc_ctx** out, int device, int ny, int nx, con
     psfmc_ctx* c = new psfmc_ctx;
     c->device = device;
     c->ny = ny; c->nx = nx; c->nxh = nx / 2 + 1; c->S = ny * nx; c->F = ny * c->nxh;
-    c->n_psf = n_psf; c->n_ps = n_ps; c->n_sersic = n_sersic;
+    c->n_fields = n_fields; c->n_psf_field = n_psf;
+    c->n_psf = n_fields * n_psf; c->n_ps = n_ps; c->n_sersic = n_sersic;
     c->max_walkers = max_walkers; c->backend = backend;
     c->rlen = row_len(n_ps, n_sersic);
     c->plen = prep_len(n_ps, n_sersic);
@@ -712,6 +725,26 @@ extern "C" int psfmc_ctx_create(psfmc_ctx** out, int device, int ny, int nx, con
     return PSFMC_OK;
 }
 
+extern "C" int psfmc_ctx_create(psfmc_ctx** out, int device, int ny, int nx, const double* sci,
+                                const double* obs_var, const uint8_t* bad_px, int n_psf,
+                                int psf_ny, int psf_nx, const double* psf, const double* psf_var,
+                                int n_ps, int n_sersic, int max_walkers, int backend) {
+    return ctx_create_impl(out, device, ny, nx, 1, sci, obs_var, bad_px, n_psf, psf_ny, psf_nx, psf, psf_var, n_ps,
+                           n_sersic, max_walkers, backend);
+}
+
+// Several observed fields of one shape in ONE context (fused back end): their walkers share the
+// batches of psfmc_eval_theta_device_fields, so many small ensembles run at the rate of one large one
+// (BASELINE config 5: independent fields x 256 walkers each).  sci / obs_var / bad_px: [n_fields][ny][nx];
+// psf / psf_var: [n_fields][n_psf][psf_ny][psf_nx]; the same component counts for every field.
+extern "C" int psfmc_ctx_create_fields(psfmc_ctx** out, int device, int ny, int nx, int n_fields,
+                                       const double* sci, const double* obs_var, const uint8_t* bad_px,
+                                       int n_psf, int psf_ny, int psf_nx, const double* psf,
+                                       const double* psf_var, int n_ps, int n_sersic, int max_walkers) {
+    return ctx_create_impl(out, device, ny, nx, n_fields, sci, obs_var, bad_px, n_psf, psf_ny, psf_nx, psf, psf_var,
+                           n_ps, n_sersic, max_walkers, PSFMC_BACKEND_FUSED);
+}
+
 extern "C" int psfmc_ctx_destroy(psfmc_ctx* c) {
     if (!c) return PSFMC_OK;
     (void)hipSetDevice(c->device);
@@ -738,6 +771,8 @@ extern "C" int psfmc_ctx_destroy(psfmc_ctx* c) {
         }
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
     }
+    for (void* b : c->more_blobs)
+        if (b) (void)hipFree(b);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     for (int i = 0; i < psfmc_ctx::kMaxStreams; ++i)
         if (c->ev_stagger[i]) (void)hipEventDestroy(c->ev_stagger[i]);
@@ -962,12 +997,15 @@ static int eval_device(psfmc_ctx* c, int W, const double* d_rows, const uint8_t*
 
 // raw vectors (or, with sp.pos set, stretch-move proposals formed on the fly) -> prep
 // records, log-priors and skip flags of W walkers
+// `field` / `w_off`: walkers [w_off, w_off + W) of the batch belong to observed field `field` (0, 0
+// for the usual one-field context): its layout, its block of kernel spectra
 static void launch_theta_prep(psfmc_ctx* c, int W, const double* d_theta, const double* d_extra,
-                              double* d_rows, hipStream_t st, const StretchIn& sp) {
+                              double* d_rows, hipStream_t st, const StretchIn& sp, int field = 0, int w_off = 0) {
+    const ThetaLayout& L = field == 0 ? c->layout : c->more_layouts[field - 1];
     hipLaunchKernelGGL(k_theta_prep, dim3((W + kThetaThreads - 1) / kThetaThreads),
                        dim3(kThetaThreads, theta_task_waves(c->n_ps, c->n_sersic)), c->theta_lds, st,
-                       c->layout, d_theta, d_extra, d_rows, c->d_prep, c->d_lnprior, c->d_skip, W, c->ny,
-                       c->nx, c->d_rho, sp);
+                       L, d_theta, d_extra, d_rows, c->d_prep + (size_t)w_off * c->plen, c->d_lnprior + w_off,
+                       c->d_skip + w_off, W, c->ny, c->nx, c->d_rho, sp, field * c->n_psf_field);
 }
 
 // raw vectors -> log-posterior, everything on the device
@@ -1029,6 +1067,7 @@ static int ensure_image_staging(psfmc_ctx* c) {
 
 extern "C" int psfmc_eval_images(psfmc_ctx* c, int W, const double* rows, double* raw, double* conv,
                                  double* resid, double* ivm, double* ps_sub) {
+    if (c && c->n_fields > 1) return fail(PSFMC_EINVAL, "this entry point serves contexts of one field");
     int rc = check_call(c, W, rows, rows);
     if (rc != PSFMC_OK || W == 0) return rc;
     HIP_TRY(hipSetDevice(c->device));
@@ -1097,11 +1136,14 @@ extern "C" int psfmc_eval_images(psfmc_ctx* c, int W, const double* rows, double
 // ---------------------------------------------------------------------------
 // raw-vector path
 // ---------------------------------------------------------------------------
-extern "C" int psfmc_set_layout(psfmc_ctx* c, int n_sky, int n_params, const int* slot_col,
-                                const double* slot_const, const int* ps_method, const int* sersic_degrees,
-                                double mag_zeropoint, const int* family, const double* p0,
-                                const double* p1, const double* p2) {
+static int set_layout_impl(psfmc_ctx* c, int field, int n_sky, int n_params, const int* slot_col,
+                           const double* slot_const, const int* ps_method, const int* sersic_degrees,
+                           double mag_zeropoint, const int* family, const double* p0,
+                           const double* p1, const double* p2) {
     if (!c) return fail(PSFMC_EINVAL, "ctx is NULL");
+    if (field < 0 || field >= c->n_fields) return fail(PSFMC_EINVAL, "field %d of %d", field, c->n_fields);
+    if (field > 0 && (!c->has_layout || n_sky != c->layout.n_sky || n_params != c->layout.n_params))
+        return fail(PSFMC_EINVAL, "set field 0's layout first; every field has the same slots and columns");
     if (n_sky < 0 || n_sky > 16 || n_params < 0 || n_params > 4096) return fail(PSFMC_EINVAL, "bad counts");
     const int ns = n_slots(n_sky, c->n_ps, c->n_sersic);
     if (!slot_col || !slot_const || (c->n_ps && !ps_method) || (c->n_sersic && !sersic_degrees) ||
@@ -1133,18 +1175,28 @@ extern "C" int psfmc_set_layout(psfmc_ctx* c, int n_sky, int n_params, const int
         memcpy(dp + ns + 2 * n_params, p2, n_params * sizeof(double));
         for (int i = 0; i < n_params; ++i) dp[ns + 3 * n_params + i] = prior_log_norm(family[i], p0[i], p1[i], p2[i]);
     }
-    if (c->d_layout_blob) { (void)hipFree(c->d_layout_blob); c->d_layout_blob = nullptr; }
-    HIP_TRY(hipMalloc(&c->d_layout_blob, blob.size()));
-    HIP_TRY(hipMemcpy(c->d_layout_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
-    const int* dip = reinterpret_cast<const int*>(c->d_layout_blob);
-    const double* ddp = reinterpret_cast<const double*>(static_cast<unsigned char*>(c->d_layout_blob) + int_bytes);
-    ThetaLayout& L = c->layout;
-    L.n_sky = n_sky; L.n_ps = c->n_ps; L.n_sersic = c->n_sersic; L.n_params = n_params; L.n_psf = c->n_psf;
+    if (field > 0 && c->more_layouts.size() < (size_t)c->n_fields - 1) {
+        c->more_layouts.resize(c->n_fields - 1);
+        c->more_blobs.resize(c->n_fields - 1, nullptr);
+        c->more_has.resize(c->n_fields - 1, 0);
+    }
+    void** blob_slot = field == 0 ? &c->d_layout_blob : &c->more_blobs[field - 1];
+    if (*blob_slot) { (void)hipFree(*blob_slot); *blob_slot = nullptr; }
+    HIP_TRY(hipMalloc(blob_slot, blob.size()));
+    HIP_TRY(hipMemcpy(*blob_slot, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    const int* dip = reinterpret_cast<const int*>(*blob_slot);
+    const double* ddp = reinterpret_cast<const double*>(static_cast<unsigned char*>(*blob_slot) + int_bytes);
+    ThetaLayout& L = field == 0 ? c->layout : c->more_layouts[field - 1];
+    L.n_sky = n_sky; L.n_ps = c->n_ps; L.n_sersic = c->n_sersic; L.n_params = n_params; L.n_psf = c->n_psf_field;
     L.mag_zp = mag_zeropoint;
     L.slot_col = dip; L.ps_method = dip + ns; L.sersic_deg = dip + ns + c->n_ps;
     L.family = dip + ns + c->n_ps + c->n_sersic;
     L.slot_const = ddp; L.pa = ddp + ns; L.pb = ddp + ns + n_params; L.pc = ddp + ns + 2 * n_params;
     L.pk = ddp + ns + 3 * n_params;
+    if (field > 0) {
+        c->more_has[field - 1] = 1;
+        return PSFMC_OK;
+    }
     for (double** p : {&c->d_theta, &c->d_extra, &c->d_lnprior})
         if (*p) { (void)hipFree(*p); *p = nullptr; }
     HIP_TRY(hipMalloc(&c->d_theta, (size_t)c->max_walkers * (n_params > 0 ? n_params : 1) * sizeof(double)));
@@ -1157,6 +1209,24 @@ extern "C" int psfmc_set_layout(psfmc_ctx* c, int n_sky, int n_params, const int
     }
     c->has_layout = true;
     return PSFMC_OK;
+}
+
+extern "C" int psfmc_set_layout(psfmc_ctx* c, int n_sky, int n_params, const int* slot_col,
+                                const double* slot_const, const int* ps_method, const int* sersic_degrees,
+                                double mag_zeropoint, const int* family, const double* p0,
+                                const double* p1, const double* p2) {
+    return set_layout_impl(c, 0, n_sky, n_params, slot_col, slot_const, ps_method, sersic_degrees, mag_zeropoint,
+                           family, p0, p1, p2);
+}
+
+// the layout of one field of a psfmc_ctx_create_fields context (field 0 first; the same slot / column
+// structure for every field, their own constants and priors)
+extern "C" int psfmc_set_layout_field(psfmc_ctx* c, int field, int n_sky, int n_params, const int* slot_col,
+                                      const double* slot_const, const int* ps_method, const int* sersic_degrees,
+                                      double mag_zeropoint, const int* family, const double* p0,
+                                      const double* p1, const double* p2) {
+    return set_layout_impl(c, field, n_sky, n_params, slot_col, slot_const, ps_method, sersic_degrees,
+                           mag_zeropoint, family, p0, p1, p2);
 }
 
 static int check_theta_call(psfmc_ctx* c, int W, const void* theta, const void* out) {
@@ -1172,6 +1242,66 @@ extern "C" int psfmc_eval_theta_device(psfmc_ctx* c, int W, const double* d_thet
     if (rc != PSFMC_OK || W == 0) return rc;
     HIP_TRY(hipSetDevice(c->device));
     return eval_theta_device(c, W, d_theta, d_extra, d_lnprob, stream ? (hipStream_t)stream : c->stream);
+}
+
+// Walkers of several fields in one batch: segment i = seg_count[i] consecutive walkers of field
+// seg_field[i] (host arrays); d_theta [W][P] / d_lnprob [W] in that order, W = sum of the counts.
+// One record derivation per segment (its field's layout), then ONE pass of the likelihood pipeline
+// over all W walkers.
+extern "C" int psfmc_eval_theta_device_fields(psfmc_ctx* c, int n_seg, const int* seg_field, const int* seg_count,
+                                              const double* d_theta, const double* d_extra, double* d_lnprob,
+                                              void* stream) {
+    if (!c || n_seg < 0 || (n_seg && (!seg_field || !seg_count))) return fail(PSFMC_EINVAL, "bad segment list");
+    if (!c->has_layout) return fail(PSFMC_EINVAL, "psfmc_set_layout has not been called");
+    long long W = 0;
+    for (int i = 0; i < n_seg; ++i) {
+        if (seg_count[i] < 0 || seg_field[i] < 0 || seg_field[i] >= c->n_fields)
+            return fail(PSFMC_EINVAL, "segment %d: field %d, count %d", i, seg_field[i], seg_count[i]);
+        if (seg_field[i] > 0 && ((size_t)seg_field[i] > c->more_has.size() || !c->more_has[seg_field[i] - 1]))
+            return fail(PSFMC_EINVAL, "field %d has no layout (psfmc_set_layout_field)", seg_field[i]);
+        W += seg_count[i];
+    }
+    if (W > c->max_walkers) return fail(PSFMC_EINVAL, "W=%lld outside [0, max_walkers=%d]", W, c->max_walkers);
+    if (W == 0) return PSFMC_OK;
+    if (!d_lnprob || (c->layout.n_params > 0 && !d_theta)) return fail(PSFMC_EINVAL, "NULL buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    const int P = c->layout.n_params;
+    int off = 0;
+    for (int i = 0; i < n_seg; ++i) {
+        if (!seg_count[i]) continue;
+        launch_theta_prep(c, seg_count[i], d_theta + (size_t)off * P, d_extra ? d_extra + off : nullptr, nullptr, st,
+                          StretchIn{}, seg_field[i], off);
+        off += seg_count[i];
+    }
+    RC_TRY(run_pipeline(c, (int)W, c->d_skip, st));
+    hipLaunchKernelGGL(k_finish_posterior, dim3(finish_blocks((int)W)), dim3(kFinishThreads), 0, st, c->d_partial,
+                       c->d_skip, c->d_lnprior, d_lnprob, (int)W, c->nblk);
+    HIP_TRY(hipGetLastError());
+    return PSFMC_OK;
+}
+
+// host-buffer form of psfmc_eval_theta_device_fields
+extern "C" int psfmc_eval_theta_fields(psfmc_ctx* c, int n_seg, const int* seg_field, const int* seg_count,
+                                       const double* theta, const double* extra, double* lnprob) {
+    if (!c || n_seg < 0 || (n_seg && !seg_count)) return fail(PSFMC_EINVAL, "bad segment list");
+    if (!c->has_layout) return fail(PSFMC_EINVAL, "psfmc_set_layout has not been called");
+    long long W = 0;
+    for (int i = 0; i < n_seg; ++i) W += seg_count[i] > 0 ? seg_count[i] : 0;
+    if (W > c->max_walkers) return fail(PSFMC_EINVAL, "W=%lld outside [0, max_walkers=%d]", W, c->max_walkers);
+    if (W == 0) return PSFMC_OK;
+    if (!lnprob || (c->layout.n_params > 0 && !theta)) return fail(PSFMC_EINVAL, "NULL buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    if (c->layout.n_params)
+        HIP_TRY(hipMemcpyAsync(c->d_theta, theta, (size_t)W * c->layout.n_params * sizeof(double),
+                               hipMemcpyHostToDevice, st));
+    if (extra) HIP_TRY(hipMemcpyAsync(c->d_extra, extra, (size_t)W * sizeof(double), hipMemcpyHostToDevice, st));
+    RC_TRY(psfmc_eval_theta_device_fields(c, n_seg, seg_field, seg_count, c->d_theta, extra ? c->d_extra : nullptr,
+                                          c->d_like, st));
+    HIP_TRY(hipMemcpyAsync(lnprob, c->d_like, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return PSFMC_OK;
 }
 
 extern "C" int psfmc_eval_theta(psfmc_ctx* c, int W, const double* theta, const double* extra,
@@ -1398,6 +1528,7 @@ static int accumulate_from_prep(psfmc_ctx* c, int W, hipStream_t st) {
 }
 
 extern "C" int psfmc_accumulate_images(psfmc_ctx* c, int W, const double* rows) {
+    if (c && c->n_fields > 1) return fail(PSFMC_EINVAL, "this entry point serves contexts of one field");
     int rc = check_call(c, W, rows, rows);
     if (rc != PSFMC_OK || W == 0) return rc;
     HIP_TRY(hipSetDevice(c->device));
@@ -1429,6 +1560,7 @@ static int grow(Tp** p, size_t* cap, size_t need) {
 
 static int stretch_check(psfmc_ctx* c, int W) {
     if (!c) return fail(PSFMC_EINVAL, "ctx is NULL");
+    if (c && c->n_fields > 1) return fail(PSFMC_EINVAL, "this entry point serves contexts of one field");
     if (!c->has_layout) return fail(PSFMC_EINVAL, "psfmc_set_layout has not been called");
     if (W < 2 || (W & 1) || W > c->max_walkers) return fail(PSFMC_EINVAL, "W must be even, 2..max_walkers");
     const int P = c->layout.n_params;

@@ -267,7 +267,7 @@ k_theta_prep(ThetaLayout G, const double* __restrict__ theta,
              const double* __restrict__ extra, double* __restrict__ rows,
              double* __restrict__ prep, double* __restrict__ lnprior,
              uint8_t* __restrict__ skip, int W, int ny, int nx,
-             const double* __restrict__ rho, StretchIn sp) {
+             const double* __restrict__ rho, StretchIn sp, int psf_base) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int ns = n_slots(G.n_sky, G.n_ps, G.n_sersic);
     const int n_int = ((ns + G.n_ps + G.n_sersic + G.n_params + 1) / 2) * 2;
@@ -394,7 +394,8 @@ k_theta_prep(ThetaLayout G, const double* __restrict__ theta,
     if (threadIdx.y != 0 || !active) return;
     double peak = fabs(row[0]);
     for (int k = 0; k < G.n_ps + G.n_sersic; ++k) peak = fmax(peak, peak_tile[k * kThetaThreads + lw]);
-    prep_head(my_prep, row[0], (int)row[rlen - 1], peak, rho);
+    // psf_base: first kernel-spectrum index of this walker's field (contexts holding several fields)
+    prep_head(my_prep, row[0], psf_base + (int)row[rlen - 1], peak, rho);
     if (rows && ok) {
         double* out = rows + (size_t)w * rlen;
         for (int i = 0; i < rlen; ++i) out[i] = row[i];

@@ -112,6 +112,17 @@ def load_library():
     lib.psfmc_eval_theta.argtypes = [vp, ci, _c_double_p, _c_double_p, _c_double_p]
     lib.psfmc_eval_theta_device.restype = ci
     lib.psfmc_eval_theta_device.argtypes = [vp, ci, vp, vp, vp, vp]
+    ip = ctypes.POINTER(ctypes.c_int)
+    lib.psfmc_ctx_create_fields.restype = ci
+    lib.psfmc_ctx_create_fields.argtypes = [ctypes.POINTER(vp), ci, ci, ci, ci, _c_double_p, _c_double_p, _c_u8_p,
+                                            ci, ci, ci, _c_double_p, _c_double_p, ci, ci, ci]
+    lib.psfmc_set_layout_field.restype = ci
+    lib.psfmc_set_layout_field.argtypes = [vp, ci, ci, ci, ip, _c_double_p, ip, ip, ctypes.c_double, ip,
+                                           _c_double_p, _c_double_p, _c_double_p]
+    lib.psfmc_eval_theta_fields.restype = ci
+    lib.psfmc_eval_theta_fields.argtypes = [vp, ci, ip, ip, _c_double_p, _c_double_p, _c_double_p]
+    lib.psfmc_eval_theta_device_fields.restype = ci
+    lib.psfmc_eval_theta_device_fields.argtypes = [vp, ci, ip, ip, vp, vp, vp, vp]
     lib.psfmc_debug_theta_rows.restype = ci
     lib.psfmc_debug_theta_rows.argtypes = [vp, ci, _c_double_p, _c_double_p, _c_double_p, _c_u8_p]
     lib.psfmc_stretch_run.restype = ci
@@ -475,6 +486,120 @@ class Context(object):
 
     def get_option(self, key):
         return self._lib.psfmc_get_option(self._ctx, key.encode())
+
+
+class FieldSetContext(object):
+    """Several observed fields of ONE shape resident on one GPU in one context (wraps
+    `psfmc_ctx_create_fields`): their walkers share the batches, so many small ensembles run at the
+    rate of one large one.  Log-posteriors of raw parameter vectors only.
+
+    fields: sequence of (sci, obs_var, bad_px, psfs [n_psf, py, px], psf_vars) with the same shapes."""
+
+    def __init__(self, fields, n_ps, n_sersic, max_walkers=4096, device=0):
+        self._lib = load_library()
+        self._ctx = None
+        fields = list(fields)
+        if not fields:
+            raise ValueError('no field')
+        sci = _f64(np.stack([_f64(f[0]) for f in fields]))
+        var = _f64(np.stack([_f64(f[1]) for f in fields]))
+        bad = np.ascontiguousarray(np.stack([np.asarray(f[2]).astype(bool) for f in fields]), dtype=np.uint8)
+        psfs = _f64(np.stack([_f64(f[3]) for f in fields]))
+        pvar = _f64(np.stack([_f64(f[4]) for f in fields]))
+        if sci.ndim != 3 or var.shape != sci.shape or bad.shape != sci.shape:
+            raise ValueError('every field needs sci / obs_var / bad_px of one 2-D shape')
+        if psfs.ndim != 4 or pvar.shape != psfs.shape:
+            raise ValueError('every field needs psfs / psf_vars of one [n_psf, py, px] shape')
+        self.n_fields, self.shape, self.n_psf = len(fields), sci.shape[1:], psfs.shape[1]
+        self.n_ps, self.n_sersic = int(n_ps), int(n_sersic)
+        self.max_walkers, self.device = int(max_walkers), int(device)
+        self.n_params = None
+        handle = ctypes.c_void_p()
+        rc = self._lib.psfmc_ctx_create_fields(
+            ctypes.byref(handle), self.device, sci.shape[1], sci.shape[2], self.n_fields, _dp(sci), _dp(var),
+            bad.ctypes.data_as(_c_u8_p), self.n_psf, psfs.shape[2], psfs.shape[3], _dp(psfs), _dp(pvar),
+            self.n_ps, self.n_sersic, self.max_walkers)
+        self._check(rc)
+        self._ctx = handle
+
+    def _check(self, rc):
+        if rc != 0:
+            raise NativeError(rc, self._lib.psfmc_last_error().decode('utf-8', 'replace'))
+
+    def close(self):
+        if self._ctx is not None:
+            self._lib.psfmc_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, key, value):
+        self._check(self._lib.psfmc_set_option(self._ctx, key.encode(), float(value)))
+
+    def get_option(self, key):
+        return self._lib.psfmc_get_option(self._ctx, key.encode())
+
+    def layout_of(self, field):
+        """An object with the `set_layout` of a Context that registers field `field`'s layout."""
+        owner = self
+
+        class _Proxy(object):
+            def set_layout(self, n_sky, n_params, slot_col, slot_const, ps_method, sersic_degrees,
+                           mag_zeropoint, family, p0, p1, p2):
+                i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+                ipt = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+                sc, pm, sd, fam = map(i32, (slot_col, ps_method, sersic_degrees, family))
+                cst, a0, a1, a2 = map(_f64, (slot_const, p0, p1, p2))
+                owner._check(owner._lib.psfmc_set_layout_field(
+                    owner._ctx, int(field), int(n_sky), int(n_params), ipt(sc), _dp(cst), ipt(pm), ipt(sd),
+                    float(mag_zeropoint), ipt(fam), _dp(a0), _dp(a1), _dp(a2)))
+                if owner.n_params not in (None, int(n_params)):
+                    raise ValueError('every field must have the same number of free parameters')
+                owner.n_params = int(n_params)
+        return _Proxy()
+
+    @staticmethod
+    def _segments(seg_field, seg_count):
+        f = np.ascontiguousarray(seg_field, dtype=np.int32)
+        n = np.ascontiguousarray(seg_count, dtype=np.int32)
+        if f.shape != n.shape or f.ndim != 1:
+            raise ValueError('seg_field / seg_count must be 1-D arrays of one length')
+        ipt = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+        return f, n, ipt(f), ipt(n)
+
+    def logpost_theta(self, thetas):
+        """thetas: one [W_f, P] array per field (None or empty to leave a field out) -> list of [W_f]
+        log-posteriors (empty arrays for the fields left out)."""
+        if len(thetas) != self.n_fields:
+            raise ValueError('one parameter array per field')
+        parts = [(f, _f64(t)) for f, t in enumerate(thetas) if t is not None and len(t)]
+        outs = [np.empty(0) for _ in range(self.n_fields)]
+        if not parts:
+            return outs
+        for _, t in parts:
+            if t.ndim != 2 or t.shape[1] != self.n_params:
+                raise ValueError('theta must be [W, {}]'.format(self.n_params))
+        theta = _f64(np.concatenate([t for _, t in parts]))
+        if len(theta) > self.max_walkers:
+            raise ValueError('W={} exceeds max_walkers={}'.format(len(theta), self.max_walkers))
+        f, n, fp, np_ = self._segments([f for f, _ in parts], [len(t) for _, t in parts])
+        out = np.empty(len(theta))
+        self._check(self._lib.psfmc_eval_theta_fields(self._ctx, len(f), fp, np_, _dp(theta), None, _dp(out)))
+        off = 0
+        for fld, t in parts:
+            outs[fld] = out[off:off + len(t)].copy()
+            off += len(t)
+        return outs
+
+    def logpost_theta_device(self, seg_field, seg_count, d_theta, d_out, stream=None):
+        f, n, fp, np_ = self._segments(seg_field, seg_count)
+        self._check(self._lib.psfmc_eval_theta_device_fields(
+            self._ctx, len(f), fp, np_, ctypes.c_void_p(d_theta), None, ctypes.c_void_p(d_out),
+            ctypes.c_void_p(stream) if stream else None))
 
 
 class ContextGroup(object):

@@ -462,3 +462,45 @@ class MultiComponentModel(object):
                     step = 1 / img if kind == 'composite_ivm' else img
                     post[kind] = (post[kind] * (n - 1) + step) / n
             post['composite_ivm'] = 1 / post['composite_ivm']
+
+
+class FieldSet(object):
+    """Several fields of one image shape and one model structure (the same component lists, their own
+    data, constants and priors) evaluated in shared GPU batches: `engine.FieldSetContext`.  The
+    reference has no counterpart (one `MultiComponentModel` per model file and process,
+    psfMC/fitting.py:13-113); this is for surveys of many small fields, where a batch per field would
+    be dominated by its fixed cost (BASELINE config 5).
+
+    models: MultiComponentModel objects (or model files) whose priors all have a device form."""
+
+    def __init__(self, models, max_walkers=4096, device=0):
+        self.models = [m if isinstance(m, MultiComponentModel) else
+                       MultiComponentModel(m, device=device, backend='fused', max_walkers=1) for m in models]
+        first = self.models[0]
+        for m in self.models:
+            if (len(m._ps), len(m._sersic), len(m._sky), m.num_params) != \
+                    (len(first._ps), len(first._sersic), len(first._sky), first.num_params):
+                raise ValueError('the fields of a FieldSet need the same component lists and free parameters')
+        fields = []
+        for m in self.models:
+            sel = m.config.psf_selector
+            fields.append((m.config.obs_data, m.config.obs_var, m.config.bad_px, np.stack(sel.psf_data),
+                           np.stack(sel.psf_var)))
+        self.context = engine.FieldSetContext(fields, n_ps=len(first._ps), n_sersic=len(first._sersic),
+                                              max_walkers=max_walkers, device=device)
+        for f, m in enumerate(self.models):
+            m._register_layout(self.context.layout_of(f))
+            if m._host_priors:
+                raise ValueError('field {}: a prior has no device form; a FieldSet evaluates priors on the '
+                                 'GPU only'.format(f))
+        self.num_params = first.num_params
+
+    def log_posterior_batch(self, thetas):
+        """thetas: one [W_f, num_params] array per field -> list of [W_f] log-posteriors."""
+        return self.context.logpost_theta(thetas)
+
+    def close(self):
+        self.context.close()
+        for m in self.models:
+            m.close()
+

@@ -122,6 +122,41 @@ def test_config5_share_eight_fields_of_256_walkers():
         model.close()
 
 
+def test_field_set_shares_batches_between_fields():
+    """`FieldSet` / psfmc_ctx_create_fields: 8 independent 256^2 fields x 256 walkers in ONE context
+    and one batch (BASELINE config 5's per-GPU share as it is meant to run): every field's
+    log-posteriors equal those of its own one-field context bit for bit, uneven and empty segments
+    included; entry points that need a single field refuse."""
+    from test_gpu_fullsize import make_model
+    from psfmc_amd import FieldSet, engine
+    models = [make_model(256, 1, 'fused', max_walkers=256, seed=s) for s in range(8)]
+    thetas = [synth_field.draw_walkers(256, 1, 256, seed=90 + i, near_truth=fld['truth'])
+              for i, (_, fld) in enumerate(models)]
+    alone = [m.log_posterior_batch(t) for (m, _), t in zip(models, thetas)]
+    fresh = [make_model(256, 1, 'fused', max_walkers=1, seed=s)[0] for s in range(8)]
+    fs = FieldSet(fresh, max_walkers=2048)
+    assert fs.context.n_fields == 8 and fs.num_params == models[0][0].num_params
+    got = fs.log_posterior_batch(thetas)
+    for f in range(8):
+        assert np.array_equal(got[f], alone[f]), f
+    # uneven shares, a field left out, a single walker
+    part = [thetas[0][:5], None, thetas[2][:1], thetas[3][:0], thetas[4][7:100], thetas[5], thetas[6][:33], thetas[7][250:]]
+    got = fs.log_posterior_batch(part)
+    for f, t in enumerate(part):
+        if t is None or len(t) == 0:
+            assert len(got[f]) == 0
+        else:
+            lo = {4: 7, 7: 250}.get(f, 0)
+            assert np.array_equal(got[f], alone[f][lo:lo + len(t)]), f
+    with pytest.raises(ValueError):
+        fs.log_posterior_batch([np.vstack([t, t]) for t in thetas])          # 4096 > max_walkers
+    with pytest.raises(engine.NativeError):                                   # a one-field entry point
+        fs.context._check(fs.context._lib.psfmc_accumulate_images(fs.context._ctx, 1, None))
+    fs.close()
+    for m, _ in models:
+        m.close()
+
+
 def test_device_group_splits_walkers_over_devices(tmp_path):
     """psfmc_group_* (one process, several devices): with the one GPU of the test box listed
     twice the walkers are split over two contexts; results equal the single context's bit for
