@@ -585,7 +585,10 @@ k_cols3(TS* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restri
 // partial[w][yg] = sum over the wave's good pixels of the chi^2 term.
 // conv_out / var_out (optional): [n][ny][nx] images (psfmc_eval_images)
 // ---------------------------------------------------------------------------
-template <int NX, typename TS = cd, bool FAST = FftShape<NX>::kPlain>
+// MULTI: the context holds several observed fields (psfmc_ctx_create_fields) -- its own instantiation,
+// so that the one-field kernel keeps its registers (at nx = 1024 two more kernel arguments pushed the
+// scalar registers over their limit and the kernel to one wave per SIMD: 33.7 -> 39.6 us)
+template <int NX, typename TS = cd, bool FAST = FftShape<NX>::kPlain, bool MULTI = false>
 __global__ void __launch_bounds__((row_threads<NX, FAST>()), fused_min_waves<NX>())
 k_rows_inv(const TS* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const cd* __restrict__ twx,
            const FieldPx* __restrict__ field, double* __restrict__ partial, int ny,
@@ -712,8 +715,8 @@ k_rows_inv(const TS* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
     // that holds no pixel at all) skip the selects.
     // contexts that hold several observed fields: the walker's field is the quotient of its
     // (field * PSFs-per-field + PSF) index; field_stride = packed pixels of one field
-    const int fid = n_psf_field > 0 ? (int)prep[(size_t)w * plen + kPrepPsfIdx] / n_psf_field : 0;
-    const FieldPx* fbase = field + (size_t)fid * field_stride + (size_t)yg * R * 64;   // wave-uniform
+    const FieldPx* fbase = field + (size_t)yg * R * 64;                                // wave-uniform
+    if constexpr (MULTI) fbase += (size_t)((int)prep[(size_t)w * plen + kPrepPsfIdx] / n_psf_field) * field_stride;
     const unsigned foff = (unsigned)lane * (unsigned)sizeof(FieldPx);
     FieldPx px[R];
     bool any_bad = false;

@@ -387,23 +387,35 @@ static int launch_cols(psfmc_ctx* c, void* Tvoid, int n_w, const double* prep, c
   }
 }
 
-template <int NX, typename TS, bool FAST>
-static int launch_rows_inv_impl(psfmc_ctx* c, int n, const TS* Tbuf, const double* prep, const uint8_t* skip,
-                                double* partial, double* conv_out, double* var_out, hipStream_t st) {
+template <int NX, typename TS, bool FAST, bool MULTI>
+static int launch_rows_inv_kernel(psfmc_ctx* c, int n, const TS* Tbuf, const double* prep, const uint8_t* skip,
+                                  double* partial, double* conv_out, double* var_out, hipStream_t st) {
     constexpr size_t lds = fused_row_lds_bytes<NX, FAST>();
     if constexpr (lds > 64 * 1024) {
         static thread_local int attr_device = -1;
         if (attr_device != c->device) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows_inv<NX, TS, FAST>),
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows_inv<NX, TS, FAST, MULTI>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_device = c->device;
         }
     }
     constexpr int waves = row_waves<NX, FAST>();
-    hipLaunchKernelGGL((k_rows_inv<NX, TS, FAST>), dim3((c->nblk + waves - 1) / waves, n),
+    hipLaunchKernelGGL((k_rows_inv<NX, TS, FAST, MULTI>), dim3((c->nblk + waves - 1) / waves, n),
                        dim3((row_threads<NX, FAST>())), lds, st, Tbuf, skip, c->d_twx, c->d_field, partial, c->ny,
-                       prep, c->plen, conv_out, var_out, c->n_fields > 1 ? c->n_psf_field : 0, (unsigned)c->field_len);
+                       prep, c->plen, conv_out, var_out, c->n_psf_field, (unsigned)c->field_len);
     return PSFMC_OK;
+}
+
+template <int NX, typename TS, bool FAST>
+static int launch_rows_inv_impl(psfmc_ctx* c, int n, const TS* Tbuf, const double* prep, const uint8_t* skip,
+                                double* partial, double* conv_out, double* var_out, hipStream_t st) {
+    if constexpr (sizeof(TS) == sizeof(cd)) {
+        if (c->n_fields > 1)
+            return launch_rows_inv_kernel<NX, TS, FAST, true>(c, n, Tbuf, prep, skip, partial, conv_out, var_out, st);
+    } else {
+        if (c->n_fields > 1) return fail(PSFMC_EINVAL, "single-precision storage serves contexts of one field");
+    }
+    return launch_rows_inv_kernel<NX, TS, FAST, false>(c, n, Tbuf, prep, skip, partial, conv_out, var_out, st);
 }
 
 template <int NX, typename TS = cd>
