@@ -716,7 +716,9 @@ k_rows_inv(const TS* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
     // contexts that hold several observed fields: the walker's field is the quotient of its
     // (field * PSFs-per-field + PSF) index; field_stride = packed pixels of one field
     const FieldPx* fbase = field + (size_t)yg * R * 64;                                // wave-uniform
-    if constexpr (MULTI) fbase += (size_t)((int)prep[(size_t)w * plen + kPrepPsfIdx] / n_psf_field) * field_stride;
+    // (below nx = 1024 the one kernel serves both kinds of context: n_psf_field = 0 marks one field)
+    if (MULTI || (NX < 1024 && n_psf_field > 0))
+        fbase += (size_t)((int)prep[(size_t)w * plen + kPrepPsfIdx] / n_psf_field) * field_stride;
     const unsigned foff = (unsigned)lane * (unsigned)sizeof(FieldPx);
     FieldPx px[R];
     bool any_bad = false;

@@ -402,17 +402,17 @@ static int launch_rows_inv_kernel(psfmc_ctx* c, int n, const TS* Tbuf, const dou
     constexpr int waves = row_waves<NX, FAST>();
     hipLaunchKernelGGL((k_rows_inv<NX, TS, FAST, MULTI>), dim3((c->nblk + waves - 1) / waves, n),
                        dim3((row_threads<NX, FAST>())), lds, st, Tbuf, skip, c->d_twx, c->d_field, partial, c->ny,
-                       prep, c->plen, conv_out, var_out, c->n_psf_field, (unsigned)c->field_len);
+                       prep, c->plen, conv_out, var_out, c->n_fields > 1 ? c->n_psf_field : 0, (unsigned)c->field_len);
     return PSFMC_OK;
 }
 
 template <int NX, typename TS, bool FAST>
 static int launch_rows_inv_impl(psfmc_ctx* c, int n, const TS* Tbuf, const double* prep, const uint8_t* skip,
                                 double* partial, double* conv_out, double* var_out, hipStream_t st) {
-    if constexpr (sizeof(TS) == sizeof(cd)) {
+    if constexpr (sizeof(TS) == sizeof(cd) && NX >= 1024) {
         if (c->n_fields > 1)
             return launch_rows_inv_kernel<NX, TS, FAST, true>(c, n, Tbuf, prep, skip, partial, conv_out, var_out, st);
-    } else {
+    } else if constexpr (sizeof(TS) != sizeof(cd)) {
         if (c->n_fields > 1) return fail(PSFMC_EINVAL, "single-precision storage serves contexts of one field");
     }
     return launch_rows_inv_kernel<NX, TS, FAST, false>(c, n, Tbuf, prep, skip, partial, conv_out, var_out, st);

@@ -157,6 +157,26 @@ def test_field_set_shares_batches_between_fields():
         m.close()
 
 
+@pytest.mark.parametrize('side,n_sersic', [(1024, 2), (200, 1), (64, 1)])
+def test_field_set_other_shapes(side, n_sersic):
+    """Two fields in one context at nx = 1024 (the inverse row kernel's own multi-field instantiation),
+    a general shape and the smallest one: bit-identical to the fields' own contexts."""
+    from test_gpu_fullsize import make_model
+    from psfmc_amd import FieldSet
+    own = [make_model(side, n_sersic, 'fused', max_walkers=8, seed=s) for s in (3, 4)]
+    thetas = [synth_field.draw_walkers(side, n_sersic, 7, seed=20 + i, near_truth=fld['truth'])
+              for i, (_, fld) in enumerate(own)]
+    alone = [m.log_posterior_batch(t) for (m, _), t in zip(own, thetas)]
+    fs = FieldSet([make_model(side, n_sersic, 'fused', max_walkers=1, seed=s)[0] for s in (3, 4)], max_walkers=16)
+    got = fs.log_posterior_batch(thetas)
+    assert np.isfinite(got[0]).all() and not np.array_equal(got[0], got[1])
+    for f in range(2):
+        assert np.array_equal(got[f], alone[f]), f
+    fs.close()
+    for m, _ in own:
+        m.close()
+
+
 def test_device_group_splits_walkers_over_devices(tmp_path):
     """psfmc_group_* (one process, several devices): with the one GPU of the test box listed
     twice the walkers are split over two contexts; results equal the single context's bit for
