@@ -27,6 +27,9 @@
 // Reference: psfMC/models.py:213-216, 233-236; utils.py:25-32 (convolve: the
 // ifftshift is the (-1)^(kx+ky) sign folded into Kt, as is 1/(nx*ny)).
 #pragma once
+#ifndef PSFMC_PART
+#define PSFMC_PART 0      /* single translation unit (see psfmc_hip.hip) */
+#endif
 #include "psfmc_device.h"
 #include "psfmc_fft.h"
 
@@ -849,6 +852,7 @@ __global__ void __launch_bounds__(64) k_raster_sums(const double* __restrict__ p
 }
 
 // lin[i] += part[0][i] + part[1][i] + ... (fixed order)
+#if PSFMC_PART == 0          /* not a template: defined in the API part only */
 __global__ void k_sum_partials(const double* __restrict__ part, int n_groups, double* __restrict__ lin, size_t n_el) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_el; i += (size_t)gridDim.x * blockDim.x) {
         double s = 0.0;
@@ -856,12 +860,14 @@ __global__ void k_sum_partials(const double* __restrict__ part, int n_groups, do
         lin[i] += s;
     }
 }
+#endif
 
 // Kt[psf][kx][c][ky] = spec_c[psf][ky][kx] * (-1)^(kx+ky) / S from the
 // column-transformed PSF buffer (T layout with ky in place of y; its c = 1 half
 // already carries the channel scale rho[psf], which stays in Kt).  k_rows_fwd leaves
 // every spectrum doubled: `inv_s` carries 1/2 for the PSF's own doubling and 1/2 for
 // the doubling of the model spectra it will multiply.
+#if PSFMC_PART == 0          /* not a template: defined in the API part only */
 __global__ void k_scale_kernel_spectrum(const cd* __restrict__ raw, cd* __restrict__ Kt, int n_total,
                                         int ny, int nxh, int rg_log2, double inv_s) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_total; i += gridDim.x * blockDim.x) {
@@ -874,8 +880,10 @@ __global__ void k_scale_kernel_spectrum(const cd* __restrict__ raw, cd* __restri
         Kt[i] = cd{v.x * sc, v.y * sc};
     }
 }
+#endif
 
 // natural-layout copy for psfmc_get_spectra: out[psf][ky][kx] of component c
+#if PSFMC_PART == 0          /* not a template: defined in the API part only */
 __global__ void k_untranspose_spectrum(const cd* __restrict__ raw, cd* __restrict__ out, int n_psf,
                                        int c, int ny, int nxh, int rg_log2,
                                        const double* __restrict__ rho) {
@@ -889,5 +897,6 @@ __global__ void k_untranspose_spectrum(const cd* __restrict__ raw, cd* __restric
         out[i] = cd{v.x * sc, v.y * sc};
     }
 }
+#endif
 
 }  // namespace psfmc

@@ -2,6 +2,14 @@
 // gfx950 only.  Build: psfmc_amd/csrc/Makefile (hipcc --offload-arch=gfx950).
 #include "../../include/psfmc_hip.h"
 
+// The file compiles either as one translation unit (PSFMC_NPARTS undefined: everything) or as
+// PSFMC_NPARTS = 4 of them built in parallel (csrc/Makefile): every part instantiates the per-side
+// kernels of its share of the sides behind psfmc_size_call_part<k>; part 0 is also the API.
+#ifndef PSFMC_NPARTS
+#define PSFMC_NPARTS 1
+#define PSFMC_PART 0
+#endif
+
 #include <hip/hip_runtime.h>
 #include <hipfft/hipfft.h>
 
@@ -15,7 +23,9 @@
 #include <vector>
 
 #include "psfmc_device.h"
+#if PSFMC_PART == 0
 #include "psfmc_hipfft_path.h"
+#endif
 #include "psfmc_fused_path.h"
 #include "psfmc_theta.h"
 
@@ -24,9 +34,14 @@ using namespace psfmc;
 // ---------------------------------------------------------------------------
 // error plumbing
 // ---------------------------------------------------------------------------
+#define PSFMC_NOT_MINE (-1000)          /* a part's answer for a side another part builds */
+
+int psfmc_fail_(int code, const char* fmt, ...);
+#define fail psfmc_fail_
+#if PSFMC_PART == 0
 static thread_local std::string g_err;
 
-static int fail(int code, const char* fmt, ...) {
+int psfmc_fail_(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -35,6 +50,7 @@ static int fail(int code, const char* fmt, ...) {
     g_err = buf;
     return code;
 }
+#endif
 
 #define HIP_TRY(expr)                                                                   \
     do {                                                                                \
@@ -62,7 +78,9 @@ static int fail(int code, const char* fmt, ...) {
 // sides the fused kernels are instantiated for (FftShape in psfmc_fft.h): every power of two
 // 64..1024 and the even 5- and 7-smooth sides listed there
 #define PSFMC_FUSED_SIDES "64 84 96 98 100 112 120 126 128 140 144 150 160 168 180 192 196 200 210 224 240 250 252 256 280 288 294 300 320 336 350 360 384 392 400 420 448 480 500 504 512 560 576 600 630 640 672 700 720 768 784 800 840 896 900 960 1024"
-// run BODY with `N_` a compile-time copy of the length n
+// run BODY with `N_` a compile-time copy of the length n; in a split build only for this part's sides
+// (side i of the list belongs to part i mod PSFMC_NPARTS)
+#if PSFMC_NPARTS == 1
 #define DISPATCH_LEN(n, BODY) \
     switch (n) { \
         case 64: { constexpr int N_ = 64; BODY; } break; \
@@ -124,6 +142,84 @@ static int fail(int code, const char* fmt, ...) {
         case 1024: { constexpr int N_ = 1024; BODY; } break; \
         default: return fail(PSFMC_EINVAL, "fused backend: side %d is not one of " PSFMC_FUSED_SIDES, n); \
     }
+#elif PSFMC_PART == 0
+#define DISPATCH_LEN(n, BODY) \
+    switch (n) { \
+        case 64: { constexpr int N_ = 64; BODY; } break; \
+        case 100: { constexpr int N_ = 100; BODY; } break; \
+        case 128: { constexpr int N_ = 128; BODY; } break; \
+        case 160: { constexpr int N_ = 160; BODY; } break; \
+        case 196: { constexpr int N_ = 196; BODY; } break; \
+        case 240: { constexpr int N_ = 240; BODY; } break; \
+        case 280: { constexpr int N_ = 280; BODY; } break; \
+        case 320: { constexpr int N_ = 320; BODY; } break; \
+        case 384: { constexpr int N_ = 384; BODY; } break; \
+        case 448: { constexpr int N_ = 448; BODY; } break; \
+        case 512: { constexpr int N_ = 512; BODY; } break; \
+        case 630: { constexpr int N_ = 630; BODY; } break; \
+        case 720: { constexpr int N_ = 720; BODY; } break; \
+        case 840: { constexpr int N_ = 840; BODY; } break; \
+        case 1024: { constexpr int N_ = 1024; BODY; } break; \
+        default: return PSFMC_NOT_MINE; \
+    }
+#elif PSFMC_PART == 1
+#define DISPATCH_LEN(n, BODY) \
+    switch (n) { \
+        case 84: { constexpr int N_ = 84; BODY; } break; \
+        case 112: { constexpr int N_ = 112; BODY; } break; \
+        case 140: { constexpr int N_ = 140; BODY; } break; \
+        case 168: { constexpr int N_ = 168; BODY; } break; \
+        case 200: { constexpr int N_ = 200; BODY; } break; \
+        case 250: { constexpr int N_ = 250; BODY; } break; \
+        case 288: { constexpr int N_ = 288; BODY; } break; \
+        case 336: { constexpr int N_ = 336; BODY; } break; \
+        case 392: { constexpr int N_ = 392; BODY; } break; \
+        case 480: { constexpr int N_ = 480; BODY; } break; \
+        case 560: { constexpr int N_ = 560; BODY; } break; \
+        case 640: { constexpr int N_ = 640; BODY; } break; \
+        case 768: { constexpr int N_ = 768; BODY; } break; \
+        case 896: { constexpr int N_ = 896; BODY; } break; \
+        default: return PSFMC_NOT_MINE; \
+    }
+#elif PSFMC_PART == 2
+#define DISPATCH_LEN(n, BODY) \
+    switch (n) { \
+        case 96: { constexpr int N_ = 96; BODY; } break; \
+        case 120: { constexpr int N_ = 120; BODY; } break; \
+        case 144: { constexpr int N_ = 144; BODY; } break; \
+        case 180: { constexpr int N_ = 180; BODY; } break; \
+        case 210: { constexpr int N_ = 210; BODY; } break; \
+        case 252: { constexpr int N_ = 252; BODY; } break; \
+        case 294: { constexpr int N_ = 294; BODY; } break; \
+        case 350: { constexpr int N_ = 350; BODY; } break; \
+        case 400: { constexpr int N_ = 400; BODY; } break; \
+        case 500: { constexpr int N_ = 500; BODY; } break; \
+        case 576: { constexpr int N_ = 576; BODY; } break; \
+        case 672: { constexpr int N_ = 672; BODY; } break; \
+        case 784: { constexpr int N_ = 784; BODY; } break; \
+        case 900: { constexpr int N_ = 900; BODY; } break; \
+        default: return PSFMC_NOT_MINE; \
+    }
+#elif PSFMC_PART == 3
+#define DISPATCH_LEN(n, BODY) \
+    switch (n) { \
+        case 98: { constexpr int N_ = 98; BODY; } break; \
+        case 126: { constexpr int N_ = 126; BODY; } break; \
+        case 150: { constexpr int N_ = 150; BODY; } break; \
+        case 192: { constexpr int N_ = 192; BODY; } break; \
+        case 224: { constexpr int N_ = 224; BODY; } break; \
+        case 256: { constexpr int N_ = 256; BODY; } break; \
+        case 300: { constexpr int N_ = 300; BODY; } break; \
+        case 360: { constexpr int N_ = 360; BODY; } break; \
+        case 420: { constexpr int N_ = 420; BODY; } break; \
+        case 504: { constexpr int N_ = 504; BODY; } break; \
+        case 600: { constexpr int N_ = 600; BODY; } break; \
+        case 700: { constexpr int N_ = 700; BODY; } break; \
+        case 800: { constexpr int N_ = 800; BODY; } break; \
+        case 960: { constexpr int N_ = 960; BODY; } break; \
+        default: return PSFMC_NOT_MINE; \
+    }
+#endif
 
 // ---------------------------------------------------------------------------
 // context
@@ -219,88 +315,8 @@ struct psfmc_ctx {
     } stretch;
 };
 
-static int flush_linear_sums(psfmc_ctx* c);   // posterior-image sums: see psfmc_reset_accumulated
-
-// ---------------------------------------------------------------------------
-// hipFFT plans, cached per batch size (a half-ensemble call and a full-ensemble
-// call use different sizes)
-// ---------------------------------------------------------------------------
-static int use_plans(psfmc_ctx* c, int batch) {
-    auto it = c->plans.find(batch);
-    if (it == c->plans.end()) {
-        if (c->plans.size() >= 8) {
-            for (auto& kv : c->plans) {
-                hipfftDestroy(kv.second.first);
-                hipfftDestroy(kv.second.second);
-            }
-            c->plans.clear();
-        }
-        int n[2] = {c->ny, c->nx};
-        hipfftHandle f = 0, b = 0;
-        FFT_TRY(hipfftPlanMany(&f, 2, n, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_D2Z, batch));
-        FFT_TRY(hipfftPlanMany(&b, 2, n, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_Z2D, batch));
-        it = c->plans.emplace(batch, std::make_pair(f, b)).first;
-    }
-    c->plan_fwd = it->second.first;
-    c->plan_inv = it->second.second;
-    return PSFMC_OK;
-}
-
-static void free_work(psfmc_ctx* c) {
-    void** bufs[] = {(void**)&c->d_real, (void**)&c->d_spec, (void**)&c->d_Ts[0], (void**)&c->d_Ts[1],
-                     (void**)&c->d_Ts[2], (void**)&c->d_Ts[3]};
-    for (void** p : bufs)
-        if (*p) {
-            (void)hipFree(*p);
-            *p = nullptr;
-        }
-    c->d_T = nullptr;
-}
-
-static int alloc_work(psfmc_ctx* c) {
-    free_work(c);
-    if (c->backend == PSFMC_BACKEND_HIPFFT) {
-        const size_t nimg = (size_t)2 * c->chunk;
-        HIP_TRY(hipMalloc(&c->d_real, nimg * c->S * sizeof(double)));
-        HIP_TRY(hipMalloc(&c->d_spec, nimg * c->F * sizeof(double2)));
-        return use_plans(c, (int)nimg);
-    }
-    // buffer 0 also serves batches of up to two chunks that run as ONE pass (run_pipeline)
-    c->single_cap = 2 * c->chunk < c->max_walkers ? 2 * c->chunk : c->max_walkers;
-    if (c->single_cap < c->chunk) c->single_cap = c->chunk;
-    for (int i = 0; i < c->n_streams; ++i)
-        HIP_TRY(hipMalloc(&c->d_Ts[i], (size_t)(i ? c->chunk : c->single_cap) * 2 * c->nxh * c->nyp *
-                                           (c->t_f32 ? sizeof(cf) : sizeof(cd))));
-    c->d_T = c->d_Ts[0];
-    return PSFMC_OK;
-}
-
-// Walkers per internal pass of the fused path: the transposed half-spectra of one pass
-// (two passes in flight, together just under the 256 MiB Infinity Cache: measured
-// best at 256^2 -- 104..120 walkers; 136 and more fall off -- see DESIGN.md).
-// Never rounded UP past that budget: 32 walkers at 512^2 (2 x 135 MB) ran 6 % slower than
-// 24, 16 at 1024^2 8 % slower than 6 (gpurun_out r2i sweep).
-static int fused_pass_walkers(const psfmc_ctx* c) {
-    const double per_walker = 2.0 * c->nxh * c->nyp * (c->t_f32 ? 8.0 : 16.0);
-    const int fit = (int)(112.0 * 1048576.0 / per_walker);
-    int chunk = fit >= 64 ? ((fit + 4) & ~7) : fit >= 16 ? (fit & ~7) : (fit & ~1);
-    return chunk < 4 ? 4 : chunk;
-}
-
-static bool fused_side(int n) {
-    static const int sides[] = {64,84,96,98,100,112,120,126,128,140,144,150,160,168,180,192,196,200,210,224,240,250,252,256,280,288,294,300,320,336,350,360,384,392,400,420,448,480,500,504,512,560,576,600,630,640,672,700,720,768,784,800,840,896,900,960,1024};
-    for (int v : sides)
-        if (v == n) return true;
-    return false;
-}
-
 // per-side constants of the row kernels
 struct RowShape { int rg, fast_waves, fast_rg_log2, regs; bool plain; };
-static int row_shape_for(int nx, RowShape* out) {
-    DISPATCH_LEN(nx, (*out = RowShape{row_group<N_>(), row_waves<N_, true>(), layout_rg_log2<N_, true>(),
-                                      FftShape<N_>::R, FftShape<N_>::kPlain}));
-    return PSFMC_OK;
-}
 
 // ---------------------------------------------------------------------------
 // fused path launchers
@@ -444,6 +460,192 @@ template <int NX> static int pack_field(psfmc_ctx* c, int f) {
     return PSFMC_OK;
 }
 
+template <int NX>
+static int launch_raster_sums(psfmc_ctx* c, int n, const double* prep, int groups, int group_size, hipStream_t st) {
+    constexpr int RG = FftShape<NX>::TPW;
+    hipLaunchKernelGGL((k_raster_sums<NX>), dim3((c->ny + RG - 1) / RG, groups), dim3(64), 0, st, prep, c->plen, n,
+                       group_size, c->n_ps, c->n_sersic, c->ny, c->n_psf, c->d_linpart);
+    return PSFMC_OK;
+}
+
+
+// ---------------------------------------------------------------------------
+// size-erased entry to the per-side launchers: what crosses the boundary between the parts
+// ---------------------------------------------------------------------------
+enum SizeOp { SZ_ROW_SHAPE, SZ_FIELD_LEN, SZ_PACK_FIELD, SZ_ROWS_FWD, SZ_COLS, SZ_ROWS_INV, SZ_RASTER_SUMS };
+struct SizeCall {
+    psfmc_ctx* c = nullptr;
+    int n = 0;                              // walkers
+    const double* prep = nullptr;
+    const uint8_t* skip = nullptr;
+    void* T = nullptr;
+    int ps_only = 0;
+    const double *img = nullptr, *img_scale = nullptr;
+    double *raw_out = nullptr, *partial = nullptr, *conv_out = nullptr, *var_out = nullptr;
+    hipStream_t st = nullptr;
+    bool from_image = false, convolve = true, f32 = false;
+    int field = 0, groups = 0, group_size = 0, ny = 0;
+    RowShape* shape = nullptr;
+    size_t* len = nullptr;
+};
+
+static int size_call_here(int op, int side, SizeCall& a) {
+    psfmc_ctx* c = a.c;
+    switch (op) {
+        case SZ_ROW_SHAPE:
+            DISPATCH_LEN(side, (*a.shape = RowShape{row_group<N_>(), row_waves<N_, true>(), layout_rg_log2<N_, true>(),
+                                                    FftShape<N_>::R, FftShape<N_>::kPlain}));
+            return PSFMC_OK;
+        case SZ_FIELD_LEN:
+            DISPATCH_LEN(side, *a.len = fused_field_len<N_>(a.ny));
+            return PSFMC_OK;
+        case SZ_PACK_FIELD:
+            DISPATCH_LEN(side, RC_TRY(pack_field<N_>(c, a.field)));
+            return PSFMC_OK;
+        case SZ_ROWS_FWD:
+            if (a.from_image) {
+                DISPATCH_LEN(side, RC_TRY((launch_rows_fwd<N_, true>(c, a.n, a.prep, a.skip, a.T, a.ps_only, a.img,
+                                                                     a.img_scale, a.raw_out, a.st))));
+            } else if (a.f32) {
+                DISPATCH_LEN(side, RC_TRY((launch_rows_fwd<N_, false, cf>(c, a.n, a.prep, a.skip, a.T, a.ps_only, a.img,
+                                                                          a.img_scale, a.raw_out, a.st))));
+            } else {
+                DISPATCH_LEN(side, RC_TRY((launch_rows_fwd<N_, false>(c, a.n, a.prep, a.skip, a.T, a.ps_only, a.img,
+                                                                      a.img_scale, a.raw_out, a.st))));
+            }
+            return PSFMC_OK;
+        case SZ_COLS:
+            if (!a.convolve) {
+                DISPATCH_LEN(side, RC_TRY((launch_cols<N_, false>(c, a.T, a.n, a.prep, a.skip, a.st))));
+            } else if (a.f32) {
+                DISPATCH_LEN(side, RC_TRY((launch_cols<N_, true, cf>(c, a.T, a.n, a.prep, a.skip, a.st))));
+            } else {
+                DISPATCH_LEN(side, RC_TRY((launch_cols<N_, true>(c, a.T, a.n, a.prep, a.skip, a.st))));
+            }
+            return PSFMC_OK;
+        case SZ_ROWS_INV:
+            if (a.f32) {
+                DISPATCH_LEN(side, RC_TRY((launch_rows_inv<N_, cf>(c, a.n, a.T, a.prep, a.skip, a.partial, a.conv_out,
+                                                                   a.var_out, a.st))));
+            } else {
+                DISPATCH_LEN(side, RC_TRY((launch_rows_inv<N_>(c, a.n, a.T, a.prep, a.skip, a.partial, a.conv_out,
+                                                               a.var_out, a.st))));
+            }
+            return PSFMC_OK;
+        case SZ_RASTER_SUMS:
+            DISPATCH_LEN(side, RC_TRY((launch_raster_sums<N_>(c, a.n, a.prep, a.groups, a.group_size, a.st))));
+            return PSFMC_OK;
+    }
+    return fail(PSFMC_EINVAL, "unknown size operation %d", op);
+}
+
+#define PSFMC_PART_FN_(k) psfmc_size_call_part##k
+#define PSFMC_PART_FN(k) PSFMC_PART_FN_(k)
+int psfmc_size_call_part0(int op, int side, void* args);
+#if PSFMC_NPARTS > 1
+int psfmc_size_call_part1(int op, int side, void* args);
+int psfmc_size_call_part2(int op, int side, void* args);
+int psfmc_size_call_part3(int op, int side, void* args);
+#endif
+int PSFMC_PART_FN(PSFMC_PART)(int op, int side, void* args) { return size_call_here(op, side, *static_cast<SizeCall*>(args)); }
+
+#if PSFMC_PART == 0
+static int size_call(int op, int side, SizeCall& a) {
+#if PSFMC_NPARTS == 1
+    return size_call_here(op, side, a);
+#else
+    int (*const parts[])(int, int, void*) = {psfmc_size_call_part0, psfmc_size_call_part1, psfmc_size_call_part2,
+                                             psfmc_size_call_part3};
+    for (auto fn : parts) {
+        const int rc = fn(op, side, &a);
+        if (rc != PSFMC_NOT_MINE) return rc;
+    }
+    return fail(PSFMC_EINVAL, "fused backend: side %d is not one of " PSFMC_FUSED_SIDES, side);
+#endif
+}
+
+static int row_shape_for(int nx, RowShape* out) {
+    SizeCall a;
+    a.shape = out;
+    return size_call(SZ_ROW_SHAPE, nx, a);
+}
+
+static int flush_linear_sums(psfmc_ctx* c);   // posterior-image sums: see psfmc_reset_accumulated
+
+// ---------------------------------------------------------------------------
+// hipFFT plans, cached per batch size (a half-ensemble call and a full-ensemble
+// call use different sizes)
+// ---------------------------------------------------------------------------
+static int use_plans(psfmc_ctx* c, int batch) {
+    auto it = c->plans.find(batch);
+    if (it == c->plans.end()) {
+        if (c->plans.size() >= 8) {
+            for (auto& kv : c->plans) {
+                hipfftDestroy(kv.second.first);
+                hipfftDestroy(kv.second.second);
+            }
+            c->plans.clear();
+        }
+        int n[2] = {c->ny, c->nx};
+        hipfftHandle f = 0, b = 0;
+        FFT_TRY(hipfftPlanMany(&f, 2, n, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_D2Z, batch));
+        FFT_TRY(hipfftPlanMany(&b, 2, n, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_Z2D, batch));
+        it = c->plans.emplace(batch, std::make_pair(f, b)).first;
+    }
+    c->plan_fwd = it->second.first;
+    c->plan_inv = it->second.second;
+    return PSFMC_OK;
+}
+
+static void free_work(psfmc_ctx* c) {
+    void** bufs[] = {(void**)&c->d_real, (void**)&c->d_spec, (void**)&c->d_Ts[0], (void**)&c->d_Ts[1],
+                     (void**)&c->d_Ts[2], (void**)&c->d_Ts[3]};
+    for (void** p : bufs)
+        if (*p) {
+            (void)hipFree(*p);
+            *p = nullptr;
+        }
+    c->d_T = nullptr;
+}
+
+static int alloc_work(psfmc_ctx* c) {
+    free_work(c);
+    if (c->backend == PSFMC_BACKEND_HIPFFT) {
+        const size_t nimg = (size_t)2 * c->chunk;
+        HIP_TRY(hipMalloc(&c->d_real, nimg * c->S * sizeof(double)));
+        HIP_TRY(hipMalloc(&c->d_spec, nimg * c->F * sizeof(double2)));
+        return use_plans(c, (int)nimg);
+    }
+    // buffer 0 also serves batches of up to two chunks that run as ONE pass (run_pipeline)
+    c->single_cap = 2 * c->chunk < c->max_walkers ? 2 * c->chunk : c->max_walkers;
+    if (c->single_cap < c->chunk) c->single_cap = c->chunk;
+    for (int i = 0; i < c->n_streams; ++i)
+        HIP_TRY(hipMalloc(&c->d_Ts[i], (size_t)(i ? c->chunk : c->single_cap) * 2 * c->nxh * c->nyp *
+                                           (c->t_f32 ? sizeof(cf) : sizeof(cd))));
+    c->d_T = c->d_Ts[0];
+    return PSFMC_OK;
+}
+
+// Walkers per internal pass of the fused path: the transposed half-spectra of one pass
+// (two passes in flight, together just under the 256 MiB Infinity Cache: measured
+// best at 256^2 -- 104..120 walkers; 136 and more fall off -- see DESIGN.md).
+// Never rounded UP past that budget: 32 walkers at 512^2 (2 x 135 MB) ran 6 % slower than
+// 24, 16 at 1024^2 8 % slower than 6 (gpurun_out r2i sweep).
+static int fused_pass_walkers(const psfmc_ctx* c) {
+    const double per_walker = 2.0 * c->nxh * c->nyp * (c->t_f32 ? 8.0 : 16.0);
+    const int fit = (int)(112.0 * 1048576.0 / per_walker);
+    int chunk = fit >= 64 ? ((fit + 4) & ~7) : fit >= 16 ? (fit & ~7) : (fit & ~1);
+    return chunk < 4 ? 4 : chunk;
+}
+
+static bool fused_side(int n) {
+    static const int sides[] = {64,84,96,98,100,112,120,126,128,140,144,150,160,168,180,192,196,200,210,224,240,250,252,256,280,288,294,300,320,336,350,360,384,392,400,420,448,480,500,504,512,560,576,600,630,640,672,700,720,768,784,800,840,896,900,960,1024};
+    for (int v : sides)
+        if (v == n) return true;
+    return false;
+}
+
+
 // per-kernel timing: bracket a launch with events on its own stream
 enum { PROF_ROWS_FWD = 0, PROF_COLS = 1, PROF_ROWS_INV = 2 };
 struct ProfScope {
@@ -478,24 +680,17 @@ static void prof_collect(psfmc_ctx* c) {
 static int fused_rows_fwd(psfmc_ctx* c, int n, cd* Tbuf, const double* prep, const uint8_t* skip,
                           int ps_only, double* raw_out, hipStream_t st) {
     ProfScope ps(c, PROF_ROWS_FWD, st);
-    if (c->t_f32) {
-        DISPATCH_LEN(c->nx, RC_TRY((launch_rows_fwd<N_, false, cf>(c, n, prep, skip, Tbuf, ps_only, nullptr,
-                                                                   nullptr, raw_out, st))));
-    } else {
-        DISPATCH_LEN(c->nx, RC_TRY((launch_rows_fwd<N_, false>(c, n, prep, skip, Tbuf, ps_only, nullptr,
-                                                               nullptr, raw_out, st))));
-    }
-    return PSFMC_OK;
+    SizeCall a;
+    a.c = c; a.n = n; a.prep = prep; a.skip = skip; a.T = Tbuf; a.ps_only = ps_only; a.raw_out = raw_out; a.st = st;
+    a.f32 = c->t_f32;
+    return size_call(SZ_ROWS_FWD, c->nx, a);
 }
 
 static int fused_cols(psfmc_ctx* c, int n, cd* Tbuf, const double* prep, const uint8_t* skip, hipStream_t st) {
     ProfScope ps(c, PROF_COLS, st);
-    if (c->t_f32) {
-        DISPATCH_LEN(c->ny, RC_TRY((launch_cols<N_, true, cf>(c, Tbuf, n, prep, skip, st))));
-    } else {
-        DISPATCH_LEN(c->ny, RC_TRY((launch_cols<N_, true>(c, Tbuf, n, prep, skip, st))));
-    }
-    return PSFMC_OK;
+    SizeCall a;
+    a.c = c; a.n = n; a.prep = prep; a.skip = skip; a.T = Tbuf; a.st = st; a.f32 = c->t_f32;
+    return size_call(SZ_COLS, c->ny, a);
 }
 
 static int fused_forward(psfmc_ctx* c, int n, cd* Tbuf, const double* prep, const uint8_t* skip,
@@ -507,12 +702,10 @@ static int fused_forward(psfmc_ctx* c, int n, cd* Tbuf, const double* prep, cons
 static int fused_inverse(psfmc_ctx* c, int n, const cd* Tbuf, const double* prep, const uint8_t* skip,
                          double* partial, double* conv_out, double* var_out, hipStream_t st) {
     ProfScope ps(c, PROF_ROWS_INV, st);
-    if (c->t_f32) {
-        DISPATCH_LEN(c->nx, RC_TRY((launch_rows_inv<N_, cf>(c, n, Tbuf, prep, skip, partial, conv_out, var_out, st))));
-    } else {
-        DISPATCH_LEN(c->nx, RC_TRY((launch_rows_inv<N_>(c, n, Tbuf, prep, skip, partial, conv_out, var_out, st))));
-    }
-    return PSFMC_OK;
+    SizeCall a;
+    a.c = c; a.n = n; a.prep = prep; a.skip = skip; a.T = const_cast<cd*>(Tbuf); a.partial = partial;
+    a.conv_out = conv_out; a.var_out = var_out; a.st = st; a.f32 = c->t_f32;
+    return size_call(SZ_ROWS_INV, c->nx, a);
 }
 
 static std::vector<cd> twiddle_table(int n) {
@@ -554,10 +747,14 @@ static int spectra_fused(psfmc_ctx* c, const double* d_canvas) {
     HIP_TRY(hipMalloc(&c->d_Kraw, (size_t)c->n_psf * 2 * c->nxh * c->nyp * sizeof(cd)));
     HIP_TRY(hipMemsetAsync(c->d_Kraw, 0, (size_t)c->n_psf * 2 * c->nxh * c->nyp * sizeof(cd), c->stream));
     HIP_TRY(hipMalloc(&c->d_Kt, n_el * sizeof(cd)));
-    DISPATCH_LEN(c->nx, RC_TRY((launch_rows_fwd<N_, true>(c, c->n_psf, nullptr, nullptr, c->d_Kraw, 0,
-                                                          d_canvas, c->d_rho, nullptr, c->stream))));
-    DISPATCH_LEN(c->ny, RC_TRY((launch_cols<N_, false>(c, c->d_Kraw, c->n_psf, nullptr,
-                                                       nullptr, c->stream))));
+    {
+        SizeCall a;
+        a.c = c; a.n = c->n_psf; a.T = c->d_Kraw; a.img = d_canvas; a.img_scale = c->d_rho; a.st = c->stream;
+        a.from_image = true;
+        RC_TRY(size_call(SZ_ROWS_FWD, c->nx, a));
+        a.convolve = false;
+        RC_TRY(size_call(SZ_COLS, c->ny, a));
+    }
     hipLaunchKernelGGL(k_scale_kernel_spectrum, dim3(256), dim3(256), 0, c->stream, c->d_Kraw, c->d_Kt,
                        (int)n_el, c->ny, c->nxh, c->rg_log2, 0.25 / (double)c->S);
     HIP_TRY(hipGetLastError());
@@ -616,10 +813,18 @@ static int ctx_init(psfmc_ctx* c, const double* sci, const double* obs_var, cons
         HIP_TRY(hipMalloc(&c->d_rho, c->n_psf * sizeof(double)));
         HIP_TRY(hipMemcpy(c->d_rho, rho.data(), c->n_psf * sizeof(double), hipMemcpyHostToDevice));
         size_t field_len = 0;
-        DISPATCH_LEN(c->nx, field_len = fused_field_len<N_>(c->ny));
+        {
+            SizeCall a;
+            a.len = &field_len; a.ny = c->ny;
+            RC_TRY(size_call(SZ_FIELD_LEN, c->nx, a));
+        }
         c->field_len = field_len;
         HIP_TRY(hipMalloc(&c->d_field, (size_t)c->n_fields * field_len * sizeof(FieldPx)));
-        for (int f = 0; f < c->n_fields; ++f) DISPATCH_LEN(c->nx, RC_TRY(pack_field<N_>(c, f)));
+        for (int f = 0; f < c->n_fields; ++f) {
+            SizeCall a;
+            a.c = c; a.field = f;
+            RC_TRY(size_call(SZ_PACK_FIELD, c->nx, a));
+        }
     }
 
     // centre-padded canvases, interleaved (psf0, var0, psf1, var1, ...)
@@ -1383,21 +1588,17 @@ static int ensure_linear_sums(psfmc_ctx* c) {
     return PSFMC_OK;
 }
 
-template <int NX>
-static int launch_raster_sums(psfmc_ctx* c, int n, const double* prep, int groups, int group_size, hipStream_t st) {
-    constexpr int RG = FftShape<NX>::TPW;
-    hipLaunchKernelGGL((k_raster_sums<NX>), dim3((c->ny + RG - 1) / RG, groups), dim3(64), 0, st, prep, c->plen, n,
-                       group_size, c->n_ps, c->n_sersic, c->ny, c->n_psf, c->d_linpart);
-    return PSFMC_OK;
-}
-
 // fused back end: add the W walkers whose prep records are in c->d_prep to the linear sums
 static int accumulate_linear(psfmc_ctx* c, int W, hipStream_t st) {
     const size_t n_el = (size_t)c->n_psf * 3 * c->S;
     int groups = c->lin_groups < W ? c->lin_groups : W;
     const int group_size = (W + groups - 1) / groups;
     groups = (W + group_size - 1) / group_size;
-    DISPATCH_LEN(c->nx, RC_TRY((launch_raster_sums<N_>(c, W, c->d_prep, groups, group_size, st))));
+    {
+        SizeCall a;
+        a.c = c; a.n = W; a.prep = c->d_prep; a.groups = groups; a.group_size = group_size; a.st = st;
+        RC_TRY(size_call(SZ_RASTER_SUMS, c->nx, a));
+    }
     hipLaunchKernelGGL(k_sum_partials, dim3(512), dim3(256), 0, st, c->d_linpart, groups, c->d_lin, n_el);
     c->lin_pending += W;
     c->acc_count += W;
@@ -1442,11 +1643,13 @@ static int flush_linear_sums(psfmc_ctx* c) {
         HIP_TRY(hipMemcpyAsync(d_scale, &scale, sizeof(double), hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(d_fprep, fprep.data(), fprep.size() * sizeof(double), hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));                 // (fprep / scale are stack data)
-        DISPATCH_LEN(c->nx, RC_TRY((launch_rows_fwd<N_, true>(c, 1, nullptr, nullptr, c->d_T, 0, d_img, d_scale,
-                                                              nullptr, st))));
-        DISPATCH_LEN(c->ny, RC_TRY((launch_cols<N_, true>(c, c->d_T, 1, d_fprep, nullptr, st))));
-        DISPATCH_LEN(c->nx, RC_TRY((launch_rows_inv<N_>(c, 1, c->d_T, d_fprep, nullptr, c->d_partial, d_out,
-                                                        d_out + S, st))));
+        SizeCall a;
+        a.c = c; a.n = 1; a.T = c->d_T; a.img = d_img; a.img_scale = d_scale; a.st = st; a.from_image = true;
+        RC_TRY(size_call(SZ_ROWS_FWD, c->nx, a));
+        a.from_image = false; a.prep = d_fprep;
+        RC_TRY(size_call(SZ_COLS, c->ny, a));
+        a.partial = c->d_partial; a.conv_out = d_out; a.var_out = d_out + S;
+        RC_TRY(size_call(SZ_ROWS_INV, c->nx, a));
         return PSFMC_OK;
     };
     for (int p = 0; p < c->n_psf && rc == PSFMC_OK; ++p) {
@@ -2112,3 +2315,5 @@ extern "C" int psfmc_debug_math(int device, int op, int n, const double* in, dou
     if (d_out) (void)hipFree(d_out);
     return rc;
 }
+
+#endif  // PSFMC_PART == 0

@@ -7,6 +7,9 @@
 // kappa Sersic.py:47-53 (scipy.special.gammaincinv(2n, 1/2)); Sigma_e Sersic.py:55-71;
 // flux utils.py:160-164; ellipse matrix Sersic.py:80-91.
 #pragma once
+#ifndef PSFMC_PART
+#define PSFMC_PART 0      /* single translation unit (see psfmc_hip.hip) */
+#endif
 #include "psfmc_device.h"
 
 namespace psfmc {
@@ -262,6 +265,7 @@ __host__ inline size_t theta_prep_lds_bytes(int n_sky, int n_ps, int n_sersic, i
                sizeof(double);
 }
 
+#if PSFMC_PART == 0          /* not a template: defined in the API part only */
 __global__ void __launch_bounds__(kThetaThreads * kThetaMaxTasks)
 k_theta_prep(ThetaLayout G, const double* __restrict__ theta,
              const double* __restrict__ extra, double* __restrict__ rows,
@@ -401,6 +405,7 @@ k_theta_prep(ThetaLayout G, const double* __restrict__ theta,
         for (int i = 0; i < rlen; ++i) out[i] = row[i];
     }
 }
+#endif
 
 // lnprob = loglike + lnprior, non-finite likelihood -> -inf (models.py:238-243); all
 // lanes of the walker's wave get the value
@@ -413,6 +418,7 @@ __device__ inline double walker_lnprob(const double* __restrict__ partial, const
 }
 
 // one wave per walker (launch: finish_blocks(W) x kFinishThreads)
+#if PSFMC_PART == 0          /* not a template: defined in the API part only */
 __global__ void k_finish_posterior(const double* __restrict__ partial, const uint8_t* __restrict__ skip,
                                    const double* __restrict__ lnprior, double* __restrict__ lnprob,
                                    int W, int nblk) {
@@ -422,6 +428,7 @@ __global__ void k_finish_posterior(const double* __restrict__ partial, const uin
     const double lp = walker_lnprob(partial, skip, lnprior, nblk, w, lane);
     if (lane == 0) lnprob[w] = lp;
 }
+#endif
 
 // ---------------------------------------------------------------------------
 // stretch move, second half of a half-step: the proposals' log-posteriors
@@ -434,6 +441,7 @@ __global__ void k_finish_posterior(const double* __restrict__ partial, const uin
 // ranks and gathered; they are read from it instead of being summed here -- the values are the
 // ones k_finish_posterior produced from the same partial sums, so the chain is the same bit for bit.
 // ---------------------------------------------------------------------------
+#if PSFMC_PART == 0          /* not a template: defined in the API part only */
 __global__ void k_stretch_finish(const double* __restrict__ partial, const uint8_t* __restrict__ skip,
                                  const double* __restrict__ lnprior, int nblk,
                                  const double* __restrict__ newlnp_in,
@@ -473,7 +481,10 @@ __global__ void k_stretch_finish(const double* __restrict__ partial, const uint8
         if (chain) lnchain[(size_t)g * n_iter + it] = lp;
     }
 }
+#endif
 
+#if PSFMC_PART == 0          /* not a template: defined in the API part only */
 __global__ void k_stretch_next(int* __restrict__ d_iter) { *d_iter += 1; }
+#endif
 
 }  // namespace psfmc
