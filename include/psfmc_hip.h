@@ -47,7 +47,9 @@ typedef struct psfmc_ctx psfmc_ctx;
                                     Sides: the powers of two 64..1024 and the even 5-smooth sides 96 100 120
                                     144 150 160 180 192 200 240 250 288 300 320 360 384 400 480 500 576 600
                                     640 720 768 800 900 960 and, with a factor 7, 84 98 112 126 140 168 196
-                                    210 224 252 280 294 336 350 392 420 448 504 560 630 672 700 784 840 896
+                                    210 224 252 280 294 336 350 392 420 448 504 560 630 672 700 784 840 896,
+                                    with a factor 11 or 13: 88 104 110 130 132 156 176 208 220 260 264 286 308 312
+                                    330 352 364 390 416 440 484 520 528 572 616 624 650 660 676 704 728 780 832
                                     (nx and ny independently, any combination);
                                     psfmc_ctx_create returns PSFMC_EINVAL for any other shape */
 #define PSFMC_BACKEND_HIPFFT  1  /* batched hipFFT D2Z/Z2D between separate kernels: any even shape

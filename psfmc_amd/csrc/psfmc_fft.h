@@ -151,6 +151,40 @@ PSFMC_FFT_SHAPE(700, 25, 28)
 PSFMC_FFT_SHAPE(784, 28, 28)
 PSFMC_FFT_SHAPE(840, 28, 30)
 PSFMC_FFT_SHAPE(896, 28, 32)
+// sides with a factor 11 or 13 (round 2): the same rules
+PSFMC_FFT_SHAPE(88, 11, 8)
+PSFMC_FFT_SHAPE(104, 13, 8)
+PSFMC_FFT_SHAPE(110, 10, 11)
+PSFMC_FFT_SHAPE(130, 10, 13)
+PSFMC_FFT_SHAPE(132, 11, 12)
+PSFMC_FFT_SHAPE(156, 12, 13)
+PSFMC_FFT_SHAPE(176, 11, 16)
+PSFMC_FFT_SHAPE(208, 13, 16)
+PSFMC_FFT_SHAPE(220, 11, 20)
+PSFMC_FFT_SHAPE(260, 13, 20)
+PSFMC_FFT_SHAPE(264, 12, 22)
+PSFMC_FFT_SHAPE(286, 13, 22)
+PSFMC_FFT_SHAPE(308, 11, 28)
+PSFMC_FFT_SHAPE(312, 13, 24)
+PSFMC_FFT_SHAPE(330, 15, 22)
+PSFMC_FFT_SHAPE(352, 16, 22)
+PSFMC_FFT_SHAPE(364, 13, 28)
+PSFMC_FFT_SHAPE(390, 15, 26)
+PSFMC_FFT_SHAPE(416, 16, 26)
+PSFMC_FFT_SHAPE(440, 20, 22)
+PSFMC_FFT_SHAPE(484, 22, 22)
+PSFMC_FFT_SHAPE(520, 20, 26)
+PSFMC_FFT_SHAPE(528, 22, 24)
+PSFMC_FFT_SHAPE(572, 22, 26)
+PSFMC_FFT_SHAPE(616, 22, 28)
+PSFMC_FFT_SHAPE(624, 24, 26)
+PSFMC_FFT_SHAPE(650, 25, 26)
+PSFMC_FFT_SHAPE(660, 22, 30)
+PSFMC_FFT_SHAPE(676, 26, 26)
+PSFMC_FFT_SHAPE(704, 22, 32)
+PSFMC_FFT_SHAPE(728, 26, 28)
+PSFMC_FFT_SHAPE(780, 26, 30)
+PSFMC_FFT_SHAPE(832, 26, 32)
 #undef PSFMC_FFT_SHAPE
 
 // the output index lane t holds in register e, and whether that register holds one at all
@@ -212,8 +246,8 @@ template <int R, int K, int SIGN> __device__ __forceinline__ cd tw_mul(cd v) {
     }
 }
 
-// the radix a length-R codelet splits off first: 7, then 5, then 3, then 2
-template <int R> constexpr int dft_radix() { return R % 7 == 0 ? 7 : R % 5 == 0 ? 5 : R % 3 == 0 ? 3 : 2; }
+// the radix a length-R codelet splits off first: 13, 11, 7, then 5, then 3, then 2
+template <int R> constexpr int dft_radix() { return R % 13 == 0 ? 13 : R % 11 == 0 ? 11 : R % 7 == 0 ? 7 : R % 5 == 0 ? 5 : R % 3 == 0 ? 3 : 2; }
 
 // in-register DFT of R points, natural order in and out
 template <int R, int SIGN, int RADIX = dft_radix<R>()> struct Dft;
@@ -347,7 +381,68 @@ template <int R, int SIGN> struct Dft<R, SIGN, 7> {
     }
 };
 
-// radix 2 (what is left once the 7s, 5s and 3s are split off: the power-of-two codelets)
+// radix 11 and 13: the radix-7 scheme written once for any odd prime PR, its cosines and sines taken
+// from the generated table at compile time (H = (PR - 1) / 2 pairs of sums and differences)
+template <int R, int SIGN, int PR> struct DftPrime {
+    static constexpr int M = R / PR, H = (PR - 1) / 2;
+    static __device__ __forceinline__ void run(cd (&v)[R]) {
+        cd s[PR][M];
+#pragma unroll
+        for (int j = 0; j < PR; ++j)
+#pragma unroll
+            for (int i = 0; i < M; ++i) s[j][i] = v[PR * i + j];
+#pragma unroll
+        for (int j = 0; j < PR; ++j) Dft<M, SIGN>::run(s[j]);
+        combine<0>(v, s);
+    }
+    template <int K, int J>
+    static __device__ __forceinline__ void pairs(const cd (&s)[PR][M], cd (&p)[H], cd (&d)[H]) {
+        if constexpr (J <= H) {
+            const cd a = tw_mul<R, J * K, SIGN>(s[J][K]), b = tw_mul<R, (PR - J) * K, SIGN>(s[PR - J][K]);
+            p[J - 1] = cadd(a, b);
+            d[J - 1] = csub(a, b);
+            pairs<K, J + 1>(s, p, d);
+        }
+    }
+    template <int Q, int J>
+    static __device__ __forceinline__ void mix(cd& m, cd& n, const cd (&p)[H], const cd (&d)[H]) {
+        if constexpr (J <= H) {
+            constexpr double c = tw_cos<PR, (J * Q) % PR>();
+            constexpr double q = SIGN * tw_sin<PR, (J * Q) % PR>();
+            m = cd{__builtin_fma(c, p[J - 1].x, m.x), __builtin_fma(c, p[J - 1].y, m.y)};
+            n = cd{__builtin_fma(q, d[J - 1].x, n.x), __builtin_fma(q, d[J - 1].y, n.y)};
+            mix<Q, J + 1>(m, n, p, d);
+        }
+    }
+    template <int K, int Q>
+    static __device__ __forceinline__ void outputs(cd (&v)[R], cd a0, const cd (&p)[H], const cd (&d)[H]) {
+        if constexpr (Q <= H) {
+            cd m = a0, n = cd{0.0, 0.0};
+            mix<Q, 1>(m, n, p, d);
+            v[K + Q * M] = cd{m.x - n.y, m.y + n.x};               // m + i n
+            v[K + (PR - Q) * M] = cd{m.x + n.y, m.y - n.x};
+            outputs<K, Q + 1>(v, a0, p, d);
+        }
+    }
+    template <int K>
+    static __device__ __forceinline__ void combine(cd (&v)[R], const cd (&s)[PR][M]) {
+        if constexpr (K < M) {
+            cd p[H], d[H];
+            pairs<K, 1>(s, p, d);
+            const cd a0 = s[0][K];
+            cd sum = a0;
+#pragma unroll
+            for (int j = 0; j < H; ++j) sum = cadd(sum, p[j]);
+            v[K] = sum;
+            outputs<K, 1>(v, a0, p, d);
+            combine<K + 1>(v, s);
+        }
+    }
+};
+template <int R, int SIGN> struct Dft<R, SIGN, 11> : DftPrime<R, SIGN, 11> {};
+template <int R, int SIGN> struct Dft<R, SIGN, 13> : DftPrime<R, SIGN, 13> {};
+
+// radix 2 (what is left once the 13s, 11s, 7s, 5s and 3s are split off: the power-of-two codelets)
 template <int R, int SIGN> struct Dft<R, SIGN, 2> {
     static __device__ __forceinline__ void run(cd (&v)[R]) {
         cd ev[R / 2], od[R / 2];

@@ -76,8 +76,8 @@ int psfmc_fail_(int code, const char* fmt, ...) {
     } while (0)
 
 // sides the fused kernels are instantiated for (FftShape in psfmc_fft.h): every power of two
-// 64..1024 and the even 5- and 7-smooth sides listed there
-#define PSFMC_FUSED_SIDES "64 84 96 98 100 112 120 126 128 140 144 150 160 168 180 192 196 200 210 224 240 250 252 256 280 288 294 300 320 336 350 360 384 392 400 420 448 480 500 504 512 560 576 600 630 640 672 700 720 768 784 800 840 896 900 960 1024"
+// 64..1024 and the even sides with factors 3, 5, 7, 11, 13 listed there
+#define PSFMC_FUSED_SIDES "64 84 88 96 98 100 104 110 112 120 126 128 130 132 140 144 150 156 160 168 176 180 192 196 200 208 210 220 224 240 250 252 256 260 264 280 286 288 294 300 308 312 320 330 336 350 352 360 364 384 390 392 400 416 420 440 448 480 484 500 504 512 520 528 560 572 576 600 616 624 630 640 650 660 672 676 700 704 720 728 768 780 784 800 832 840 896 900 960 1024"
 // run BODY with `N_` a compile-time copy of the length n; in a split build only for this part's sides
 // (side i of the list belongs to part i mod PSFMC_NPARTS)
 #if PSFMC_NPARTS == 1
@@ -85,56 +85,89 @@ int psfmc_fail_(int code, const char* fmt, ...) {
     switch (n) { \
         case 64: { constexpr int N_ = 64; BODY; } break; \
         case 84: { constexpr int N_ = 84; BODY; } break; \
+        case 88: { constexpr int N_ = 88; BODY; } break; \
         case 96: { constexpr int N_ = 96; BODY; } break; \
         case 98: { constexpr int N_ = 98; BODY; } break; \
         case 100: { constexpr int N_ = 100; BODY; } break; \
+        case 104: { constexpr int N_ = 104; BODY; } break; \
+        case 110: { constexpr int N_ = 110; BODY; } break; \
         case 112: { constexpr int N_ = 112; BODY; } break; \
         case 120: { constexpr int N_ = 120; BODY; } break; \
         case 126: { constexpr int N_ = 126; BODY; } break; \
         case 128: { constexpr int N_ = 128; BODY; } break; \
+        case 130: { constexpr int N_ = 130; BODY; } break; \
+        case 132: { constexpr int N_ = 132; BODY; } break; \
         case 140: { constexpr int N_ = 140; BODY; } break; \
         case 144: { constexpr int N_ = 144; BODY; } break; \
         case 150: { constexpr int N_ = 150; BODY; } break; \
+        case 156: { constexpr int N_ = 156; BODY; } break; \
         case 160: { constexpr int N_ = 160; BODY; } break; \
         case 168: { constexpr int N_ = 168; BODY; } break; \
+        case 176: { constexpr int N_ = 176; BODY; } break; \
         case 180: { constexpr int N_ = 180; BODY; } break; \
         case 192: { constexpr int N_ = 192; BODY; } break; \
         case 196: { constexpr int N_ = 196; BODY; } break; \
         case 200: { constexpr int N_ = 200; BODY; } break; \
+        case 208: { constexpr int N_ = 208; BODY; } break; \
         case 210: { constexpr int N_ = 210; BODY; } break; \
+        case 220: { constexpr int N_ = 220; BODY; } break; \
         case 224: { constexpr int N_ = 224; BODY; } break; \
         case 240: { constexpr int N_ = 240; BODY; } break; \
         case 250: { constexpr int N_ = 250; BODY; } break; \
         case 252: { constexpr int N_ = 252; BODY; } break; \
         case 256: { constexpr int N_ = 256; BODY; } break; \
+        case 260: { constexpr int N_ = 260; BODY; } break; \
+        case 264: { constexpr int N_ = 264; BODY; } break; \
         case 280: { constexpr int N_ = 280; BODY; } break; \
+        case 286: { constexpr int N_ = 286; BODY; } break; \
         case 288: { constexpr int N_ = 288; BODY; } break; \
         case 294: { constexpr int N_ = 294; BODY; } break; \
         case 300: { constexpr int N_ = 300; BODY; } break; \
+        case 308: { constexpr int N_ = 308; BODY; } break; \
+        case 312: { constexpr int N_ = 312; BODY; } break; \
         case 320: { constexpr int N_ = 320; BODY; } break; \
+        case 330: { constexpr int N_ = 330; BODY; } break; \
         case 336: { constexpr int N_ = 336; BODY; } break; \
         case 350: { constexpr int N_ = 350; BODY; } break; \
+        case 352: { constexpr int N_ = 352; BODY; } break; \
         case 360: { constexpr int N_ = 360; BODY; } break; \
+        case 364: { constexpr int N_ = 364; BODY; } break; \
         case 384: { constexpr int N_ = 384; BODY; } break; \
+        case 390: { constexpr int N_ = 390; BODY; } break; \
         case 392: { constexpr int N_ = 392; BODY; } break; \
         case 400: { constexpr int N_ = 400; BODY; } break; \
+        case 416: { constexpr int N_ = 416; BODY; } break; \
         case 420: { constexpr int N_ = 420; BODY; } break; \
+        case 440: { constexpr int N_ = 440; BODY; } break; \
         case 448: { constexpr int N_ = 448; BODY; } break; \
         case 480: { constexpr int N_ = 480; BODY; } break; \
+        case 484: { constexpr int N_ = 484; BODY; } break; \
         case 500: { constexpr int N_ = 500; BODY; } break; \
         case 504: { constexpr int N_ = 504; BODY; } break; \
         case 512: { constexpr int N_ = 512; BODY; } break; \
+        case 520: { constexpr int N_ = 520; BODY; } break; \
+        case 528: { constexpr int N_ = 528; BODY; } break; \
         case 560: { constexpr int N_ = 560; BODY; } break; \
+        case 572: { constexpr int N_ = 572; BODY; } break; \
         case 576: { constexpr int N_ = 576; BODY; } break; \
         case 600: { constexpr int N_ = 600; BODY; } break; \
+        case 616: { constexpr int N_ = 616; BODY; } break; \
+        case 624: { constexpr int N_ = 624; BODY; } break; \
         case 630: { constexpr int N_ = 630; BODY; } break; \
         case 640: { constexpr int N_ = 640; BODY; } break; \
+        case 650: { constexpr int N_ = 650; BODY; } break; \
+        case 660: { constexpr int N_ = 660; BODY; } break; \
         case 672: { constexpr int N_ = 672; BODY; } break; \
+        case 676: { constexpr int N_ = 676; BODY; } break; \
         case 700: { constexpr int N_ = 700; BODY; } break; \
+        case 704: { constexpr int N_ = 704; BODY; } break; \
         case 720: { constexpr int N_ = 720; BODY; } break; \
+        case 728: { constexpr int N_ = 728; BODY; } break; \
         case 768: { constexpr int N_ = 768; BODY; } break; \
+        case 780: { constexpr int N_ = 780; BODY; } break; \
         case 784: { constexpr int N_ = 784; BODY; } break; \
         case 800: { constexpr int N_ = 800; BODY; } break; \
+        case 832: { constexpr int N_ = 832; BODY; } break; \
         case 840: { constexpr int N_ = 840; BODY; } break; \
         case 896: { constexpr int N_ = 896; BODY; } break; \
         case 900: { constexpr int N_ = 900; BODY; } break; \
@@ -146,77 +179,110 @@ int psfmc_fail_(int code, const char* fmt, ...) {
 #define DISPATCH_LEN(n, BODY) \
     switch (n) { \
         case 64: { constexpr int N_ = 64; BODY; } break; \
-        case 100: { constexpr int N_ = 100; BODY; } break; \
-        case 128: { constexpr int N_ = 128; BODY; } break; \
-        case 160: { constexpr int N_ = 160; BODY; } break; \
-        case 196: { constexpr int N_ = 196; BODY; } break; \
-        case 240: { constexpr int N_ = 240; BODY; } break; \
-        case 280: { constexpr int N_ = 280; BODY; } break; \
-        case 320: { constexpr int N_ = 320; BODY; } break; \
-        case 384: { constexpr int N_ = 384; BODY; } break; \
+        case 98: { constexpr int N_ = 98; BODY; } break; \
+        case 112: { constexpr int N_ = 112; BODY; } break; \
+        case 130: { constexpr int N_ = 130; BODY; } break; \
+        case 150: { constexpr int N_ = 150; BODY; } break; \
+        case 176: { constexpr int N_ = 176; BODY; } break; \
+        case 200: { constexpr int N_ = 200; BODY; } break; \
+        case 224: { constexpr int N_ = 224; BODY; } break; \
+        case 256: { constexpr int N_ = 256; BODY; } break; \
+        case 286: { constexpr int N_ = 286; BODY; } break; \
+        case 308: { constexpr int N_ = 308; BODY; } break; \
+        case 336: { constexpr int N_ = 336; BODY; } break; \
+        case 364: { constexpr int N_ = 364; BODY; } break; \
+        case 400: { constexpr int N_ = 400; BODY; } break; \
         case 448: { constexpr int N_ = 448; BODY; } break; \
-        case 512: { constexpr int N_ = 512; BODY; } break; \
-        case 630: { constexpr int N_ = 630; BODY; } break; \
-        case 720: { constexpr int N_ = 720; BODY; } break; \
-        case 840: { constexpr int N_ = 840; BODY; } break; \
-        case 1024: { constexpr int N_ = 1024; BODY; } break; \
+        case 504: { constexpr int N_ = 504; BODY; } break; \
+        case 560: { constexpr int N_ = 560; BODY; } break; \
+        case 616: { constexpr int N_ = 616; BODY; } break; \
+        case 650: { constexpr int N_ = 650; BODY; } break; \
+        case 700: { constexpr int N_ = 700; BODY; } break; \
+        case 768: { constexpr int N_ = 768; BODY; } break; \
+        case 832: { constexpr int N_ = 832; BODY; } break; \
+        case 960: { constexpr int N_ = 960; BODY; } break; \
         default: return PSFMC_NOT_MINE; \
     }
 #elif PSFMC_PART == 1
 #define DISPATCH_LEN(n, BODY) \
     switch (n) { \
         case 84: { constexpr int N_ = 84; BODY; } break; \
-        case 112: { constexpr int N_ = 112; BODY; } break; \
-        case 140: { constexpr int N_ = 140; BODY; } break; \
-        case 168: { constexpr int N_ = 168; BODY; } break; \
-        case 200: { constexpr int N_ = 200; BODY; } break; \
-        case 250: { constexpr int N_ = 250; BODY; } break; \
+        case 100: { constexpr int N_ = 100; BODY; } break; \
+        case 120: { constexpr int N_ = 120; BODY; } break; \
+        case 132: { constexpr int N_ = 132; BODY; } break; \
+        case 156: { constexpr int N_ = 156; BODY; } break; \
+        case 180: { constexpr int N_ = 180; BODY; } break; \
+        case 208: { constexpr int N_ = 208; BODY; } break; \
+        case 240: { constexpr int N_ = 240; BODY; } break; \
+        case 260: { constexpr int N_ = 260; BODY; } break; \
         case 288: { constexpr int N_ = 288; BODY; } break; \
-        case 336: { constexpr int N_ = 336; BODY; } break; \
-        case 392: { constexpr int N_ = 392; BODY; } break; \
+        case 312: { constexpr int N_ = 312; BODY; } break; \
+        case 350: { constexpr int N_ = 350; BODY; } break; \
+        case 384: { constexpr int N_ = 384; BODY; } break; \
+        case 416: { constexpr int N_ = 416; BODY; } break; \
         case 480: { constexpr int N_ = 480; BODY; } break; \
-        case 560: { constexpr int N_ = 560; BODY; } break; \
-        case 640: { constexpr int N_ = 640; BODY; } break; \
-        case 768: { constexpr int N_ = 768; BODY; } break; \
-        case 896: { constexpr int N_ = 896; BODY; } break; \
+        case 512: { constexpr int N_ = 512; BODY; } break; \
+        case 572: { constexpr int N_ = 572; BODY; } break; \
+        case 624: { constexpr int N_ = 624; BODY; } break; \
+        case 660: { constexpr int N_ = 660; BODY; } break; \
+        case 704: { constexpr int N_ = 704; BODY; } break; \
+        case 780: { constexpr int N_ = 780; BODY; } break; \
+        case 840: { constexpr int N_ = 840; BODY; } break; \
+        case 1024: { constexpr int N_ = 1024; BODY; } break; \
         default: return PSFMC_NOT_MINE; \
     }
 #elif PSFMC_PART == 2
 #define DISPATCH_LEN(n, BODY) \
     switch (n) { \
-        case 96: { constexpr int N_ = 96; BODY; } break; \
-        case 120: { constexpr int N_ = 120; BODY; } break; \
-        case 144: { constexpr int N_ = 144; BODY; } break; \
-        case 180: { constexpr int N_ = 180; BODY; } break; \
+        case 88: { constexpr int N_ = 88; BODY; } break; \
+        case 104: { constexpr int N_ = 104; BODY; } break; \
+        case 126: { constexpr int N_ = 126; BODY; } break; \
+        case 140: { constexpr int N_ = 140; BODY; } break; \
+        case 160: { constexpr int N_ = 160; BODY; } break; \
+        case 192: { constexpr int N_ = 192; BODY; } break; \
         case 210: { constexpr int N_ = 210; BODY; } break; \
-        case 252: { constexpr int N_ = 252; BODY; } break; \
+        case 250: { constexpr int N_ = 250; BODY; } break; \
+        case 264: { constexpr int N_ = 264; BODY; } break; \
         case 294: { constexpr int N_ = 294; BODY; } break; \
-        case 350: { constexpr int N_ = 350; BODY; } break; \
-        case 400: { constexpr int N_ = 400; BODY; } break; \
-        case 500: { constexpr int N_ = 500; BODY; } break; \
+        case 320: { constexpr int N_ = 320; BODY; } break; \
+        case 352: { constexpr int N_ = 352; BODY; } break; \
+        case 390: { constexpr int N_ = 390; BODY; } break; \
+        case 420: { constexpr int N_ = 420; BODY; } break; \
+        case 484: { constexpr int N_ = 484; BODY; } break; \
+        case 520: { constexpr int N_ = 520; BODY; } break; \
         case 576: { constexpr int N_ = 576; BODY; } break; \
+        case 630: { constexpr int N_ = 630; BODY; } break; \
         case 672: { constexpr int N_ = 672; BODY; } break; \
+        case 720: { constexpr int N_ = 720; BODY; } break; \
         case 784: { constexpr int N_ = 784; BODY; } break; \
-        case 900: { constexpr int N_ = 900; BODY; } break; \
+        case 896: { constexpr int N_ = 896; BODY; } break; \
         default: return PSFMC_NOT_MINE; \
     }
 #elif PSFMC_PART == 3
 #define DISPATCH_LEN(n, BODY) \
     switch (n) { \
-        case 98: { constexpr int N_ = 98; BODY; } break; \
-        case 126: { constexpr int N_ = 126; BODY; } break; \
-        case 150: { constexpr int N_ = 150; BODY; } break; \
-        case 192: { constexpr int N_ = 192; BODY; } break; \
-        case 224: { constexpr int N_ = 224; BODY; } break; \
-        case 256: { constexpr int N_ = 256; BODY; } break; \
+        case 96: { constexpr int N_ = 96; BODY; } break; \
+        case 110: { constexpr int N_ = 110; BODY; } break; \
+        case 128: { constexpr int N_ = 128; BODY; } break; \
+        case 144: { constexpr int N_ = 144; BODY; } break; \
+        case 168: { constexpr int N_ = 168; BODY; } break; \
+        case 196: { constexpr int N_ = 196; BODY; } break; \
+        case 220: { constexpr int N_ = 220; BODY; } break; \
+        case 252: { constexpr int N_ = 252; BODY; } break; \
+        case 280: { constexpr int N_ = 280; BODY; } break; \
         case 300: { constexpr int N_ = 300; BODY; } break; \
+        case 330: { constexpr int N_ = 330; BODY; } break; \
         case 360: { constexpr int N_ = 360; BODY; } break; \
-        case 420: { constexpr int N_ = 420; BODY; } break; \
-        case 504: { constexpr int N_ = 504; BODY; } break; \
+        case 392: { constexpr int N_ = 392; BODY; } break; \
+        case 440: { constexpr int N_ = 440; BODY; } break; \
+        case 500: { constexpr int N_ = 500; BODY; } break; \
+        case 528: { constexpr int N_ = 528; BODY; } break; \
         case 600: { constexpr int N_ = 600; BODY; } break; \
-        case 700: { constexpr int N_ = 700; BODY; } break; \
+        case 640: { constexpr int N_ = 640; BODY; } break; \
+        case 676: { constexpr int N_ = 676; BODY; } break; \
+        case 728: { constexpr int N_ = 728; BODY; } break; \
         case 800: { constexpr int N_ = 800; BODY; } break; \
-        case 960: { constexpr int N_ = 960; BODY; } break; \
+        case 900: { constexpr int N_ = 900; BODY; } break; \
         default: return PSFMC_NOT_MINE; \
     }
 #endif
@@ -639,7 +705,7 @@ static int fused_pass_walkers(const psfmc_ctx* c) {
 }
 
 static bool fused_side(int n) {
-    static const int sides[] = {64,84,96,98,100,112,120,126,128,140,144,150,160,168,180,192,196,200,210,224,240,250,252,256,280,288,294,300,320,336,350,360,384,392,400,420,448,480,500,504,512,560,576,600,630,640,672,700,720,768,784,800,840,896,900,960,1024};
+    static const int sides[] = {64,84,88,96,98,100,104,110,112,120,126,128,130,132,140,144,150,156,160,168,176,180,192,196,200,208,210,220,224,240,250,252,256,260,264,280,286,288,294,300,308,312,320,330,336,350,352,360,364,384,390,392,400,416,420,440,448,480,484,500,504,512,520,528,560,572,576,600,616,624,630,640,650,660,672,676,700,704,720,728,768,780,784,800,832,840,896,900,960,1024};
     for (int v : sides)
         if (v == n) return true;
     return false;

@@ -15,10 +15,12 @@ BACKENDS = {'fused': BACKEND_FUSED, 'hipfft': BACKEND_HIPFFT}
 ROW_SKY, ROW_PS, ROW_SERSIC = 1, 4, 9
 
 # sides the fused kernels are built for (psfmc_amd/csrc/psfmc_fft.h FftShape)
-FUSED_SIDES = (64, 84, 96, 98, 100, 112, 120, 126, 128, 140, 144, 150, 160, 168, 180, 192, 196, 200,
-               210, 224, 240, 250, 252, 256, 280, 288, 294, 300, 320, 336, 350, 360, 384, 392, 400,
-               420, 448, 480, 500, 504, 512, 560, 576, 600, 630, 640, 672, 700, 720, 768, 784, 800,
-               840, 896, 900, 960, 1024)
+FUSED_SIDES = (64, 84, 88, 96, 98, 100, 104, 110, 112, 120, 126, 128, 130, 132, 140, 144, 150, 156,
+               160, 168, 176, 180, 192, 196, 200, 208, 210, 220, 224, 240, 250, 252, 256, 260, 264,
+               280, 286, 288, 294, 300, 308, 312, 320, 330, 336, 350, 352, 360, 364, 384, 390, 392,
+               400, 416, 420, 440, 448, 480, 484, 500, 504, 512, 520, 528, 560, 572, 576, 600, 616,
+               624, 630, 640, 650, 660, 672, 676, 700, 704, 720, 728, 768, 780, 784, 800, 832, 840,
+               896, 900, 960, 1024)
 
 
 def nearest_fused_sides(n):

@@ -111,10 +111,10 @@ def test_many_fields_each_with_its_own_context():
 
 
 def test_auto_backend_falls_back_to_hipfft_for_unbuilt_sides():
-    """backend='auto': a side outside the built list (130 = 2 * 5 * 13) runs on the hipFFT back end,
+    """backend='auto': a side outside the built list (170 = 2 * 5 * 17) runs on the hipFFT back end,
     a built one (140) on the fused kernels; both against the oracle."""
     import psfmc_oracle as orc
-    for side, want_backend in ((130, 'hipfft'), (140, 'fused')):
+    for side, want_backend in ((170, 'hipfft'), (140, 'fused')):
         model, fld = make_model(side, 1, 'auto', max_walkers=8)
         assert model._backend == want_backend
         theta = synth_field.draw_walkers(side, 1, 4, seed=3, near_truth=fld['truth'])

@@ -135,16 +135,22 @@ def general_shapes():
     partners = [84, 256, 100, 126, 64, 150, 196, 128, 96, 252, 140, 120, 64, 350, 96, 210, 128, 84, 160, 98, 144,
                 112, 168, 64, 224]
     shapes += list(zip(sevens, partners)) + [(140, 140), (64, 448), (200, 294)]
+    # sides with a factor 11 or 13 (the generic prime-radix codelet)
+    primes = [88, 104, 110, 130, 132, 156, 176, 208, 220, 260, 264, 286, 308, 312, 330, 352, 364, 390, 416, 440, 484,
+              520, 528, 572, 616, 624, 650, 660, 676, 704, 728, 780, 832]
+    mates = [88, 64, 100, 130, 96, 128, 176, 84, 110, 64, 120, 104, 96, 156, 64, 88, 100, 130, 64, 132, 96,
+             104, 64, 110, 88, 96, 64, 84, 100, 64, 104, 96, 64]
+    shapes += list(zip(primes, mates)) + [(128, 286), (64, 676)]
     assert all(engine.fused_supports(ny, nx) for ny, nx in shapes)
-    # a side with a prime factor > 7 (or an odd factor the shapes cannot split into P, T <= 32) goes to
+    # a side with a prime factor > 13 (or factors the shapes cannot split into P, T <= 32) goes to
     # the hipFFT back end under backend='auto'
-    assert not engine.fused_supports(130, 130) and not engine.fused_supports(256, 90) and not engine.fused_supports(490, 64)
+    assert not engine.fused_supports(170, 170) and not engine.fused_supports(256, 90) and not engine.fused_supports(490, 64)
     return shapes
 
 
 @pytest.mark.parametrize('shape', general_shapes(), ids=lambda s: '%dx%d' % s)
 def test_general_sides_match_oracle(shape):
-    """Sides with factors 3, 5 and 7 (real cut-outs are rarely 2^k) on the fused kernels: likelihood
+    """Sides with factors 3, 5, 7, 11 and 13 (real cut-outs are rarely 2^k) on the fused kernels: likelihood
     and all five images against the fp64 oracle, and the two back ends against each other."""
     seed = 1000 + shape[0] * 7 + shape[1]
     case = random_case(seed, shape)

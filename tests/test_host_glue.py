@@ -210,7 +210,7 @@ def test_ds9_region_mask(tmp_path):
 def test_nearest_fused_sides():
     from psfmc_amd import engine
     assert engine.nearest_fused_sides(256) == (256, 256)
-    assert engine.nearest_fused_sides(130) == (128, 140)
+    assert engine.nearest_fused_sides(134) == (132, 140)
     assert engine.nearest_fused_sides(50) == (None, 64)
     assert engine.nearest_fused_sides(2000) == (1024, None)
-    assert engine.fused_supports(140, 256) and not engine.fused_supports(130, 256)
+    assert engine.fused_supports(140, 256) and not engine.fused_supports(134, 256)
