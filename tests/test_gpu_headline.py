@@ -177,6 +177,33 @@ def test_field_set_other_shapes(side, n_sersic):
         m.close()
 
 
+def test_field_set_from_model_files_with_two_psfs_each(tmp_path):
+    """`FieldSet` built from model FILES: the `edge` fixture (two PSFs chosen by a free psf_index, a
+    mask, bad pixels, out-of-support vectors) as field 0 AND field 1 next to each other -- a walker's
+    kernel spectrum is (field x 2 + PSF) -- against the reference's own log-posteriors and, bit for bit,
+    the one-field context."""
+    from psfmc_amd import FieldSet
+    case = helpers.load_case('edge')
+    files = []
+    for k in range(2):
+        d = tmp_path / ('f%d' % k)
+        d.mkdir()
+        files.append(helpers.write_case_files('edge', case, d))
+    alone = helpers.build_model('edge', case, tmp_path, backend='fused', max_walkers=64)
+    want = alone.log_posterior_batch(case['params'])
+    assert helpers.rel_err(want, case['lnprob']) <= REF_TOL
+    fs = FieldSet(files, max_walkers=128)
+    assert fs.context.n_psf == 2 and fs.context.n_fields == 2
+    half = len(case['params']) // 2
+    got = fs.log_posterior_batch([case['params'], case['params'][::-1]])
+    assert np.array_equal(got[0], want) and np.array_equal(got[1], want[::-1])
+    got = fs.log_posterior_batch([case['params'][:half], case['params'][half:]])
+    assert np.array_equal(np.concatenate(got), want)
+    assert helpers.rel_err(np.concatenate(got), case['lnprob']) <= REF_TOL
+    fs.close()
+    alone.close()
+
+
 def test_device_group_splits_walkers_over_devices(tmp_path):
     """psfmc_group_* (one process, several devices): with the one GPU of the test box listed
     twice the walkers are split over two contexts; results equal the single context's bit for
