@@ -53,9 +53,11 @@ for N in $CONFIGS; do
   esac
 done
 tail -c 600 $OUT/${TAG}_bench*.json
-# BASELINE config 5's per-GPU share (8 independent 256^2 fields x 256 walkers each), the
+# BASELINE config 5's per-GPU share (8 independent 256^2 fields x 256 walkers each: in one shared
+# context, and with a context per field), the
 # small-ensemble timeline and the device-resident sampler's trace
 python3 bench.py --fields 8 --walkers 256 --no-cpu --no-example > $OUT/${TAG}_bench_fields8.json 2>/dev/null || true
+python3 bench.py --fields 8 --walkers 256 --no-cpu --no-example --fields-merge 0 > $OUT/${TAG}_bench_fields8_own_contexts.json 2>/dev/null || true
 cd /tmp
 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_small -o small -- python3 $R/tools/trace_small.py > /dev/null 2>&1 || true
 python3 $R/tools/trace_small.py --analyse $R/gpurun_out/${TAG}_small/small_kernel_trace.csv > $OUT/${TAG}_small_ensemble_timeline.txt 2>&1 || true
