@@ -285,6 +285,8 @@ int psfmc_group_eval_theta(psfmc_group* group, int W, const double* theta, const
  * each, any pointer may be NULL; ivm = 1 / mean variance) and the sample count.
  */
 int psfmc_accumulate_images(psfmc_ctx* ctx, int W, const double* rows);
+/* the same for W raw parameter vectors [W][n_params] (psfmc_set_layout): records derived on the device */
+int psfmc_accumulate_theta(psfmc_ctx* ctx, int W, const double* theta);
 int psfmc_get_accumulated(psfmc_ctx* ctx, double* raw, double* conv, double* resid, double* ivm,
                           double* ps_sub, long long* count);
 int psfmc_reset_accumulated(psfmc_ctx* ctx);

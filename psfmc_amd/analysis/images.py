@@ -71,6 +71,7 @@ def save_posterior_images(model, database, output_name='out_{}', mode='weighted'
         if total != model.accumulated_samples:
             model.reset_images()
             theta = database.param_matrix(names)
+            batch = max(batch, getattr(model, '_max_walkers', batch))
             for lo in range(0, total, batch):
                 print_progress(lo, total, 'Creating posterior images')
                 model.accumulate_samples(theta[lo:lo + batch])

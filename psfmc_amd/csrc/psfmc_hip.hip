@@ -1825,6 +1825,27 @@ extern "C" int psfmc_accumulate_images(psfmc_ctx* c, int W, const double* rows) 
     return rc;
 }
 
+// raw parameter vectors (host) -> posterior-image sums: the records are derived on the device like
+// psfmc_eval_theta does (no host-side gammaincinv per sample when the images of a whole database
+// are recomputed, analysis/images.py:62-74)
+extern "C" int psfmc_accumulate_theta(psfmc_ctx* c, int W, const double* theta) {
+    if (c && c->n_fields > 1) return fail(PSFMC_EINVAL, "this entry point serves contexts of one field");
+    int rc = check_theta_call(c, W, theta, theta ? (const void*)theta : (const void*)c);
+    if (rc != PSFMC_OK || W == 0) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->d_acc) RC_TRY(psfmc_reset_accumulated(c));
+    RC_TRY(ensure_linear_sums(c));
+    hipStream_t st = c->stream;
+    if (c->layout.n_params)
+        HIP_TRY(hipMemcpyAsync(c->d_theta, theta, (size_t)W * c->layout.n_params * sizeof(double),
+                               hipMemcpyHostToDevice, st));
+    launch_theta_prep(c, W, c->d_theta, nullptr, nullptr, st, StretchIn{});
+    rc = accumulate_from_prep(c, W, st);
+    (void)hipStreamSynchronize(st);
+    if (rc == PSFMC_OK) HIP_TRY(hipGetLastError());
+    return rc;
+}
+
 // ---------------------------------------------------------------------------
 // device-resident stretch-move sampling
 // ---------------------------------------------------------------------------

@@ -125,6 +125,8 @@ def load_library():
     lib.psfmc_eval_theta_fields.argtypes = [vp, ci, ip, ip, _c_double_p, _c_double_p, _c_double_p]
     lib.psfmc_eval_theta_device_fields.restype = ci
     lib.psfmc_eval_theta_device_fields.argtypes = [vp, ci, ip, ip, vp, vp, vp, vp]
+    lib.psfmc_accumulate_theta.restype = ci
+    lib.psfmc_accumulate_theta.argtypes = [vp, ci, _c_double_p]
     lib.psfmc_debug_theta_rows.restype = ci
     lib.psfmc_debug_theta_rows.argtypes = [vp, ci, _c_double_p, _c_double_p, _c_double_p, _c_u8_p]
     lib.psfmc_stretch_run.restype = ci
@@ -462,6 +464,13 @@ class Context(object):
         rows = self._rows(rows)
         if len(rows):
             self._check(self._lib.psfmc_accumulate_images(self._ctx, len(rows), _dp(rows)))
+
+    def accumulate_theta(self, theta):
+        """Add the images of [W, P] raw parameter vectors to the device-resident sums (records derived
+        on the device)."""
+        theta = self._theta(theta)
+        if len(theta):
+            self._check(self._lib.psfmc_accumulate_theta(self._ctx, len(theta), _dp(theta)))
 
     def accumulated(self):
         """(dict kind -> mean image, sample count) of the device sums."""

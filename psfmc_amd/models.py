@@ -402,11 +402,12 @@ class MultiComponentModel(object):
         """Add the images of W parameter vectors to the posterior means ON THE
         DEVICE (no image leaves the GPU until `collect_posterior_images`)."""
         theta = self._theta(theta)
-        rows = self.derived_rows(theta)
-        for lo in range(0, len(rows), self._max_walkers):
-            self.engine.accumulate(rows[lo:lo + self._max_walkers])
-        self._device_samples += len(rows)
-        self.accumulated_samples += len(rows)
+        eng = self.engine
+        for lo in range(0, len(theta), self._max_walkers):
+            # flux, kappa, Sigma_e, ellipse matrix on the device (host scipy cost 0.2 ms per sample)
+            eng.accumulate_theta(theta[lo:lo + self._max_walkers])
+        self._device_samples += len(theta)
+        self.accumulated_samples += len(theta)
 
     def reduce_accumulated(self, ranks):
         """Walkers sharded over GPUs (`parallel.RankGroup`): add up the ranks' device-resident
