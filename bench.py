@@ -96,6 +96,48 @@ def physical_cores():
     return max(len(seen), 1), os.cpu_count() or 1
 
 
+def cgroup_cpu_quota():
+    """CPUs the cgroup's bandwidth controller lets this job use at once (cpu.max = "quota period",
+    cgroup v2; cpu.cfs_quota_us / cpu.cfs_period_us, v1), or None when unlimited / unreadable.  The
+    affinity mask alone says nothing about it: the GPU boxes of this pool show 256 logical CPUs in
+    the mask and a quota of 16."""
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            quota, period = f.read().split()[:2]
+        return None if quota == 'max' else float(quota) / float(period)
+    except (IOError, OSError, ValueError):
+        pass
+    try:
+        with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as f:
+            quota = float(f.read())
+        with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f:
+            period = float(f.read())
+        return None if quota <= 0 else quota / period
+    except (IOError, OSError, ValueError):
+        return None
+
+
+def cgroup_throttled_usec():
+    try:
+        with open('/sys/fs/cgroup/cpu.stat') as f:
+            for line in f:
+                if line.startswith('throttled_usec'):
+                    return int(line.split()[1])
+    except (IOError, OSError, ValueError):
+        pass
+    return None
+
+
+def usable_cores():
+    """Processes the all-cores CPU baseline may run without oversubscribing the job's CPU share:
+    min(physical cores in the affinity mask, cgroup CPU quota).  Returns (n, detail dict)."""
+    n_phys, n_logical = physical_cores()
+    quota = cgroup_cpu_quota()
+    n = n_phys if quota is None else max(1, min(n_phys, int(quota)))
+    return n, {'physical_cores_in_affinity_mask': n_phys, 'host_logical_cpus': n_logical,
+               'cgroup_cpu_quota': quota}
+
+
 def draw_theta(args, fld, n, seed=1):
     import synth_field
     half = n // 2
@@ -253,31 +295,83 @@ def cpu_worker(args):
     import synth_field
     fld = synth_field.make_field(args.size, args.sersic, seed=0)
     theta = draw_theta(args, fld, args.walkers)
+    t0 = time.perf_counter()
     _, vals = cpu_baseline(args, fld, theta[args.cpu_worker::7], args.cpu_seconds)
-    print('CPU_WORKER_DONE %d' % len(vals))
+    print('CPU_WORKER_DONE %d %.3f' % (len(vals), time.perf_counter() - t0))
 
 
-def cpu_baseline_multi(args, n_procs, n_logical):
+def cpu_baseline_multi(args, n_procs, detail, single_rate=None):
     """The best the reference could do had `threads=n` worked: one
-    single-threaded process per physical core, walkers split between them."""
+    single-threaded process per core this job may really use (usable_cores: affinity mask AND cgroup
+    quota), walkers split between them.  The per-process rates are on the line so that a collapse
+    (oversubscription, a throttled cgroup) is visible; `valid` is false when the aggregate does not
+    even reach the single-process rate."""
     env = dict(os.environ, OMP_NUM_THREADS='1', MKL_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1')
     cmd = [sys.executable, os.path.abspath(__file__), '--size', str(args.size), '--sersic',
            str(args.sersic), '--walkers', str(args.walkers), '--cpu-seconds', str(args.cpu_seconds)]
+    thr0 = cgroup_throttled_usec()
     t0 = time.perf_counter()
     procs = [subprocess.Popen(cmd + ['--cpu-worker', str(i)], env=env, stdout=subprocess.PIPE,
                               stderr=subprocess.DEVNULL, text=True) for i in range(n_procs)]
-    done = 0
+    rates = []
     for p in procs:
         out, _ = p.communicate(timeout=args.cpu_seconds * 4 + 120)
         for line in out.splitlines():
             if line.startswith('CPU_WORKER_DONE'):
-                done += int(line.split()[1])
+                _, n_done, secs = line.split()
+                rates.append(int(n_done) / float(secs))
     el = time.perf_counter() - t0
-    return {'value': done / args.cpu_seconds, 'unit': 'evals/s', 'cores': n_procs, 'kind': 'port',
-            'host_logical_cpus': n_logical,
-            'sample': '%d single-threaded processes (one per physical core available to this job; the '
-                      'host reports %d logical CPUs) x %.0f s of walkers of the same batch (wall %.1f s '
-                      'incl. start-up)' % (n_procs, n_logical, args.cpu_seconds, el)}
+    thr1 = cgroup_throttled_usec()
+    total = float(sum(rates))
+    res = {'value': total, 'unit': 'evals/s', 'cores': n_procs, 'kind': 'port',
+           'per_process_evals_per_s': {'min': min(rates) if rates else None,
+                                       'median': float(np.median(rates)) if rates else None,
+                                       'max': max(rates) if rates else None},
+           'cgroup_throttled_s_during_run': (thr1 - thr0) * 1e-6 if thr0 is not None and thr1 is not None else None,
+           'sample': '%d single-threaded processes (min of the physical cores in the affinity mask and the '
+                     'cgroup CPU quota) x %.0f s of walkers of the same batch, each timing its own loop '
+                     '(wall %.1f s incl. start-up)' % (n_procs, args.cpu_seconds, el)}
+    res.update(detail)
+    if single_rate:
+        res['speedup_over_one_process'] = total / single_rate
+        res['valid'] = bool(total >= single_rate and len(rates) == n_procs)
+    return res
+
+
+class Watchdog(object):
+    """Per-rank deadline around the phases of a multi-rank run that can hang (rendezvous, RCCL
+    communicator set-up, the first collective): when a phase overruns, the rank prints ONE JSON error
+    line naming itself and the phase and leaves with a non-zero code -- no retry, no re-exec; the
+    launcher (torch.distributed.run) then tears the other ranks down."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world, self._timer, self.name = rank, world, None, None
+
+    def _expired(self, name, seconds):
+        print(json.dumps({'error': 'timeout', 'rank': self.rank, 'world_size': self.world, 'phase': name,
+                          'limit_s': seconds, 'host': socket.gethostname(),
+                          'hint': 'rendezvous: MASTER_ADDR / MASTER_PORT; communicator: '
+                                  'HSA_ENABLE_IPC_MODE_LEGACY=0, one visible GPU per LOCAL_RANK'}), flush=True)
+        os._exit(3)
+
+    def phase(self, name, seconds):
+        import threading
+        self.done()
+        self.name = name
+        self._timer = threading.Timer(seconds, self._expired, (name, seconds))
+        self._timer.daemon = True
+        self._timer.start()
+
+    def done(self):
+        if self._timer is not None:
+            self._timer.cancel()
+            self._timer = None
+
+    def failed(self, exc):
+        self.done()
+        print(json.dumps({'error': type(exc).__name__, 'rank': self.rank, 'world_size': self.world,
+                          'phase': self.name, 'message': str(exc)[:400]}), flush=True)
+        os._exit(4)
 
 
 def spawn_ranks(args, argv):
@@ -408,8 +502,11 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--walkers', type=int, default=4096, help='walkers per batch (per GPU)')
     ap.add_argument('--batches', type=int, default=0,
-                    help='batches per step (0: enough for ~31 ms per step, so that the default 20 '
-                         'steps time >= 0.6 s: 10 at 256^2 x 4096 walkers)')
+                    help='batches per step (0: enough for ~250 ms per step, so that the default 20 '
+                         'steps time >= 5 s: 84 at 256^2 x 4096 walkers)')
+    ap.add_argument('--step-ms', type=float, default=250.0, help='target step duration of --batches 0')
+    ap.add_argument('--distinct-batches', type=int, default=10,
+                    help='sets of walker vectors resident in HBM; the batches of a step cycle through them')
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--sersic', type=int, default=1)
     ap.add_argument('--backend', default=os.environ.get('PSFMC_BACKEND', 'fused'))
@@ -421,6 +518,9 @@ def main():
     ap.add_argument('--dist-backend', default='nccl',
                     help="'nccl' (RCCL over xGMI; the real thing) or 'gloo' (rehearsal of the "
                          "multi-rank path on a box with fewer GPUs than ranks: ranks share devices)")
+    ap.add_argument('--init-timeout', type=float, default=180.0,
+                    help='seconds a rank waits for the rendezvous / the first collective before it prints a '
+                         'JSON error line and exits (N > 1)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-example', action='store_true', help='skip the configs[1] (example model) rate')
     ap.add_argument('--no-cpu', action='store_true')
@@ -441,16 +541,14 @@ def main():
                          'run plain `python bench.py --gpus N`)' % (args.gpus, world, args.gpus))
     if args.batches <= 0:
         # ~3.3 ms per 4096-walker batch at 256^2 on one MI355X; scale by the bytes of a walker
-        per_batch_ms = 3.1 * (args.walkers / 4096.0) * (args.size / 256.0) ** 2 * max(args.fields, 1)
-        args.batches = max(1, min(64, int(np.ceil(31.0 / per_batch_ms))))
-    # the all-cores CPU baseline runs first, in child processes, before this process
-    # touches the GPU (rank 0, N = 1 only)
-    multi = None
-    n_phys, n_logical = physical_cores()
+        per_batch_ms = 3.0 * (args.walkers / 4096.0) * (args.size / 256.0) ** 2 * max(args.fields, 1)
+        args.batches = max(1, min(512, int(np.ceil(args.step_ms / per_batch_ms))))
+    # The GPU timing comes FIRST (the driver samples GPU utilisation while the command runs); the
+    # CPU baselines follow, the all-cores one in child processes (started with fork + exec: this
+    # process itself is never replaced)
+    n_usable, cpu_detail = usable_cores()
     if args.cpu_procs < 0:
-        args.cpu_procs = n_phys
-    if not args.no_cpu and args.cpu_procs > 1 and world == 1 and args.fields == 1:
-        multi = cpu_baseline_multi(args, args.cpu_procs, n_logical)
+        args.cpu_procs = n_usable
 
     import torch
     import torch.distributed as dist
@@ -461,15 +559,32 @@ def main():
     gloo = world > 1 and args.dist_backend == 'gloo'
     if gloo:                                 # rehearsal: several ranks may share one device
         local = local % torch.cuda.device_count()
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        if gloo:
-            dist.init_process_group('gloo')
-        else:
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    if world > 1:
+        import datetime
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dog = Watchdog(rank, world)
+        try:
+            dog.phase('init_process_group(%s)' % args.dist_backend, args.init_timeout)
+            limit = datetime.timedelta(seconds=args.init_timeout)
+            if gloo:
+                dist.init_process_group('gloo', timeout=limit)
+            else:
+                dist.init_process_group('nccl', device_id=dev, timeout=limit)
+            # the first collective builds the RCCL communicator (xGMI / dmabuf IPC set-up happens here)
+            dog.phase('first collective (all_gather of one double per rank)', args.init_timeout)
+            probe = torch.full((1,), float(rank), dtype=torch.float64, device='cpu' if gloo else dev)
+            got = torch.empty(world, dtype=torch.float64, device=probe.device)
+            dist.all_gather_into_tensor(got, probe)
+            if not gloo:
+                torch.cuda.synchronize(dev)
+            if got.cpu().tolist() != [float(r) for r in range(world)]:
+                raise RuntimeError('all_gather returned %r' % (got.cpu().tolist(),))
+        except Exception as exc:           # noqa: BLE001 -- report and leave, whatever it was
+            dog.failed(exc)
+        dog.done()
 
     if args.fields > 1:
         return many_fields(args, torch, dist, world, rank, local, dev, gloo)
@@ -480,10 +595,11 @@ def main():
     for kv in args.opt:
         key, val = kv.split('=')
         eng.set_option(key, float(val))
-    # every batch of a step has its own walkers (same field); all resident in HBM
-    thetas = [theta] + [draw_theta(args, fld, args.walkers, seed=11 + 2 * b) for b in range(1, args.batches)]
-    theta_dev = torch.from_numpy(np.ascontiguousarray(np.stack(thetas))).to(dev)      # [B, W, P]
-    out = torch.empty((args.batches, args.walkers), dtype=torch.float64, device=dev)
+    # the batches of a step cycle through n_sets sets of walkers of their own (same field); all resident in HBM
+    n_sets = max(1, min(args.batches, args.distinct_batches))
+    thetas = [theta] + [draw_theta(args, fld, args.walkers, seed=11 + 2 * b) for b in range(1, n_sets)]
+    theta_dev = torch.from_numpy(np.ascontiguousarray(np.stack(thetas))).to(dev)      # [n_sets, W, P]
+    out = torch.empty((n_sets, args.walkers), dtype=torch.float64, device=dev)
     gathered = torch.empty(args.walkers * world, dtype=torch.float64, device='cpu' if gloo else dev)
     # a real (non-NULL) stream: the library launches on the stream it is handed,
     # and the HIP events below must sit on that same stream
@@ -495,7 +611,8 @@ def main():
         eng.logpost_theta_device(args.walkers, theta_dev[b].data_ptr(), 0, out[b].data_ptr(), sptr)
 
     def step():
-        for b in range(args.batches):
+        for i in range(args.batches):
+            b = i % n_sets
             one_batch(b)
             if gloo:                         # host staging only in the rehearsal back end
                 dist.all_gather_into_tensor(gathered, out[b].cpu())
@@ -530,10 +647,13 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'synthetic %dx%d field, 1 PointSource + %d Sersic, %d batches x %d walkers '
-                                   'per GPU per step, raw emcee vectors resident in HBM -> full '
-                                   'log-posterior (priors, early-out, Sersic constants, likelihood), fp64'
-                                   % (args.size, args.size, args.sersic, args.batches, args.walkers),
+                                   'per GPU per step (cycling through %d resident sets of walkers), raw emcee '
+                                   'vectors resident in HBM -> full log-posterior (priors, early-out, Sersic '
+                                   'constants, likelihood), fp64'
+                                   % (args.size, args.size, args.sersic, args.batches, args.walkers, n_sets),
                        'image': args.size, 'walkers_per_batch': args.walkers, 'batches_per_step': args.batches,
+                       'value_is': 'device-resident vectors (psfmc_eval_theta_device); the Python call '
+                                   'log_posterior_batch(theta) with HOST vectors is python_entry_point below',
                        'evals_per_gpu_per_step': evals_per_step, 'entry_point': 'psfmc_eval_theta_device',
                        'backend': args.backend, 'parallelism': 'walkers sharded x%d' % world},
             'finite_logposts': n_finite,
@@ -555,6 +675,8 @@ def main():
             # 8(d)'s figure) over its event-timed average launch duration
             k = kernels[0]
             traffic = pmc_lookup(table, k['kernel'].split('<')[0])
+            prof_wpl = next((rec.get('walkers_per_launch') for name, rec in table.items()
+                             if name.startswith(k['kernel'].split('<')[0])), None)
             line['roofline'] = {
                 'bound': 'hbm', 'achieved': k['GBps'], 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                 'frac': k['GBps'] / HBM_PEAK_GBPS,
@@ -563,6 +685,9 @@ def main():
                 'bytes_per_launch': k['bytes_per_walker'] * k['walkers_per_launch'],
                 'walkers_per_launch': k['walkers_per_launch'],
                 'timing': 'HIP events around every launch on its own stream, one pass in flight',
+                'traffic_source': 'profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of '
+                                  'this command at %s walkers per launch (this run: %.1f), 2 x FETCH_SIZE + '
+                                  'WRITE_SIZE per launch' % (prof_wpl, k['walkers_per_launch']),
                 'bytes_note': BYTES_NOTE}
             line['roofline_step'] = step_roof
             line['kernels'] = kernels
@@ -581,10 +706,18 @@ def main():
                 eng.loglike_device(args.walkers, rows.data_ptr(), 0, like.data_ptr(), sptr)
             torch.cuda.synchronize(dev)
             line['loglike_from_rows_evals_per_s'] = args.walkers * 10 / (time.perf_counter() - t0)
-            t0 = time.perf_counter()
-            for _ in range(5):
+            model.log_posterior_batch(theta)
+            n_calls, t0 = 0, time.perf_counter()
+            while n_calls < 5 or time.perf_counter() - t0 < 1.0:
                 model.log_posterior_batch(theta)
-            line['host_path_evals_per_s'] = args.walkers * 5 / (time.perf_counter() - t0)
+                n_calls += 1
+            host_rate = args.walkers * n_calls / (time.perf_counter() - t0)
+            line['host_path_evals_per_s'] = host_rate
+            line['python_entry_point'] = {
+                'evals_per_s': host_rate, 'calls': n_calls, 'walkers_per_call': args.walkers,
+                'what': 'SURVEY.md section 8(d) literally: MultiComponentModel.log_posterior_batch(theta) with '
+                        'HOST numpy vectors in and HOST log-posteriors out (host-to-device copy, launch, '
+                        'device-to-host copy and synchronisation inside every call)'}
             line['small_ensembles'] = small_ensembles(eng, args, torch, dev, theta_dev[0], out[0], stream)
             if args.backend == 'fused':
                 per_pass = eng.pass_size(args.walkers)
@@ -622,8 +755,15 @@ def main():
         if not args.no_cpu and world == 1:      # CPU baseline: rank 0 at N = 1 only
             base, vals = cpu_baseline(args, fld, theta, args.cpu_seconds)
             line['cpu_baseline'] = base
-            if multi:
-                line['cpu_baseline_all_cores'] = multi
+            if args.cpu_procs > 1:
+                line['cpu_baseline_all_cores'] = cpu_baseline_multi(args, args.cpu_procs, cpu_detail, base['value'])
+            if args.size == 256 and args.sersic == 1:
+                line['reference_cpu_survey'] = {
+                    'value': 79.0, 'unit': 'evals/s', 'cores': 1, 'kind': 'reference',
+                    'note': 'a labelled constant, not measured in this run: the unmodified reference '
+                            '(mmechtley/psfMC, numpy 1.26 + numexpr, one process) on this workload in the '
+                            'survey container, BASELINE.md section 2 / SURVEY.md section 6; the reference '
+                            'cannot travel to the GPU box'}
             ref = np.array(vals)[:len(lnpost)]
             ref = ref + model.log_priors_batch(theta[:len(ref)])
             got = lnpost[:len(ref)]

@@ -179,24 +179,22 @@ __global__ void k_pack_field(const double* __restrict__ sci, const double* __res
 //   FROM_IMAGE = true : z = img0 + i img_scale[w] img1 from memory (PSF spectra at setup)
 // raw_out (optional): [n][ny][nx] copy of the raw model (psfmc_eval_images)
 // ---------------------------------------------------------------------------
-template <int NX, bool FROM_IMAGE, typename TS = cd, bool FAST = FftShape<NX>::kPlain>
-__global__ void __launch_bounds__((row_threads<NX, FAST>()), fused_min_waves<NX>())
-k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
-           const cd* __restrict__ twx, TS* __restrict__ Tbuf, int n_ps, int n_sersic, int ny,
-           int ps_only, const double* __restrict__ img, const double* __restrict__ img_scale,
-           double* __restrict__ raw_out) {
+// One wave's share of rows_fwd: row group yg of walker w; `wave_lds` = the wave's own LDS region of
+// fused_row_wave_lds_doubles<NX>() doubles.  Shared by k_rows_fwd and the paired kernel (psfmc_pair_path.h).
+template <int NX, bool FROM_IMAGE, typename TS, bool FAST>
+__device__ __forceinline__ void rows_fwd_wave(int w, int yg, int lane, double* __restrict__ wave_lds,
+                                              const double* __restrict__ prep, const uint8_t* __restrict__ skip,
+                                              const cd* __restrict__ twx, TS* __restrict__ Tbuf, int n_ps,
+                                              int n_sersic, int ny, int ps_only, const double* __restrict__ img,
+                                              const double* __restrict__ img_scale, double* __restrict__ raw_out) {
     using S = FftShape<NX>;
     constexpr int P = S::P, T = S::T, R = S::R, RG = row_group<NX>();
     constexpr int NXH = NX / 2 + 1;
     constexpr int RGL2 = layout_rg_log2<NX, FAST>(), RGL = 1 << RGL2;       // rows per layout group
-    extern __shared__ __align__(16) double smem[];
-    const int w = blockIdx.y;
     // the skip flag is a (wave-uniform) byte behind a vector load: tested only after the loads that
     // do not depend on it have been issued, so that its latency is not a serial step of every wave
     const bool skipped = skip && skip[w];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int f = lane / T, t = lane % T;
-    const int yg = blockIdx.x * row_waves<NX, FAST>() + wave;
     if constexpr (!FAST)
         if (yg * RG >= ny) return;                                    // wave-uniform: past the last row group
     const bool lane_on = S::kFull || f < RG;                          // not one of the idle tail lanes
@@ -223,7 +221,7 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
         // the rasteriser's log2 table borrows the start of the wave's transform exchange region,
         // which is idle until the transform begins
         static_assert((size_t)RG * fft_lds_elems<NX>() * sizeof(double) >= (size_t)kLogTabBytes, "exchange region too small");
-        double* log_tab = smem + (size_t)wave * fused_row_wave_lds_doubles<NX>();
+        double* log_tab = wave_lds;
         if (!ps_only) {
             load_log_table(log_tab, lane);
             wave_lds_sync();
@@ -239,7 +237,6 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
             for (int k = 0; k < P; ++k) o[T * k + t] = v[k].x;
         }
     }
-    double* wave_lds = smem + (size_t)wave * fused_row_wave_lds_doubles<NX>();
     cd* twl = reinterpret_cast<cd*>(wave_lds + (size_t)RG * fft_lds_elems<NX>());
     cd tw[fft_tw_regs<NX>()];
     load_twiddles<NX>(tw, twx, t, twl, lane);
@@ -306,6 +303,19 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
             }
         }
     }
+}
+
+template <int NX, bool FROM_IMAGE, typename TS = cd, bool FAST = FftShape<NX>::kPlain>
+__global__ void __launch_bounds__((row_threads<NX, FAST>()), fused_min_waves<NX>())
+k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
+           const cd* __restrict__ twx, TS* __restrict__ Tbuf, int n_ps, int n_sersic, int ny,
+           int ps_only, const double* __restrict__ img, const double* __restrict__ img_scale,
+           double* __restrict__ raw_out) {
+    extern __shared__ __align__(16) double smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    rows_fwd_wave<NX, FROM_IMAGE, TS, FAST>(blockIdx.y, blockIdx.x * row_waves<NX, FAST>() + wave, lane,
+                                            smem + (size_t)wave * fused_row_wave_lds_doubles<NX>(), prep, skip, twx,
+                                            Tbuf, n_ps, n_sersic, ny, ps_only, img, img_scale, raw_out);
 }
 
 // ---------------------------------------------------------------------------
@@ -521,28 +531,19 @@ template <int NY> constexpr size_t fused_col3_lds_bytes() {
 #ifndef PSFMC_COLS3_WAVES
 #define PSFMC_COLS3_WAVES 2     /* measured at 1024 (before the shared LDS twiddle table: 150 us now): 1 or 2 -> 178 us, 3 -> 273 us, 4 -> 374 us (spills) */
 #endif
-template <int NY, bool CONVOLVE, typename TS = cd>
-__global__ void __launch_bounds__(kColThreads, Fft3Shape<NY>::R1 > 8 ? PSFMC_COLS3_WAVES : 2)
-k_cols3(TS* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restrict__ prep,
-        const uint8_t* __restrict__ skip, const cd* __restrict__ twy, int plen, int nxh, int n_w,
-        int rg_log2) {
+// One wave's share of cols3: the columns `wave`, `wave` + 4, ... of the workgroup's groups (persistent;
+// the groups of a workgroup come from xcd_group_range).  `lds` = the wave's exchange region of
+// fft3_lds_doubles<NY>() doubles, `w1s` = the workgroup's shared stage-1 twiddle table (R1 = 16) or
+// nullptr.  Shared by k_cols3 and the paired kernel (psfmc_pair_path.h).
+template <int NY, bool CONVOLVE, typename TS>
+__device__ __forceinline__ void cols3_wave(int wave, int t, double* __restrict__ lds, const cd* __restrict__ w1s,
+                                           TS* __restrict__ Tbuf, const cd* __restrict__ Kt,
+                                           const double* __restrict__ prep, const uint8_t* __restrict__ skip,
+                                           const cd* __restrict__ twy, int plen, int nxh, int n_w, int rg_log2) {
     constexpr int R1 = Fft3Shape<NY>::R1;
     constexpr int WPB = kColThreads / 64;
-    extern __shared__ __align__(16) double smem[];
-#if PSFMC_COLS_PRIO
-    __builtin_amdgcn_s_setprio(PSFMC_COLS_PRIO);
-#endif
-    const int t = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double* lds = smem + (size_t)wave * fft3_lds_doubles<NY>();
     cd w1[fft3_w1_regs<NY>()], w2[8];
     load_twiddles3<NY>(w1, w2, twy, t);
-    const cd* w1s = nullptr;
-    if constexpr (R1 > 8) {
-        cd* tab = reinterpret_cast<cd*>(smem + (size_t)WPB * fft3_lds_doubles<NY>());
-        for (int i = threadIdx.x; i < R1 * 64; i += kColThreads) tab[i] = twy[(i & 63) * (i >> 6)];
-        __syncthreads();                                   // once, before any wave can leave
-        w1s = tab;
-    }
     const int rg = 1 << rg_log2;
     const int e0 = t_elem(t, 0, rg_log2);              // offset of y = t; y = 64 a + t adds 128 a
     const int n_cols = n_w * 2 * nxh;
@@ -583,6 +584,29 @@ k_cols3(TS* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restri
     }
 }
 
+template <int NY, bool CONVOLVE, typename TS = cd>
+__global__ void __launch_bounds__(kColThreads, Fft3Shape<NY>::R1 > 8 ? PSFMC_COLS3_WAVES : 2)
+k_cols3(TS* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restrict__ prep,
+        const uint8_t* __restrict__ skip, const cd* __restrict__ twy, int plen, int nxh, int n_w,
+        int rg_log2) {
+    constexpr int R1 = Fft3Shape<NY>::R1;
+    constexpr int WPB = kColThreads / 64;
+    extern __shared__ __align__(16) double smem[];
+#if PSFMC_COLS_PRIO
+    __builtin_amdgcn_s_setprio(PSFMC_COLS_PRIO);
+#endif
+    const int t = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const cd* w1s = nullptr;
+    if constexpr (R1 > 8) {
+        cd* tab = reinterpret_cast<cd*>(smem + (size_t)WPB * fft3_lds_doubles<NY>());
+        for (int i = threadIdx.x; i < R1 * 64; i += kColThreads) tab[i] = twy[(i & 63) * (i >> 6)];
+        __syncthreads();                                   // once, before any wave can leave
+        w1s = tab;
+    }
+    cols3_wave<NY, CONVOLVE, TS>(wave, t, smem + (size_t)wave * fft3_lds_doubles<NY>(), w1s, Tbuf, Kt, prep, skip, twy,
+                                 plen, nxh, n_w, rg_log2);
+}
+
 // ---------------------------------------------------------------------------
 // rows_inv.  grid (ny / RG, n_walkers); one wave per workgroup.
 // partial[w][yg] = sum over the wave's good pixels of the chi^2 term.
@@ -591,28 +615,23 @@ k_cols3(TS* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restri
 // MULTI: the context holds several observed fields (psfmc_ctx_create_fields) -- its own instantiation,
 // so that the one-field kernel keeps its registers (at nx = 1024 two more kernel arguments pushed the
 // scalar registers over their limit and the kernel to one wave per SIMD: 33.7 -> 39.6 us)
-template <int NX, typename TS = cd, bool FAST = FftShape<NX>::kPlain, bool MULTI = false>
-__global__ void __launch_bounds__((row_threads<NX, FAST>()), fused_min_waves<NX>())
-k_rows_inv(const TS* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const cd* __restrict__ twx,
-           const FieldPx* __restrict__ field, double* __restrict__ partial, int ny,
-           const double* __restrict__ prep, int plen,
-           double* __restrict__ conv_out, double* __restrict__ var_out, int n_psf_field, unsigned field_stride) {
+// One wave's share of rows_inv: row group yg (of nyg per walker) of walker w; `wave_lds` as in
+// rows_fwd_wave.  Shared by k_rows_inv and the paired kernel.
+template <int NX, typename TS, bool FAST, bool MULTI>
+__device__ __forceinline__ void rows_inv_wave(int w, int yg, int nyg, int lane, double* __restrict__ wave_lds,
+                                              const TS* __restrict__ Tbuf, const uint8_t* __restrict__ skip,
+                                              const cd* __restrict__ twx, const FieldPx* __restrict__ field,
+                                              double* __restrict__ partial, int ny, const double* __restrict__ prep,
+                                              int plen, double* __restrict__ conv_out, double* __restrict__ var_out,
+                                              int n_psf_field, unsigned field_stride) {
     using S = FftShape<NX>;
     constexpr int P = S::P, T = S::T, R = S::R, RG = row_group<NX>();
     constexpr int NXH = NX / 2 + 1;
     constexpr int RGL2 = layout_rg_log2<NX, FAST>(), RGL = 1 << RGL2;
-    extern __shared__ __align__(16) double smem[];
-#if PSFMC_INV_PRIO
-    __builtin_amdgcn_s_setprio(PSFMC_INV_PRIO);
-#endif
-
-    const int w = blockIdx.y;
     // (testing the flag only after the loads of T were issued, as k_rows_fwd and k_cols3 do, made
     // this kernel slower at 512 and 1024 -- 31.5 -> 37.7 us, 34.1 -> 41.6 us -- and left 256 unchanged)
     if (skip && skip[w]) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int f = lane / T, t = lane % T;
-    const int yg = blockIdx.x * row_waves<NX, FAST>() + wave;
     if constexpr (!FAST)
         if (yg * RG >= ny) return;                                    // wave-uniform
     const bool lane_on = S::kFull || f < RG;
@@ -620,7 +639,6 @@ k_rows_inv(const TS* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
     const int iy = yg * RG + f;
     const bool row_on = FAST || (lane_on && iy < ny);
     const int nyp = t_col_len(ny, RGL2);
-    const int nyg = FAST ? (int)gridDim.x * row_waves<NX, FAST>() : (ny + RG - 1) / RG;
     const TS* wbase = Tbuf + (size_t)w * 2 * NXH * nyp;             // wave-uniform
     constexpr unsigned kEl = sizeof(TS);                             // bytes of a T element
     const unsigned kstride = 2u * (unsigned)nyp * kEl;               // bytes between kx columns
@@ -629,7 +647,6 @@ k_rows_inv(const TS* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
     // Every (G, H) pair is loaded once, by the lane that owns k <= NX/2; that lane also
     // forms the mirrored value and hands it to the owner of NX - k through the transform's
     // LDS region.
-    double* wave_lds = smem + (size_t)wave * fused_row_wave_lds_doubles<NX>();
     cd* mbuf = reinterpret_cast<cd*>(wave_lds + (size_t)fe * fft_lds_elems<NX>());
     cd v[R];
 #pragma unroll
@@ -765,6 +782,24 @@ k_rows_inv(const TS* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
     if (lane == 0) partial[(size_t)w * nyg + yg] = acc;
+}
+
+template <int NX, typename TS = cd, bool FAST = FftShape<NX>::kPlain, bool MULTI = false>
+__global__ void __launch_bounds__((row_threads<NX, FAST>()), fused_min_waves<NX>())
+k_rows_inv(const TS* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const cd* __restrict__ twx,
+           const FieldPx* __restrict__ field, double* __restrict__ partial, int ny,
+           const double* __restrict__ prep, int plen,
+           double* __restrict__ conv_out, double* __restrict__ var_out, int n_psf_field, unsigned field_stride) {
+    extern __shared__ __align__(16) double smem[];
+#if PSFMC_INV_PRIO
+    __builtin_amdgcn_s_setprio(PSFMC_INV_PRIO);
+#endif
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int RG = row_group<NX>();
+    const int nyg = FAST ? (int)gridDim.x * row_waves<NX, FAST>() : (ny + RG - 1) / RG;
+    rows_inv_wave<NX, TS, FAST, MULTI>(blockIdx.y, blockIdx.x * row_waves<NX, FAST>() + wave, nyg, lane,
+                                       smem + (size_t)wave * fused_row_wave_lds_doubles<NX>(), Tbuf, skip, twx, field,
+                                       partial, ny, prep, plen, conv_out, var_out, n_psf_field, field_stride);
 }
 
 // ---------------------------------------------------------------------------

@@ -2268,12 +2268,15 @@ static int group_eval(psfmc_group* g, int W, const double* rows, const uint8_t* 
     if (W < 0 || (W > 0 && (!out || (!rows && !theta)))) return fail(PSFMC_EINVAL, "bad argument");
     const int n = (int)g->ctx.size();
     int rc = PSFMC_OK;
-    for (int r = 0; r < n && rc == PSFMC_OK; ++r) {          // enqueue everything ...
+    // one device's share: enqueue its copies and kernels.  An error ends the enqueueing but NEVER
+    // skips the synchronize loop below: earlier devices still have copies in flight out of `theta`
+    // / `rows` and into `out`, which the caller may free as soon as this function returns.
+    auto enqueue = [&](int r) -> int {
         int lo, hi;
         group_block(W, n, r, &lo, &hi);
         psfmc_ctx* c = g->ctx[r];
         const int w = hi - lo;
-        if (w == 0) continue;
+        if (w == 0) return PSFMC_OK;
         if (w > c->max_walkers) return fail(PSFMC_EINVAL, "W=%d exceeds the group's max_walkers", W);
         HIP_TRY(hipSetDevice(c->device));
         hipStream_t st = c->stream;
@@ -2281,19 +2284,23 @@ static int group_eval(psfmc_group* g, int W, const double* rows, const uint8_t* 
             HIP_TRY(hipMemcpyAsync(c->d_rows, rows + (size_t)lo * c->rlen, (size_t)w * c->rlen * sizeof(double),
                                    hipMemcpyHostToDevice, st));
             if (skip) HIP_TRY(hipMemcpyAsync(c->d_skip, skip + lo, (size_t)w, hipMemcpyHostToDevice, st));
-            rc = eval_device(c, w, c->d_rows, skip ? c->d_skip : nullptr, c->d_like, st);
+            RC_TRY(eval_device(c, w, c->d_rows, skip ? c->d_skip : nullptr, c->d_like, st));
         } else {
-            rc = check_theta_call(c, w, theta, out);
-            if (rc != PSFMC_OK) break;
+            RC_TRY(check_theta_call(c, w, theta, out));
             const int P = c->layout.n_params;
             if (P) HIP_TRY(hipMemcpyAsync(c->d_theta, theta + (size_t)lo * P, (size_t)w * P * sizeof(double),
                                           hipMemcpyHostToDevice, st));
             if (extra) HIP_TRY(hipMemcpyAsync(c->d_extra, extra + lo, (size_t)w * sizeof(double),
                                               hipMemcpyHostToDevice, st));
-            rc = eval_theta_device(c, w, c->d_theta, extra ? c->d_extra : nullptr, c->d_like, st);
+            RC_TRY(eval_theta_device(c, w, c->d_theta, extra ? c->d_extra : nullptr, c->d_like, st));
         }
-        if (rc == PSFMC_OK)
-            HIP_TRY(hipMemcpyAsync(out + lo, c->d_like, (size_t)w * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(out + lo, c->d_like, (size_t)w * sizeof(double), hipMemcpyDeviceToHost, st));
+        return PSFMC_OK;
+    };
+    std::string first_error;
+    for (int r = 0; r < n && rc == PSFMC_OK; ++r) {          // enqueue everything ...
+        rc = enqueue(r);
+        if (rc != PSFMC_OK) first_error = psfmc_last_error();
     }
     for (int r = 0; r < n; ++r) {                             // ... then wait for every device
         psfmc_ctx* c = g->ctx[r];
@@ -2301,6 +2308,7 @@ static int group_eval(psfmc_group* g, int W, const double* rows, const uint8_t* 
             if (rc == PSFMC_OK) rc = fail(PSFMC_EHIP, "device %d failed: %s", c->device,
                                           hipGetErrorString(hipGetLastError()));
     }
+    if (!first_error.empty()) (void)fail(rc, "%s", first_error.c_str());   // the enqueue error is the one to report
     return rc;
 }
 

@@ -19,6 +19,30 @@ from .sampler import EnsembleSampler, DeviceEnsembleSampler
 from .utils import print_progress
 
 
+def _rank_group(group, device):
+    """The `parallel.RankGroup` of this run, or None for a single process.  'auto' looks for an
+    initialised torch.distributed process group and quietly settles for one process when torch
+    (or its distributed package) is not importable: the single-GPU entry point needs neither."""
+    if group is None:
+        return None
+    auto = isinstance(group, str)
+    try:
+        from .parallel import RankGroup
+        if isinstance(group, RankGroup):
+            ranks = group
+        else:
+            if auto:
+                import torch.distributed as dist
+                if not (dist.is_available() and dist.is_initialized()):
+                    return None
+            ranks = RankGroup(None if auto else group, 'cuda:%d' % device)
+    except ImportError:
+        if auto:
+            return None
+        raise
+    return None if ranks.single else ranks
+
+
 def model_galaxy_mcmc(model_file, output_name=None, write_fits=default_filetypes, iterations=0,
                       burn=0, chains=None, max_iterations=1,
                       convergence_check=check_convergence_autocorr, sampler_class=None,
@@ -35,7 +59,6 @@ def model_galaxy_mcmc(model_file, output_name=None, write_fits=default_filetypes
     object) the walkers of every half-step are sharded over the ranks, one process per GPU
     (`device` should then be the rank's LOCAL_RANK); rank 0 draws the start positions and the
     sampler's random state and writes the outputs, every rank returns the same database."""
-    from .parallel import RankGroup, ShardedLogPosterior
     if output_name is None:
         output_name = 'out_' + model_file.replace('.py', '')
     output_name += '_{}'
@@ -45,11 +68,7 @@ def model_galaxy_mcmc(model_file, output_name=None, write_fits=default_filetypes
         n_hint = max(chains or 0, 64)
         mc_model = MultiComponentModel(model_file, device=device, backend=backend,
                                        max_walkers=n_hint)
-    ranks = None
-    if group is not None:
-        ranks = RankGroup(None if isinstance(group, str) else group, 'cuda:%d' % mc_model._device)
-        if ranks.world == 1:
-            ranks = None
+    ranks = _rank_group(group, mc_model._device)
     if chains is None:
         chains = 2 * mc_model.num_params + 2
     if chains > mc_model._max_walkers:
@@ -64,7 +83,11 @@ def model_galaxy_mcmc(model_file, output_name=None, write_fits=default_filetypes
         sampler = cls(chains, mc_model, group=ranks)
         device_acc = accumulate
     elif cls is EnsembleSampler:
-        evaluate = ShardedLogPosterior(mc_model, group=ranks.group) if ranks else mc_model.log_posterior_batch
+        if ranks:
+            from .parallel import ShardedLogPosterior
+            evaluate = ShardedLogPosterior(mc_model, group=ranks)
+        else:
+            evaluate = mc_model.log_posterior_batch
         sampler = cls(chains, mc_model.num_params, batch_lnpostfn=evaluate)
     else:                      # a real emcee: batch through its pool hook
         from .batch import BatchLogPosterior

@@ -413,7 +413,7 @@ class MultiComponentModel(object):
         """Walkers sharded over GPUs (`parallel.RankGroup`): add up the ranks' device-resident
         posterior sums, so that every rank holds the sums over ALL walkers.  One all-reduce of
         4 images at the end of sampling."""
-        if ranks is None or ranks.world == 1 or self._engine is None:
+        if ranks is None or ranks.single or self._engine is None:
             return
         sums, count = self._engine.accumulated_sums()
         total = ranks.all_reduce_sum_host(np.concatenate([sums.ravel(), [float(count)]]))

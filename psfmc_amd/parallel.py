@@ -32,9 +32,11 @@ class RankGroup(object):
             group at all -> a world of one)
     device  torch device of this rank's GPU (None: CPU tensors, for CPU-only tests)
     With the `gloo` backend the gathered tensors are staged through the host (tests,
-    rehearsals); with `nccl` (RCCL) they stay on the device."""
+    rehearsals); with `nccl` (RCCL) they stay on the device.
+    shortcut  False: a world of ONE rank still goes through the collectives (the single-GPU
+              rehearsal of the RCCL path: tests/test_gpu_multirank.py); default True."""
 
-    def __init__(self, group=None, device=None):
+    def __init__(self, group=None, device=None, shortcut=True):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -44,9 +46,22 @@ class RankGroup(object):
         self.rank = dist.get_rank(group) if self.active else 0
         self.device = torch.device(device) if device is not None else torch.device('cpu')
         backend = dist.get_backend(group) if self.active else 'none'
+        self.backend = backend
         self.host_staged = self.active and (backend != 'nccl' or self.device.type == 'cpu')
+        # a lone rank skips the collectives unless the caller wants them exercised
+        self.single = self.world == 1 and (shortcut or not self.active)
         self._index = {}
         self._stream = None
+
+    def _on_device(self):
+        """Context manager: this rank's GPU is torch's CURRENT device.  RCCL places the tensors of
+        its object collectives (`broadcast_object_list`) and its communicator on the current
+        device; a rank that never called `torch.cuda.set_device` would otherwise put them on
+        cuda:0 like every other rank (duplicate-GPU error or a hang at the first broadcast)."""
+        import contextlib
+        if self.device.type != 'cuda':
+            return contextlib.nullcontext()
+        return self.torch.cuda.device(self.device)
 
     def on_stream(self):
         """Context manager: torch work and library launches of the sharded paths share ONE real
@@ -83,37 +98,40 @@ class RankGroup(object):
         """send: [slot(n)] float64 tensor on `self.device` whose first (hi - lo) entries are
         this rank's block -> [n] tensor with every rank's block in place.  One all-gather."""
         torch, dist = self.torch, self.dist
-        if self.world == 1:
+        if self.single:
             return send[:n]
         slot = self.slot(n)
-        if self.host_staged:
-            recv = torch.empty(slot * self.world, dtype=torch.float64)
-            dist.all_gather_into_tensor(recv, send.detach().cpu().contiguous(), group=self.group)
-            recv = recv.to(self.device)
-        else:
-            recv = torch.empty(slot * self.world, dtype=torch.float64, device=self.device)
-            dist.all_gather_into_tensor(recv, send, group=self.group)
-        return recv.index_select(0, self._gather_index(n))
+        with self._on_device():
+            if self.host_staged:
+                recv = torch.empty(slot * self.world, dtype=torch.float64)
+                dist.all_gather_into_tensor(recv, send.detach().cpu().contiguous(), group=self.group)
+                recv = recv.to(self.device)
+            else:
+                recv = torch.empty(slot * self.world, dtype=torch.float64, device=self.device)
+                dist.all_gather_into_tensor(recv, send, group=self.group)
+            return recv.index_select(0, self._gather_index(n))
 
     def all_reduce_sum_host(self, array):
         """Element-wise sum over ranks of a host float64 array (posterior-image sums: a
         one-off exchange at the end of sampling)."""
-        if self.world == 1:
+        if self.single:
             return array
         torch, dist = self.torch, self.dist
         t = torch.from_numpy(np.ascontiguousarray(array, dtype=np.float64))
         if self.host_staged:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
             return t.numpy()
-        d = t.to(self.device)
-        dist.all_reduce(d, op=dist.ReduceOp.SUM, group=self.group)
-        return d.cpu().numpy()
+        with self._on_device():
+            d = t.to(self.device)
+            dist.all_reduce(d, op=dist.ReduceOp.SUM, group=self.group)
+            return d.cpu().numpy()
 
     def broadcast_object(self, obj, src=0):
-        if self.world == 1:
+        if self.single:
             return obj
         box = [obj]
-        self.dist.broadcast_object_list(box, src=src, group=self.group)
+        with self._on_device():
+            self.dist.broadcast_object_list(box, src=src, group=self.group)
         return box[0]
 
 
@@ -128,24 +146,24 @@ class ShardedLogPosterior(object):
     With world_size 1 (or no process group) it is a plain call.
     """
 
-    def __init__(self, evaluate, group=None, device=None):
+    def __init__(self, evaluate, group=None, device=None, shortcut=True):
         self.model = evaluate if hasattr(evaluate, 'log_posterior_batch') else None
         self.evaluate = self.model.log_posterior_batch if self.model is not None else evaluate
         if self.model is not None and device is None:
             device = 'cuda:%d' % self.model._device
-        self._group_arg, self._device_arg = group, device
-        self._rg = None
+        self._group_arg, self._device_arg, self._shortcut = group, device, shortcut
+        self._rg = group if isinstance(group, RankGroup) else None
 
     @property
     def ranks(self):
         if self._rg is None:
-            self._rg = RankGroup(self._group_arg, self._device_arg)
+            self._rg = RankGroup(self._group_arg, self._device_arg, shortcut=self._shortcut)
         return self._rg
 
     def __call__(self, theta):
         theta = np.ascontiguousarray(theta, dtype=np.float64)
         rg = self.ranks
-        if rg.world == 1:
+        if rg.single:
             return self.evaluate(theta)
         torch = rg.torch
         n_w = theta.shape[0]

@@ -294,8 +294,8 @@ class DeviceEnsembleSampler(EnsembleSampler):
         ranks = group if isinstance(group, RankGroup) else None
         if ranks is None and group is not None:
             ranks = RankGroup(None if group is True else group, 'cuda:%d' % model._device)
-        self.ranks = ranks if ranks is not None and ranks.world > 1 else None
-        evaluate = (ShardedLogPosterior(model, group=self.ranks.group) if self.ranks is not None
+        self.ranks = ranks if ranks is not None and not ranks.single else None
+        evaluate = (ShardedLogPosterior(model, group=self.ranks) if self.ranks is not None
                     else model.log_posterior_batch)
         super(DeviceEnsembleSampler, self).__init__(nwalkers, model.num_params, a=a,
                                                     batch_lnpostfn=evaluate,

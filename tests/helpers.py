@@ -119,3 +119,18 @@ def rel_err(got, ref):
     if not fin.any():
         return 0.0
     return float(np.max(np.abs(got[fin] - ref[fin]) / np.abs(ref[fin])))
+
+
+def longdouble_weight_map(field, raw, psf_index):
+    """models.py:265-280 with the two transforms of the variance convolution in numpy `longdouble`
+    (x87 80-bit: 64-bit significand): the composite inverse-variance map to ~1e-19 of the norm of
+    raw^2, i.e. 'exact' next to any fp64 evaluation -- the yardstick for how far the fp64 oracle
+    itself sits from the true weight map (tests/test_oracle_precision.py, test_gpu_random.py)."""
+    ld = np.longdouble
+    shape = raw.shape
+    k = int(np.rint(psf_index))
+    kernel = np.fft.irfft2(np.asarray(field.var_spec[k]).astype(np.clongdouble), s=shape)
+    spec = np.fft.rfft2(kernel.astype(ld))
+    model_var = np.fft.ifftshift(np.fft.irfft2(np.fft.rfft2(np.asarray(raw, dtype=ld) ** 2) * spec, s=shape))
+    with np.errstate(all='ignore'):
+        return 1 / (model_var + np.asarray(field.obs_var, dtype=ld))

@@ -135,13 +135,21 @@ def general_shapes():
     partners = [84, 256, 100, 126, 64, 150, 196, 128, 96, 252, 140, 120, 64, 350, 96, 210, 128, 84, 160, 98, 144,
                 112, 168, 64, 224]
     shapes += list(zip(sevens, partners)) + [(140, 140), (64, 448), (200, 294)]
+    # ... and once as the ROW length (round-2 advice: k_rows_fwd / k_rows_inv / k_raster_sums / k_pack_field of
+    # these NX had only ever run for the few sides that happened to be a partner)
+    shapes += [(p, s) for s, p in zip(sevens, partners) if (p, s) not in shapes]
     # sides with a factor 11 or 13 (the generic prime-radix codelet)
     primes = [88, 104, 110, 130, 132, 156, 176, 208, 220, 260, 264, 286, 308, 312, 330, 352, 364, 390, 416, 440, 484,
               520, 528, 572, 616, 624, 650, 660, 676, 704, 728, 780, 832]
     mates = [88, 64, 100, 130, 96, 128, 176, 84, 110, 64, 120, 104, 96, 156, 64, 88, 100, 130, 64, 132, 96,
              104, 64, 110, 88, 96, 64, 84, 100, 64, 104, 96, 64]
     shapes += list(zip(primes, mates)) + [(128, 286), (64, 676)]
+    shapes += [(m, s) for s, m in zip(primes, mates) if (m, s) not in shapes]
+    shapes += [(420, 420), (560, 560), (308, 308), (832, 832), (512, 100)]          # squares of the larger seven / prime sides
     assert all(engine.fused_supports(ny, nx) for ny, nx in shapes)
+    # the claim above, enforced: every built side runs as the column length AND as the row length
+    assert {ny for ny, _ in shapes} >= set(engine.FUSED_SIDES), sorted(set(engine.FUSED_SIDES) - {ny for ny, _ in shapes})
+    assert {nx for _, nx in shapes} >= set(engine.FUSED_SIDES), sorted(set(engine.FUSED_SIDES) - {nx for _, nx in shapes})
     # a side with a prime factor > 13 (or factors the shapes cannot split into P, T <= 32) goes to
     # the hipFFT back end under backend='auto'
     assert not engine.fused_supports(170, 170) and not engine.fused_supports(256, 90) and not engine.fused_supports(490, 64)
@@ -179,6 +187,14 @@ def test_general_sides_match_oracle(shape):
             peak = np.nanmax(np.abs(imgs['raw_model']))
             tol = 5e-9 * max(1.0, (peak / 2e3) ** 2) if kind == 'composite_ivm' else 1e-11
             assert np.abs(dev[kind][0][fin] - ref[fin]).max() <= tol * scale, (shape, kind)
+            if kind == 'composite_ivm' and peak > 2e3 and np.finfo(np.longdouble).nmant >= 63:
+                # the evidence for that bound (tests/test_oracle_precision.py): against the weight map
+                # computed with 80-bit transforms the GPU is no farther off than a few times the fp64
+                # oracle itself
+                exact = helpers.longdouble_weight_map(field, imgs['raw_model'], case['psf_index'])
+                e_orc = float(np.abs(ref[fin].astype(np.longdouble) - exact[fin]).max())
+                e_gpu = float(np.abs(dev[kind][0][fin].astype(np.longdouble) - exact[fin]).max())
+                assert e_gpu <= 4.0 * e_orc + 1e-11 * scale, (shape, e_gpu / scale, e_orc / scale)
     else:
         assert got[0] == -np.inf
     # the device-computed PSF spectra of this shape against numpy
