@@ -173,12 +173,9 @@ def kernel_profile(eng, args, one_batch, torch, dev, reps):
     n = args.size
     nxh = n // 2 + 1
     t_bytes = 2 * nxh * n * 16                  # transposed half-spectra of one walker
-    # (pair: one launch of the paired pipeline moves a pass's T four times -- its row waves read the
-    # leaving walkers' rows and write the entering ones', its column waves read and write a pass in place)
-    designed = {'rows_fwd': t_bytes, 'cols': 2 * t_bytes, 'rows_inv': t_bytes, 'pair': 4 * t_bytes}
+    designed = {'rows_fwd': t_bytes, 'cols': 2 * t_bytes, 'rows_inv': t_bytes}
     names = {'rows_fwd': 'k_rows_fwd<%d, false>' % n, 'rows_inv': 'k_rows_inv<%d>' % n,
-             'cols': ('k_cols3<%d, true>' if n in (512, 1024) else 'k_cols<%d, true>') % n,
-             'pair': 'k_pair<%d, false>' % n}
+             'cols': ('k_cols3<%d, true>' if n in (512, 1024) else 'k_cols<%d, true>') % n}
     streams = eng.get_option('streams')
     eng.set_option('streams', 1)
     eng.set_option('profile', 1)
@@ -186,7 +183,7 @@ def kernel_profile(eng, args, one_batch, torch, dev, reps):
         one_batch()
     torch.cuda.synchronize(dev)
     out = []
-    for key in ('rows_fwd', 'cols', 'rows_inv', 'pair'):
+    for key in ('rows_fwd', 'cols', 'rows_inv'):
         ms = eng.get_option('prof_ms_' + key)
         cnt = eng.get_option('prof_n_' + key)
         if not cnt or cnt != cnt:            # 0, or NaN from a library that does not know the key

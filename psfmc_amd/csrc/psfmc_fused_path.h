@@ -50,9 +50,6 @@ constexpr int kColThreads = 256;     // column kernel: 4 waves, persistent
 #ifndef PSFMC_INV_PRIO
 #define PSFMC_INV_PRIO 0
 #endif
-#ifndef PSFMC_INV_CHUNK
-#define PSFMC_INV_CHUNK 8             /* field pixels per load chunk of k_rows_inv at nx = 512, 1024 */
-#endif
 #ifndef PSFMC_COLS_PREFETCH
 #define PSFMC_COLS_PREFETCH 1         /* register double-buffering of the column loads */
 #endif
@@ -182,22 +179,24 @@ __global__ void k_pack_field(const double* __restrict__ sci, const double* __res
 //   FROM_IMAGE = true : z = img0 + i img_scale[w] img1 from memory (PSF spectra at setup)
 // raw_out (optional): [n][ny][nx] copy of the raw model (psfmc_eval_images)
 // ---------------------------------------------------------------------------
-// One wave's share of rows_fwd: row group yg of walker w; `wave_lds` = the wave's own LDS region of
-// fused_row_wave_lds_doubles<NX>() doubles.  Shared by k_rows_fwd and the paired kernel (psfmc_pair_path.h).
-template <int NX, bool FROM_IMAGE, typename TS, bool FAST>
-__device__ __forceinline__ void rows_fwd_wave(int w, int yg, int lane, double* __restrict__ wave_lds,
-                                              const double* __restrict__ prep, const uint8_t* __restrict__ skip,
-                                              const cd* __restrict__ twx, TS* __restrict__ Tbuf, int n_ps,
-                                              int n_sersic, int ny, int ps_only, const double* __restrict__ img,
-                                              const double* __restrict__ img_scale, double* __restrict__ raw_out) {
+template <int NX, bool FROM_IMAGE, typename TS = cd, bool FAST = FftShape<NX>::kPlain>
+__global__ void __launch_bounds__((row_threads<NX, FAST>()), fused_min_waves<NX>())
+k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
+           const cd* __restrict__ twx, TS* __restrict__ Tbuf, int n_ps, int n_sersic, int ny,
+           int ps_only, const double* __restrict__ img, const double* __restrict__ img_scale,
+           double* __restrict__ raw_out) {
     using S = FftShape<NX>;
     constexpr int P = S::P, T = S::T, R = S::R, RG = row_group<NX>();
     constexpr int NXH = NX / 2 + 1;
     constexpr int RGL2 = layout_rg_log2<NX, FAST>(), RGL = 1 << RGL2;       // rows per layout group
+    extern __shared__ __align__(16) double smem[];
+    const int w = blockIdx.y;
     // the skip flag is a (wave-uniform) byte behind a vector load: tested only after the loads that
     // do not depend on it have been issued, so that its latency is not a serial step of every wave
     const bool skipped = skip && skip[w];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int f = lane / T, t = lane % T;
+    const int yg = blockIdx.x * row_waves<NX, FAST>() + wave;
     if constexpr (!FAST)
         if (yg * RG >= ny) return;                                    // wave-uniform: past the last row group
     const bool lane_on = S::kFull || f < RG;                          // not one of the idle tail lanes
@@ -224,7 +223,7 @@ __device__ __forceinline__ void rows_fwd_wave(int w, int yg, int lane, double* _
         // the rasteriser's log2 table borrows the start of the wave's transform exchange region,
         // which is idle until the transform begins
         static_assert((size_t)RG * fft_lds_elems<NX>() * sizeof(double) >= (size_t)kLogTabBytes, "exchange region too small");
-        double* log_tab = wave_lds;
+        double* log_tab = smem + (size_t)wave * fused_row_wave_lds_doubles<NX>();
         if (!ps_only) {
             load_log_table(log_tab, lane);
             wave_lds_sync();
@@ -240,6 +239,7 @@ __device__ __forceinline__ void rows_fwd_wave(int w, int yg, int lane, double* _
             for (int k = 0; k < P; ++k) o[T * k + t] = v[k].x;
         }
     }
+    double* wave_lds = smem + (size_t)wave * fused_row_wave_lds_doubles<NX>();
     cd* twl = reinterpret_cast<cd*>(wave_lds + (size_t)RG * fft_lds_elems<NX>());
     cd tw[fft_tw_regs<NX>()];
     load_twiddles<NX>(tw, twx, t, twl, lane);
@@ -306,19 +306,6 @@ __device__ __forceinline__ void rows_fwd_wave(int w, int yg, int lane, double* _
             }
         }
     }
-}
-
-template <int NX, bool FROM_IMAGE, typename TS = cd, bool FAST = FftShape<NX>::kPlain>
-__global__ void __launch_bounds__((row_threads<NX, FAST>()), fused_min_waves<NX>())
-k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
-           const cd* __restrict__ twx, TS* __restrict__ Tbuf, int n_ps, int n_sersic, int ny,
-           int ps_only, const double* __restrict__ img, const double* __restrict__ img_scale,
-           double* __restrict__ raw_out) {
-    extern __shared__ __align__(16) double smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    rows_fwd_wave<NX, FROM_IMAGE, TS, FAST>(blockIdx.y, blockIdx.x * row_waves<NX, FAST>() + wave, lane,
-                                            smem + (size_t)wave * fused_row_wave_lds_doubles<NX>(), prep, skip, twx,
-                                            Tbuf, n_ps, n_sersic, ny, ps_only, img, img_scale, raw_out);
 }
 
 // ---------------------------------------------------------------------------
@@ -534,19 +521,28 @@ template <int NY> constexpr size_t fused_col3_lds_bytes() {
 #ifndef PSFMC_COLS3_WAVES
 #define PSFMC_COLS3_WAVES 2     /* measured at 1024 (before the shared LDS twiddle table: 150 us now): 1 or 2 -> 178 us, 3 -> 273 us, 4 -> 374 us (spills) */
 #endif
-// One wave's share of cols3: the columns `wave`, `wave` + 4, ... of the workgroup's groups (persistent;
-// the groups of a workgroup come from xcd_group_range).  `lds` = the wave's exchange region of
-// fft3_lds_doubles<NY>() doubles, `w1s` = the workgroup's shared stage-1 twiddle table (R1 = 16) or
-// nullptr.  Shared by k_cols3 and the paired kernel (psfmc_pair_path.h).
-template <int NY, bool CONVOLVE, typename TS>
-__device__ __forceinline__ void cols3_wave(int wave, int t, double* __restrict__ lds, const cd* __restrict__ w1s,
-                                           TS* __restrict__ Tbuf, const cd* __restrict__ Kt,
-                                           const double* __restrict__ prep, const uint8_t* __restrict__ skip,
-                                           const cd* __restrict__ twy, int plen, int nxh, int n_w, int rg_log2) {
+template <int NY, bool CONVOLVE, typename TS = cd>
+__global__ void __launch_bounds__(kColThreads, Fft3Shape<NY>::R1 > 8 ? PSFMC_COLS3_WAVES : 2)
+k_cols3(TS* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restrict__ prep,
+        const uint8_t* __restrict__ skip, const cd* __restrict__ twy, int plen, int nxh, int n_w,
+        int rg_log2) {
     constexpr int R1 = Fft3Shape<NY>::R1;
     constexpr int WPB = kColThreads / 64;
+    extern __shared__ __align__(16) double smem[];
+#if PSFMC_COLS_PRIO
+    __builtin_amdgcn_s_setprio(PSFMC_COLS_PRIO);
+#endif
+    const int t = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* lds = smem + (size_t)wave * fft3_lds_doubles<NY>();
     cd w1[fft3_w1_regs<NY>()], w2[8];
     load_twiddles3<NY>(w1, w2, twy, t);
+    const cd* w1s = nullptr;
+    if constexpr (R1 > 8) {
+        cd* tab = reinterpret_cast<cd*>(smem + (size_t)WPB * fft3_lds_doubles<NY>());
+        for (int i = threadIdx.x; i < R1 * 64; i += kColThreads) tab[i] = twy[(i & 63) * (i >> 6)];
+        __syncthreads();                                   // once, before any wave can leave
+        w1s = tab;
+    }
     const int rg = 1 << rg_log2;
     const int e0 = t_elem(t, 0, rg_log2);              // offset of y = t; y = 64 a + t adds 128 a
     const int n_cols = n_w * 2 * nxh;
@@ -587,29 +583,6 @@ __device__ __forceinline__ void cols3_wave(int wave, int t, double* __restrict__
     }
 }
 
-template <int NY, bool CONVOLVE, typename TS = cd>
-__global__ void __launch_bounds__(kColThreads, Fft3Shape<NY>::R1 > 8 ? PSFMC_COLS3_WAVES : 2)
-k_cols3(TS* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restrict__ prep,
-        const uint8_t* __restrict__ skip, const cd* __restrict__ twy, int plen, int nxh, int n_w,
-        int rg_log2) {
-    constexpr int R1 = Fft3Shape<NY>::R1;
-    constexpr int WPB = kColThreads / 64;
-    extern __shared__ __align__(16) double smem[];
-#if PSFMC_COLS_PRIO
-    __builtin_amdgcn_s_setprio(PSFMC_COLS_PRIO);
-#endif
-    const int t = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const cd* w1s = nullptr;
-    if constexpr (R1 > 8) {
-        cd* tab = reinterpret_cast<cd*>(smem + (size_t)WPB * fft3_lds_doubles<NY>());
-        for (int i = threadIdx.x; i < R1 * 64; i += kColThreads) tab[i] = twy[(i & 63) * (i >> 6)];
-        __syncthreads();                                   // once, before any wave can leave
-        w1s = tab;
-    }
-    cols3_wave<NY, CONVOLVE, TS>(wave, t, smem + (size_t)wave * fft3_lds_doubles<NY>(), w1s, Tbuf, Kt, prep, skip, twy,
-                                 plen, nxh, n_w, rg_log2);
-}
-
 // ---------------------------------------------------------------------------
 // rows_inv.  grid (ny / RG, n_walkers); one wave per workgroup.
 // partial[w][yg] = sum over the wave's good pixels of the chi^2 term.
@@ -618,23 +591,28 @@ k_cols3(TS* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restri
 // MULTI: the context holds several observed fields (psfmc_ctx_create_fields) -- its own instantiation,
 // so that the one-field kernel keeps its registers (at nx = 1024 two more kernel arguments pushed the
 // scalar registers over their limit and the kernel to one wave per SIMD: 33.7 -> 39.6 us)
-// One wave's share of rows_inv: row group yg (of nyg per walker) of walker w; `wave_lds` as in
-// rows_fwd_wave.  Shared by k_rows_inv and the paired kernel.
-template <int NX, typename TS, bool FAST, bool MULTI>
-__device__ __forceinline__ void rows_inv_wave(int w, int yg, int nyg, int lane, double* __restrict__ wave_lds,
-                                              const TS* __restrict__ Tbuf, const uint8_t* __restrict__ skip,
-                                              const cd* __restrict__ twx, const FieldPx* __restrict__ field,
-                                              double* __restrict__ partial, int ny, const double* __restrict__ prep,
-                                              int plen, double* __restrict__ conv_out, double* __restrict__ var_out,
-                                              int n_psf_field, unsigned field_stride) {
+template <int NX, typename TS = cd, bool FAST = FftShape<NX>::kPlain, bool MULTI = false>
+__global__ void __launch_bounds__((row_threads<NX, FAST>()), fused_min_waves<NX>())
+k_rows_inv(const TS* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const cd* __restrict__ twx,
+           const FieldPx* __restrict__ field, double* __restrict__ partial, int ny,
+           const double* __restrict__ prep, int plen,
+           double* __restrict__ conv_out, double* __restrict__ var_out, int n_psf_field, unsigned field_stride) {
     using S = FftShape<NX>;
     constexpr int P = S::P, T = S::T, R = S::R, RG = row_group<NX>();
     constexpr int NXH = NX / 2 + 1;
     constexpr int RGL2 = layout_rg_log2<NX, FAST>(), RGL = 1 << RGL2;
+    extern __shared__ __align__(16) double smem[];
+#if PSFMC_INV_PRIO
+    __builtin_amdgcn_s_setprio(PSFMC_INV_PRIO);
+#endif
+
+    const int w = blockIdx.y;
     // (testing the flag only after the loads of T were issued, as k_rows_fwd and k_cols3 do, made
     // this kernel slower at 512 and 1024 -- 31.5 -> 37.7 us, 34.1 -> 41.6 us -- and left 256 unchanged)
     if (skip && skip[w]) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int f = lane / T, t = lane % T;
+    const int yg = blockIdx.x * row_waves<NX, FAST>() + wave;
     if constexpr (!FAST)
         if (yg * RG >= ny) return;                                    // wave-uniform
     const bool lane_on = S::kFull || f < RG;
@@ -642,6 +620,7 @@ __device__ __forceinline__ void rows_inv_wave(int w, int yg, int nyg, int lane, 
     const int iy = yg * RG + f;
     const bool row_on = FAST || (lane_on && iy < ny);
     const int nyp = t_col_len(ny, RGL2);
+    const int nyg = FAST ? (int)gridDim.x * row_waves<NX, FAST>() : (ny + RG - 1) / RG;
     const TS* wbase = Tbuf + (size_t)w * 2 * NXH * nyp;             // wave-uniform
     constexpr unsigned kEl = sizeof(TS);                             // bytes of a T element
     const unsigned kstride = 2u * (unsigned)nyp * kEl;               // bytes between kx columns
@@ -650,6 +629,7 @@ __device__ __forceinline__ void rows_inv_wave(int w, int yg, int nyg, int lane, 
     // Every (G, H) pair is loaded once, by the lane that owns k <= NX/2; that lane also
     // forms the mirrored value and hands it to the owner of NX - k through the transform's
     // LDS region.
+    double* wave_lds = smem + (size_t)wave * fused_row_wave_lds_doubles<NX>();
     cd* mbuf = reinterpret_cast<cd*>(wave_lds + (size_t)fe * fft_lds_elems<NX>());
     cd v[R];
 #pragma unroll
@@ -743,67 +723,40 @@ __device__ __forceinline__ void rows_inv_wave(int w, int yg, int nyg, int lane, 
     if (MULTI || (NX < 1024 && n_psf_field > 0))
         fbase += (size_t)((int)prep[(size_t)w * plen + kPrepPsfIdx] / n_psf_field) * field_stride;
     const unsigned foff = (unsigned)lane * (unsigned)sizeof(FieldPx);
-    // The field pixels arrive in chunks of CH registers, the next chunk's loads in flight while this
-    // one is summed.  One chunk = all R for the small shapes; at R = 32 (nx = 512, 1024) four chunks of
-    // 8: all 32 pixels at once were 128 registers on top of the transform's 128 -- the whole budget of a
-    // wave at two per SIMD, with scalar registers spilling into what was left.  The sums do not depend
-    // on the chunking: good pixels are added in register order by the same instructions either way.
-    constexpr int CH = (FAST && R == 32) ? PSFMC_INV_CHUNK : R, NCH = R / CH;
-    static_assert(R % CH == 0, "chunks");
+    FieldPx px[R];
+    bool any_bad = false;
+#pragma unroll
+    for (int e = 0; e < R; ++e) {
+        px[e] = *at_bytes(fbase, foff + (unsigned)(e * 64 * sizeof(FieldPx)));
+        any_bad |= px[e].sci != px[e].sci;
+    }
     double acc = 0.0, mant = 1.0;
-    int expo = 0, n_good = 0;
+    int expo = 0, n_good = R;
     bool invalid = false;
-    auto load_chunk = [&](FieldPx (&px)[CH], int c) {
+    if (!__any(any_bad)) {
 #pragma unroll
-        for (int j = 0; j < CH; ++j) px[j] = *at_bytes(fbase, foff + (unsigned)((c * CH + j) * 64 * sizeof(FieldPx)));
-    };
-    auto sum_chunk = [&](const FieldPx (&px)[CH], int c) {
-        bool any_bad = false;
-#pragma unroll
-        for (int j = 0; j < CH; ++j) any_bad |= px[j].sci != px[j].sci;
-        if (!__any(any_bad)) {
-#pragma unroll
-            for (int j = 0; j < CH; ++j) {
-                const int e = c * CH + j;
-                const double d = __builtin_fma(v[e].y, inv_lambda, px[j].var);
-                const double r = px[j].sci - v[e].x;
-                acc = __builtin_fma(r * r, fast_rcp(d), acc);
-                invalid |= !(d > 0.0);
-                mant *= __builtin_amdgcn_frexp_mant(d);
-                expo += __builtin_amdgcn_frexp_exp(d);
-            }
-            n_good += CH;
-        } else {
-#pragma unroll
-            for (int j = 0; j < CH; ++j) {
-                const int e = c * CH + j;
-                const bool good = px[j].sci == px[j].sci;
-                const double d = __builtin_fma(v[e].y, inv_lambda, px[j].var);
-                const double r = px[j].sci - v[e].x;
-                const double a1 = __builtin_fma(r * r, fast_rcp(d), acc);
-                acc = good ? a1 : acc;
-                const double dd = good ? d : 1.0;                // neutral factor
-                invalid |= !(dd > 0.0);
-                mant *= __builtin_amdgcn_frexp_mant(dd);
-                expo += __builtin_amdgcn_frexp_exp(dd);
-                n_good += good ? 1 : 0;
-            }
+        for (int e = 0; e < R; ++e) {
+            const double d = __builtin_fma(v[e].y, inv_lambda, px[e].var);
+            const double r = px[e].sci - v[e].x;
+            acc = __builtin_fma(r * r, fast_rcp(d), acc);
+            invalid |= !(d > 0.0);
+            mant *= __builtin_amdgcn_frexp_mant(d);
+            expo += __builtin_amdgcn_frexp_exp(d);
         }
-    };
-    if constexpr (NCH == 1) {
-        FieldPx px[CH];
-        load_chunk(px, 0);
-        sum_chunk(px, 0);
     } else {
-        static_assert(NCH % 2 == 0, "chunk pairs");
-        FieldPx pa[CH], pb[CH];
-        load_chunk(pa, 0);
+        n_good = 0;
 #pragma unroll
-        for (int c = 0; c < NCH; c += 2) {
-            load_chunk(pb, c + 1);
-            sum_chunk(pa, c);
-            if (c + 2 < NCH) load_chunk(pa, c + 2);
-            sum_chunk(pb, c + 1);
+        for (int e = 0; e < R; ++e) {
+            const bool good = px[e].sci == px[e].sci;
+            const double d = __builtin_fma(v[e].y, inv_lambda, px[e].var);
+            const double r = px[e].sci - v[e].x;
+            const double q = r * r * fast_rcp(d);
+            acc += good ? q : 0.0;
+            const double dd = good ? d : 1.0;                // neutral factor
+            invalid |= !(dd > 0.0);
+            mant *= __builtin_amdgcn_frexp_mant(dd);
+            expo += __builtin_amdgcn_frexp_exp(dd);
+            n_good += good ? 1 : 0;
         }
     }
     acc += 0.69314718055994530942 * (fast_log2(mant) + (double)expo) +
@@ -812,24 +765,6 @@ __device__ __forceinline__ void rows_inv_wave(int w, int yg, int nyg, int lane, 
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
     if (lane == 0) partial[(size_t)w * nyg + yg] = acc;
-}
-
-template <int NX, typename TS = cd, bool FAST = FftShape<NX>::kPlain, bool MULTI = false>
-__global__ void __launch_bounds__((row_threads<NX, FAST>()), fused_min_waves<NX>())
-k_rows_inv(const TS* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const cd* __restrict__ twx,
-           const FieldPx* __restrict__ field, double* __restrict__ partial, int ny,
-           const double* __restrict__ prep, int plen,
-           double* __restrict__ conv_out, double* __restrict__ var_out, int n_psf_field, unsigned field_stride) {
-    extern __shared__ __align__(16) double smem[];
-#if PSFMC_INV_PRIO
-    __builtin_amdgcn_s_setprio(PSFMC_INV_PRIO);
-#endif
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int RG = row_group<NX>();
-    const int nyg = FAST ? (int)gridDim.x * row_waves<NX, FAST>() : (ny + RG - 1) / RG;
-    rows_inv_wave<NX, TS, FAST, MULTI>(blockIdx.y, blockIdx.x * row_waves<NX, FAST>() + wave, nyg, lane,
-                                       smem + (size_t)wave * fused_row_wave_lds_doubles<NX>(), Tbuf, skip, twx, field,
-                                       partial, ny, prep, plen, conv_out, var_out, n_psf_field, field_stride);
 }
 
 // ---------------------------------------------------------------------------

@@ -27,7 +27,6 @@
 #include "psfmc_hipfft_path.h"
 #endif
 #include "psfmc_fused_path.h"
-#include "psfmc_pair_path.h"
 #include "psfmc_theta.h"
 
 using namespace psfmc;
@@ -334,17 +333,12 @@ struct psfmc_ctx {
                               // the iteration is kernel-time- not launch-bound)
     long long graph_launches = 0;
     int min_split = 1 << 30;  // split a single-pass batch over both streams from this size (off: no gain measured)
-    // the paired pipeline (psfmc_pair_path.h): one launch per pass, row waves and column waves co-resident
-    bool paired = false;      // opt-in for 512^2 and 1024^2 (set_option "paired"): an experiment that lost
-    int pair_grid = 0;        // its persistent grid: one 512-thread workgroup per CU
-    int pair_min_passes = 3;  // batches of fewer passes keep the three-kernel flow
-    int pair_roles = 3;       // measurement only (set_option "pair_roles"): bit 0 row role, bit 1 column role; results are wrong unless 3
     // optional per-kernel timing with HIP events (set_option "profile")
     bool profile = false;
     struct ProfRec { int kind; hipEvent_t a, b; };
     std::vector<ProfRec> prof_pending;
-    double prof_ms[4] = {0, 0, 0, 0};
-    long prof_n[4] = {0, 0, 0, 0};
+    double prof_ms[3] = {0, 0, 0};
+    long prof_n[3] = {0, 0, 0};
     cd* d_Kraw = nullptr;     // [n_psf][2][nxh][ny] kernel spectra, unscaled
     cd* d_Kt = nullptr;       // same * (-1)^(kx+ky) / S
     cd *d_twx = nullptr, *d_twy = nullptr;            // exp(-2 pi i k/n) tables
@@ -532,39 +526,6 @@ template <int NX> static int pack_field(psfmc_ctx* c, int f) {
     return PSFMC_OK;
 }
 
-// the paired pipeline's one kernel (psfmc_pair_path.h); built for the sides 512 and 1024
-struct PairCall { PairRows rows; PairCols cols; };
-template <int N>
-static int launch_pair(psfmc_ctx* c, const PairCall& pc, hipStream_t st) {
-    if constexpr (N == 512 || N == 1024) {
-        constexpr size_t lds = pair_lds_bytes<N>();
-        const bool multi = N >= 1024 && c->n_fields > 1;
-        static thread_local int attr_device = -1;
-        if (attr_device != c->device) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pair<N, false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            if constexpr (N >= 1024)
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pair<N, true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_device = c->device;
-        }
-        const int npf = c->n_fields > 1 ? c->n_psf_field : 0;
-        if constexpr (N >= 1024) {
-            if (multi) {
-                hipLaunchKernelGGL((k_pair<N, true>), dim3(c->pair_grid), dim3(kPairThreads), lds, st, pc.rows, pc.cols,
-                                   c->d_twx, c->d_Kt, c->d_field, c->n_ps, c->n_sersic, c->plen, npf,
-                                   (unsigned)c->field_len);
-                return PSFMC_OK;
-            }
-        }
-        hipLaunchKernelGGL((k_pair<N, false>), dim3(c->pair_grid), dim3(kPairThreads), lds, st, pc.rows, pc.cols,
-                           c->d_twx, c->d_Kt, c->d_field, c->n_ps, c->n_sersic, c->plen, npf, (unsigned)c->field_len);
-        return PSFMC_OK;
-    } else {
-        return fail(PSFMC_EINVAL, "the paired pipeline is built for 512^2 and 1024^2");
-    }
-}
-
 template <int NX>
 static int launch_raster_sums(psfmc_ctx* c, int n, const double* prep, int groups, int group_size, hipStream_t st) {
     constexpr int RG = FftShape<NX>::TPW;
@@ -577,7 +538,7 @@ static int launch_raster_sums(psfmc_ctx* c, int n, const double* prep, int group
 // ---------------------------------------------------------------------------
 // size-erased entry to the per-side launchers: what crosses the boundary between the parts
 // ---------------------------------------------------------------------------
-enum SizeOp { SZ_ROW_SHAPE, SZ_FIELD_LEN, SZ_PACK_FIELD, SZ_ROWS_FWD, SZ_COLS, SZ_ROWS_INV, SZ_RASTER_SUMS, SZ_PAIR };
+enum SizeOp { SZ_ROW_SHAPE, SZ_FIELD_LEN, SZ_PACK_FIELD, SZ_ROWS_FWD, SZ_COLS, SZ_ROWS_INV, SZ_RASTER_SUMS };
 struct SizeCall {
     psfmc_ctx* c = nullptr;
     int n = 0;                              // walkers
@@ -592,7 +553,6 @@ struct SizeCall {
     int field = 0, groups = 0, group_size = 0, ny = 0;
     RowShape* shape = nullptr;
     size_t* len = nullptr;
-    const PairCall* pair = nullptr;
 };
 
 static int size_call_here(int op, int side, SizeCall& a) {
@@ -640,9 +600,6 @@ static int size_call_here(int op, int side, SizeCall& a) {
             return PSFMC_OK;
         case SZ_RASTER_SUMS:
             DISPATCH_LEN(side, RC_TRY((launch_raster_sums<N_>(c, a.n, a.prep, a.groups, a.group_size, a.st))));
-            return PSFMC_OK;
-        case SZ_PAIR:
-            DISPATCH_LEN(side, RC_TRY((launch_pair<N_>(c, *a.pair, a.st))));
             return PSFMC_OK;
     }
     return fail(PSFMC_EINVAL, "unknown size operation %d", op);
@@ -756,7 +713,7 @@ static bool fused_side(int n) {
 
 
 // per-kernel timing: bracket a launch with events on its own stream
-enum { PROF_ROWS_FWD = 0, PROF_COLS = 1, PROF_ROWS_INV = 2, PROF_PAIR = 3 };
+enum { PROF_ROWS_FWD = 0, PROF_COLS = 1, PROF_ROWS_INV = 2 };
 struct ProfScope {
     psfmc_ctx* c; int kind; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
     ProfScope(psfmc_ctx* c_, int kind_, hipStream_t st_) : c(c_), kind(kind_), st(st_) {
@@ -1030,8 +987,6 @@ static int ctx_create_impl(psfmc_ctx** out, int device, int ny, int nx, int n_fi
         // (+3.8 % with two Sersics); 384^2 -0.4 %, 512^2 -1.3...-2.5 %, 1024^2 0, 200^2 -1.6 %, 300^2 -7.7 %,
         // 400^2 -10.6 %: on for the small power-of-two shapes only
         c->stagger = (c->plain_shape && c->row_fast && nx <= 256 && ny <= 256) ? 1 : 0;
-        c->pair_grid = prop.multiProcessorCount;
-        c->paired = false;      // opt-in (set_option "paired"): measured at half the rate of the three-kernel flow, DESIGN.md section 6
     } else {
         c->nblk = (c->S + 1023) / 1024;
         if (c->nblk > 64) c->nblk = 64;
@@ -1151,26 +1106,6 @@ extern "C" int psfmc_set_option(psfmc_ctx* c, const char* key, double value) {
         c->stagger = (int)value;
         return PSFMC_OK;
     }
-    if (!strcmp(key, "paired")) {
-        if (value != 0 && !(c->backend == PSFMC_BACKEND_FUSED && c->row_fast && c->nx == c->ny &&
-                            (c->nx == 512 || c->nx == 1024)))
-            return fail(PSFMC_EINVAL, "the paired pipeline is built for 512^2 and 1024^2 on the fused back end");
-        c->paired = value != 0;
-        return PSFMC_OK;
-    }
-    if (!strcmp(key, "pair_grid")) {
-        if (value < 1) return fail(PSFMC_EINVAL, "pair_grid must be >= 1");
-        c->pair_grid = (int)value;
-        return PSFMC_OK;
-    }
-    if (!strcmp(key, "pair_roles")) {
-        c->pair_roles = (int)value;
-        return PSFMC_OK;
-    }
-    if (!strcmp(key, "pair_min_passes")) {
-        c->pair_min_passes = value < 1 ? 1 : (int)value;
-        return PSFMC_OK;
-    }
     if (!strcmp(key, "linear_accumulation")) {
         HIP_TRY(hipSetDevice(c->device));
         RC_TRY(flush_linear_sums(c));
@@ -1194,7 +1129,7 @@ extern "C" int psfmc_set_option(psfmc_ctx* c, const char* key, double value) {
         HIP_TRY(hipDeviceSynchronize());
         prof_collect(c);
         c->profile = value != 0;
-        for (int i = 0; i < 4; ++i) { c->prof_ms[i] = 0; c->prof_n[i] = 0; }
+        for (int i = 0; i < 3; ++i) { c->prof_ms[i] = 0; c->prof_n[i] = 0; }
         return PSFMC_OK;
     }
     if (!strcmp(key, "streams")) {
@@ -1210,8 +1145,8 @@ extern "C" int psfmc_set_option(psfmc_ctx* c, const char* key, double value) {
 extern "C" double psfmc_get_option(const psfmc_ctx* cc, const char* key) {
     if (!cc || !key) return NAN;
     psfmc_ctx* c = const_cast<psfmc_ctx*>(cc);
-    static const char* kinds[4] = {"rows_fwd", "cols", "rows_inv", "pair"};
-    for (int i = 0; i < 4; ++i) {
+    static const char* kinds[3] = {"rows_fwd", "cols", "rows_inv"};
+    for (int i = 0; i < 3; ++i) {
         char name[64];
         snprintf(name, sizeof name, "prof_ms_%s", kinds[i]);
         if (!strcmp(key, name)) { prof_collect(c); return c->prof_ms[i]; }
@@ -1228,8 +1163,6 @@ extern "C" double psfmc_get_option(const psfmc_ctx* cc, const char* key) {
     if (!strcmp(key, "cols_grid")) return c->cols_grid;
     if (!strcmp(key, "streams")) return c->n_streams;
     if (!strcmp(key, "stagger")) return c->stagger;
-    if (!strcmp(key, "paired")) return c->paired ? 1.0 : 0.0;
-    if (!strcmp(key, "pair_grid")) return c->pair_grid;
     if (!strcmp(key, "linear_accumulation")) return c->linear_acc ? 1.0 : 0.0;
     return NAN;
 }
@@ -1279,59 +1212,10 @@ static int pass_size(const psfmc_ctx* c, int W) {
     return chunk;
 }
 
-// walkers per pass of the paired pipeline for a batch of W, or 0 when the batch takes the three-kernel
-// flow (the pipeline is off, or the batch has too few passes to fill it): passes of c->chunk walkers,
-// evened out, never more than a T buffer holds
-static int paired_pass_size(const psfmc_ctx* c, int W) {
-    if (c->backend != PSFMC_BACKEND_FUSED || !c->paired || c->t_f32 || c->n_streams < 2) return 0;
-    const int np = (W + c->chunk - 1) / c->chunk;
-    if (np < c->pair_min_passes) return 0;
-    const int chunk = (W + np - 1) / np;
-    return chunk > c->chunk ? c->chunk : chunk;
-}
-
 extern "C" int psfmc_pass_size(const psfmc_ctx* c, int W) {
     if (!c) return fail(PSFMC_EINVAL, "ctx is NULL");
     if (W < 1 || W > c->max_walkers) return fail(PSFMC_EINVAL, "W=%d outside [1, max_walkers=%d]", W, c->max_walkers);
-    if (const int pchunk = paired_pass_size(c, W)) return pchunk;
     return pass_size(c, W);
-}
-
-// The paired pipeline (psfmc_pair_path.h): np passes in np + 2 launches on the caller's stream.
-// Launch k rasterises + row-transforms pass k into buffer k % 2 (its row waves first taking pass
-// k - 2 out of the same slots: inverse row transform + chi^2) while its column waves convolve
-// pass k - 1 in the other buffer.
-static int run_pipeline_paired(psfmc_ctx* c, int W, int chunk, const uint8_t* d_skip, hipStream_t st, int w_off) {
-    const int npass = (W + chunk - 1) / chunk;
-    auto count = [&](int p) { return p < 0 || p >= npass ? 0 : (W - p * chunk < chunk ? W - p * chunk : chunk); };
-    auto prep_of = [&](int p) { return c->d_prep + (size_t)(w_off + (p < 0 || p >= npass ? 0 : p) * chunk) * c->plen; };
-    auto skip_of = [&](int p) -> const uint8_t* {
-        return d_skip ? d_skip + w_off + (p < 0 || p >= npass ? 0 : p) * chunk : nullptr;
-    };
-    for (int k = 0; k < npass + 2; ++k) {
-        PairCall pc;
-        pc.rows.T = c->d_Ts[k & 1];
-        pc.rows.n_inv = count(k - 2);
-        pc.rows.n_fwd = count(k);
-        pc.rows.prep_inv = prep_of(k - 2);
-        pc.rows.prep_fwd = prep_of(k);
-        pc.rows.skip_inv = skip_of(k - 2);
-        pc.rows.skip_fwd = skip_of(k);
-        pc.rows.partial = c->d_partial + (size_t)(w_off + (k >= 2 ? (k - 2) * chunk : 0)) * c->nblk;
-        pc.cols.T = c->d_Ts[(k + 1) & 1];
-        pc.cols.n = count(k - 1);
-        pc.cols.prep = prep_of(k - 1);
-        pc.cols.skip = skip_of(k - 1);
-        if (!(c->pair_roles & 1)) pc.rows.n_inv = pc.rows.n_fwd = 0;
-        if (!(c->pair_roles & 2)) pc.cols.n = 0;
-        if (!(c->pair_roles & 4) == 0) pc.rows.n_inv = 0;        // bit 2: no inverse rows
-        if (!(c->pair_roles & 8) == 0) pc.rows.n_fwd = 0;        // bit 3: no forward rows
-        ProfScope ps(c, PROF_PAIR, st);
-        SizeCall a;
-        a.c = c; a.pair = &pc; a.st = st;
-        RC_TRY(size_call(SZ_PAIR, c->nx, a));
-    }
-    return PSFMC_OK;
 }
 
 // the likelihood pipeline over walkers whose prep records are in c->d_prep;
@@ -1339,7 +1223,6 @@ static int run_pipeline_paired(psfmc_ctx* c, int W, int chunk, const uint8_t* d_
 // stream semantics.
 static int run_pipeline(psfmc_ctx* c, int W, const uint8_t* d_skip, hipStream_t st, int w_off = 0) {
     const bool fused = c->backend == PSFMC_BACKEND_FUSED;
-    if (const int pchunk = paired_pass_size(c, W)) return run_pipeline_paired(c, W, pchunk, d_skip, st, w_off);
     const int chunk = pass_size(c, W);
     const int npass = (W + chunk - 1) / chunk;
     const int lanes = !fused ? 1 : (npass < c->n_streams ? npass : c->n_streams);

@@ -95,14 +95,6 @@ def test_config3_and_config4_share_at_full_batch(n_side, n_sersic, n_w):
     small = model.log_posterior_batch(theta[slots[:16]])
     assert np.array_equal(small, got[slots[:16]])
     assert np.array_equal(model.log_posterior_batch(theta[slots[-3:]]), got[slots[-3:]])
-    # the opt-in paired pipeline (one launch per pass: row waves and column waves co-resident,
-    # csrc/psfmc_pair_path.h -- an experiment that measured slower and is off by default) runs the same
-    # per-wave bodies: bit for bit the same log-posteriors, ragged last pass included
-    eng.set_option('paired', 1)
-    assert np.array_equal(model.log_posterior_batch(theta), got)
-    assert np.array_equal(model.log_posterior_batch(theta[:n_w - 5]), got[:n_w - 5])
-    eng.set_option('paired', 0)
-    assert np.array_equal(model.log_posterior_batch(theta), got)
     model.close()
 
 
