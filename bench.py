@@ -409,6 +409,45 @@ def timed_region(args, torch, dist, world, dev, step, gloo):
     return elapsed
 
 
+def fields_mcmc_rates(args, probs, merged, n_iter=60):
+    """Config 5 as a FIT (psfMC/fitting.py:56-86 for every field): stretch-move iterations per second
+    with the fields' ensembles stepped TOGETHER in the shared context (`FieldSetSampler`) and one after
+    the other in their own contexts (`DeviceEnsembleSampler` each); an iteration moves every walker of
+    every field once (two half-steps), posterior images accumulated every iteration."""
+    import synth_field
+    from psfmc_amd import FieldSetSampler, DeviceEnsembleSampler
+    p0 = [synth_field.draw_walkers(args.size, args.sersic, args.walkers, seed=300 + f, near_truth=fld['truth'])
+          for f, (_, _, fld) in enumerate(probs)]
+    out = {}
+    for accumulate in (False, True):
+        joint = FieldSetSampler(args.walkers, merged, accumulate=accumulate)
+        for f, sub in enumerate(joint.fields):
+            sub.random_state = np.random.RandomState(900 + f).get_state()
+        for _ in joint.sample(p0, iterations=4):
+            pass
+        t0 = time.perf_counter()
+        for _ in joint.sample(p0, iterations=n_iter):
+            pass
+        t_joint = time.perf_counter() - t0
+        t_own = 0.0
+        for f, (model, _, _) in enumerate(probs):
+            solo = DeviceEnsembleSampler(args.walkers, model, accumulate=accumulate)
+            solo.random_state = np.random.RandomState(900 + f).get_state()
+            for _ in solo.sample(p0[f], iterations=4):
+                pass
+            t0 = time.perf_counter()
+            for _ in solo.sample(p0[f], iterations=n_iter):
+                pass
+            t_own += time.perf_counter() - t0
+        evals = args.fields * args.walkers * n_iter
+        out['accumulating_images' if accumulate else 'sampling_only'] = {
+            'one_context_iterations_per_s': n_iter / t_joint, 'one_context_evals_per_s': evals / t_joint,
+            'own_contexts_iterations_per_s': n_iter / t_own, 'own_contexts_evals_per_s': evals / t_own}
+    out['what'] = ('%d fields x %d walkers, %d iterations after 4 of warm-up; an iteration = two half-steps of '
+                   'every field' % (args.fields, args.walkers, n_iter))
+    return out
+
+
 def many_fields(args, torch, dist, world, rank, local, dev, gloo):
     """BASELINE config 5: every rank owns --fields independent fields (own context,
     own streams, own walkers); a step evaluates all of them (raw vectors -> log-posterior).
@@ -417,8 +456,11 @@ def many_fields(args, torch, dist, world, rank, local, dev, gloo):
     merged = None
     if args.fields_merge:
         # the fields' walkers share ONE context and one batch (psfmc_ctx_create_fields)
+        # (its own model objects: a FieldSet routes its models through the shared context, and the
+        # fields' own contexts are evaluated next to it)
         from psfmc_amd import FieldSet
-        merged = FieldSet([m for m, _, _ in probs], max_walkers=args.fields * args.walkers, device=local)
+        twins = [build_problem(args, local, seed=rank * args.fields + f)[0] for f in range(args.fields)]
+        merged = FieldSet(twins, max_walkers=args.fields * args.walkers, device=local)
         all_theta = torch.from_numpy(np.concatenate([t for _, t, _ in probs])).to(dev)
         all_out = torch.empty(args.fields * args.walkers, dtype=torch.float64, device=dev)
         seg_f, seg_n = list(range(args.fields)), [args.walkers] * args.fields
@@ -456,6 +498,9 @@ def many_fields(args, torch, dist, world, rank, local, dev, gloo):
             eng.logpost_theta_device(args.walkers, t.data_ptr(), 0, o.data_ptr(), None)
         torch.cuda.synchronize(dev)
         agree = bool(torch.equal(torch.cat(outs), all_out))
+    mcmc = None
+    if rank == 0 and merged is not None and not args.no_extras:
+        mcmc = fields_mcmc_rates(args, probs, merged)
     if rank == 0:
         total = args.walkers * args.fields * args.batches * world * args.steps
         b_eval = algorithmic_bytes_per_eval(args.size)
@@ -483,7 +528,7 @@ def many_fields(args, torch, dist, world, rank, local, dev, gloo):
                          'traffic': measured * args.walkers * args.fields * args.batches if measured else None,
                          'kernel': 'evaluation pipelines of all fields (per GPU), measured PMC bytes per walker',
                          'algorithmic_equiv_GBps': b_eval * rate_gpu / 1e9, 'bytes_note': BYTES_NOTE},
-            'finite_logposts': finite}))
+            'finite_logposts': finite, 'mcmc': mcmc}))
     if merged is not None:
         merged.context.close()
     for model, _, _ in probs:

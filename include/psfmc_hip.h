@@ -179,7 +179,15 @@ int psfmc_eval_theta_device(psfmc_ctx* ctx, int W, const double* d_theta, const 
  *   psfmc_set_layout (= field 0) first, then psfmc_set_layout_field for fields 1..: own constants, priors
  *   psfmc_eval_theta[_device]_fields: segment i = seg_count[i] consecutive walkers of field seg_field[i];
  *   theta [W][n_params], lnprob [W] in segment order, W = sum of the counts <= max_walkers.
- * Image output, accumulation and the device-resident sampler serve one-field contexts only.
+ * Round 3: a context of several fields is also FITTED as one (psfMC/fitting.py:56-113 for every field at once):
+ *   psfmc_stretch_run_fields      every field's ensemble (W walkers each, own random numbers) sampled together,
+ *                                 the half-step proposals of all fields in one batch of n_fields W / 2 walkers;
+ *                                 arrays as psfmc_stretch_run's with the field as the leading dimension
+ *   psfmc_accumulate_theta_field  posterior-image sums of ONE field from raw vectors (analysis/images.py:62-74)
+ *   psfmc_get_accumulated_field   that field's five posterior images (models.py:74-97) and sample count
+ *   psfmc_eval_images_field       the five per-sample images (models.py:222-226) of walkers of one field
+ * psfmc_reset_accumulated clears every field's sums, psfmc_reset_accumulated_field one field's.  The raw-sum exchange for sharded ranks
+ * (psfmc_get/set_accumulated_sums) and the half-step API (psfmc_stretch_open ...) serve one-field contexts.
  */
 int psfmc_ctx_create_fields(psfmc_ctx** out, int device, int ny, int nx, int n_fields, const double* sci,
                             const double* obs_var, const uint8_t* bad_px, int n_psf, int psf_ny, int psf_nx,
@@ -188,6 +196,15 @@ int psfmc_set_layout_field(psfmc_ctx* ctx, int field, int n_sky, int n_params, c
                            const double* slot_const, const int* ps_method, const int* sersic_degrees,
                            double mag_zeropoint, const int* family, const double* p0, const double* p1,
                            const double* p2);
+int psfmc_stretch_run_fields(psfmc_ctx* ctx, int W, int n_iter, double* pos, double* lnprob, int lnprob_valid,
+                             const double* z, const double* lz, const int* partner, const double* log_u,
+                             double* chain, double* lnprob_chain, long long* naccepted, int accumulate);
+int psfmc_accumulate_theta_field(psfmc_ctx* ctx, int field, int W, const double* theta);
+int psfmc_reset_accumulated_field(psfmc_ctx* ctx, int field);
+int psfmc_get_accumulated_field(psfmc_ctx* ctx, int field, double* raw, double* conv, double* resid, double* ivm,
+                                double* ps_sub, long long* count);
+int psfmc_eval_images_field(psfmc_ctx* ctx, int field, int W, const double* rows, double* raw, double* conv,
+                            double* resid, double* ivm, double* ps_sub);
 int psfmc_eval_theta_fields(psfmc_ctx* ctx, int n_seg, const int* seg_field, const int* seg_count,
                             const double* theta, const double* extra_lnprior, double* lnprob);
 int psfmc_eval_theta_device_fields(psfmc_ctx* ctx, int n_seg, const int* seg_field, const int* seg_count,

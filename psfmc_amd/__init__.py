@@ -4,11 +4,12 @@ brightness modelling.  Public names mirror the reference package `psfMC`.
 """
 from .models import MultiComponentModel, FieldSet
 from .batch import BatchLogPosterior
-from .sampler import EnsembleSampler, DeviceEnsembleSampler
+from .sampler import EnsembleSampler, DeviceEnsembleSampler, FieldSetSampler
 from .parallel import RankGroup, ShardedLogPosterior
-from .fitting import model_galaxy_mcmc
+from .fitting import model_galaxy_mcmc, model_fields_mcmc
 from .database import load_database
 
 __version__ = '0.1.0'
 __all__ = ['MultiComponentModel', 'FieldSet', 'BatchLogPosterior', 'EnsembleSampler', 'DeviceEnsembleSampler',
-           'RankGroup', 'ShardedLogPosterior', 'model_galaxy_mcmc', 'load_database']
+           'FieldSetSampler', 'RankGroup', 'ShardedLogPosterior', 'model_galaxy_mcmc', 'model_fields_mcmc',
+           'load_database']

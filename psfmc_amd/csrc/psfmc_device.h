@@ -126,16 +126,18 @@ __device__ inline int clamp_psf_index(double v, int n_psf) {
     return r > (double)(n_psf - 1) ? n_psf - 1 : (int)r;
 }
 
+// psf_base: first kernel spectrum of the walker's field (contexts that hold several fields; else 0);
+// n_psf: PSFs of that field
 __device__ inline void build_prep(const double* __restrict__ row, double* __restrict__ prep,
                                   int n_ps, int n_sersic, int ny, int nx,
-                                  const double* __restrict__ rho, int n_psf) {
+                                  const double* __restrict__ rho, int n_psf, int psf_base = 0) {
     double peak = fabs(row[0]);
     const double* r = row + kRowSky;
     double* p = prep + kPrepHead;
     for (int k = 0; k < n_ps; ++k, r += kRowPs, p += kPrepPs) peak = fmax(peak, prep_ps_block(r, p, ny, nx));
     for (int k = 0; k < n_sersic; ++k, r += kRowSersic, p += kPrepSersic)
         peak = fmax(peak, prep_sersic_block(r, p));
-    prep_head(prep, row[0], clamp_psf_index(r[0], n_psf), peak, rho);
+    prep_head(prep, row[0], psf_base + clamp_psf_index(r[0], n_psf), peak, rho);
 }
 
 // ---------------------------------------------------------------------------

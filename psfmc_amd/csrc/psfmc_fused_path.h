@@ -829,10 +829,14 @@ __device__ __forceinline__ void raster_sums_all(const double* __restrict__ prep,
     }
 }
 
+// per_field > 0: the walkers are field-contiguous (per_field of them per field, the first belonging to
+// field f0) and a group never straddles two fields: the group then only looks at its own field's npf
+// kernel spectra and writes part[group][npf][3][ny][NX] (k_sum_partials_fields adds a field's groups up).
+// per_field == 0: any mixture of kernel spectra, part[group][n_psf][3][ny][NX].
 template <int NX>
 __global__ void __launch_bounds__(64) k_raster_sums(const double* __restrict__ prep, int plen, int n_w, int group_size,
                                                     int n_ps, int n_sersic, int ny, int n_psf,
-                                                    double* __restrict__ part) {
+                                                    double* __restrict__ part, int per_field, int f0, int npf) {
     using S = FftShape<NX>;
     constexpr int T = S::T, RG = S::TPW;
     static_assert(S::P % raster_seg<S::P>() == 0, "segment");
@@ -846,9 +850,11 @@ __global__ void __launch_bounds__(64) k_raster_sums(const double* __restrict__ p
     load_log_table(log_tab, lane);
     wave_lds_sync();
     const size_t Spx = (size_t)ny * NX;
-    for (int psf = 0; psf < n_psf; ++psf)
-        raster_sums_all<NX, 0>(prep, plen, w0, w1, psf, n_ps, n_sersic, t, row_on ? iy : 0, row_on, log_tab,
-                               part + ((size_t)g * n_psf + psf) * 3 * Spx, Spx);
+    const int psf0 = per_field > 0 ? (f0 + w0 / per_field) * npf : 0;      // (wave-uniform)
+    const int n_here = per_field > 0 ? npf : n_psf;
+    for (int p = 0; p < n_here; ++p)
+        raster_sums_all<NX, 0>(prep, plen, w0, w1, psf0 + p, n_ps, n_sersic, t, row_on ? iy : 0, row_on, log_tab,
+                               part + ((size_t)g * n_here + p) * 3 * Spx, Spx);
 }
 
 // lin[i] += part[0][i] + part[1][i] + ... (fixed order)
@@ -857,6 +863,18 @@ __global__ void k_sum_partials(const double* __restrict__ part, int n_groups, do
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_el; i += (size_t)gridDim.x * blockDim.x) {
         double s = 0.0;
         for (int g = 0; g < n_groups; ++g) s += part[(size_t)g * n_el + i];
+        lin[i] += s;
+    }
+}
+// field-contiguous walkers (k_raster_sums with per_field > 0): field j of the call owns the groups
+// [j gpf, (j + 1) gpf); lin is the block of the call's first field, n_el = elements of ONE field (npf 3 S)
+__global__ void k_sum_partials_fields(const double* __restrict__ part, int gpf, int n_fields_here,
+                                      double* __restrict__ lin, size_t n_el) {
+    const size_t total = n_el * n_fields_here;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t j = i / n_el, r = i - j * n_el;
+        double s = 0.0;
+        for (int g = 0; g < gpf; ++g) s += part[((size_t)j * gpf + g) * n_el + r];
         lin[i] += s;
     }
 }

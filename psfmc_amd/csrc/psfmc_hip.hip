@@ -355,9 +355,10 @@ struct psfmc_ctx {
     std::vector<void*> more_blobs;
     std::vector<char> more_has;
     size_t theta_lds = 0;
+    ThetaLayout* d_field_layouts = nullptr;  // [n_fields] device copies of the layouts (launches that span several fields)
     void* d_layout_blob = nullptr;           // one allocation behind the layout's pointers
     double *d_theta = nullptr, *d_extra = nullptr, *d_lnprior = nullptr;
-    double* d_acc = nullptr;  // [4][S] sums: raw, conv, model variance, PS-only conv
+    double* d_acc = nullptr;  // [n_fields][4][S] sums: raw, conv, model variance, PS-only conv
     // fused path: samples are first added to three LINEAR sums per PSF -- raw, raw^2, PS-only raw --
     // (k_raster_sums) and convolved into d_acc only when the images are asked for (flush_linear_sums)
     double* d_lin = nullptr;      // [n_psf][3][S]
@@ -366,7 +367,8 @@ struct psfmc_ctx {
     long long lin_pending = 0;    // samples in d_lin not yet convolved into d_acc
     bool linear_acc = true;       // set_option "linear_accumulation" 0: every sample through the full pipeline (round 1's way)
     double* d_rawstage = nullptr;   // [img_cap][S] raw-model staging for the sums
-    long long acc_count = 0;
+    long long acc_count = 0;        // samples in the sums of field 0 (the only field of an ordinary context)
+    std::vector<long long> acc_more;   // ... of fields 1.. (psfmc_ctx_create_fields)
     int cols_grid = 0;
     // device-resident sampler state (psfmc_stretch_*): grow-only buffers
     struct Stretch {
@@ -377,9 +379,13 @@ struct psfmc_ctx {
         size_t cap_pos = 0, cap_lnp = 0, cap_q = 0, cap_new = 0, cap_rand = 0, cap_chain = 0, cap_lnchain = 0,
                cap_partner = 0, cap_iter = 0, cap_nacc = 0;
         int W = 0, n_iter = 0;
+        int F = 1;                // ensembles in the run (psfmc_stretch_run_fields: one per field)
         bool store = false, open = false;
     } stretch;
 };
+
+// samples in the posterior-image sums of one field
+static long long& acc_n(psfmc_ctx* c, int field) { return field == 0 ? c->acc_count : c->acc_more[field - 1]; }
 
 // per-side constants of the row kernels
 struct RowShape { int rg, fast_waves, fast_rg_log2, regs; bool plain; };
@@ -527,10 +533,12 @@ template <int NX> static int pack_field(psfmc_ctx* c, int f) {
 }
 
 template <int NX>
-static int launch_raster_sums(psfmc_ctx* c, int n, const double* prep, int groups, int group_size, hipStream_t st) {
+static int launch_raster_sums(psfmc_ctx* c, int n, const double* prep, int groups, int group_size, hipStream_t st,
+                              int per_field, int f0) {
     constexpr int RG = FftShape<NX>::TPW;
     hipLaunchKernelGGL((k_raster_sums<NX>), dim3((c->ny + RG - 1) / RG, groups), dim3(64), 0, st, prep, c->plen, n,
-                       group_size, c->n_ps, c->n_sersic, c->ny, c->n_psf, c->d_linpart);
+                       group_size, c->n_ps, c->n_sersic, c->ny, c->n_psf, c->d_linpart, per_field, f0,
+                       c->n_psf_field);
     return PSFMC_OK;
 }
 
@@ -550,7 +558,7 @@ struct SizeCall {
     double *raw_out = nullptr, *partial = nullptr, *conv_out = nullptr, *var_out = nullptr;
     hipStream_t st = nullptr;
     bool from_image = false, convolve = true, f32 = false;
-    int field = 0, groups = 0, group_size = 0, ny = 0;
+    int field = 0, groups = 0, group_size = 0, ny = 0, per_field = 0;
     RowShape* shape = nullptr;
     size_t* len = nullptr;
 };
@@ -599,7 +607,8 @@ static int size_call_here(int op, int side, SizeCall& a) {
             }
             return PSFMC_OK;
         case SZ_RASTER_SUMS:
-            DISPATCH_LEN(side, RC_TRY((launch_raster_sums<N_>(c, a.n, a.prep, a.groups, a.group_size, a.st))));
+            DISPATCH_LEN(side, RC_TRY((launch_raster_sums<N_>(c, a.n, a.prep, a.groups, a.group_size, a.st,
+                                                              a.per_field, a.field))));
             return PSFMC_OK;
     }
     return fail(PSFMC_EINVAL, "unknown size operation %d", op);
@@ -966,6 +975,7 @@ static int ctx_create_impl(psfmc_ctx** out, int device, int ny, int nx, int n_fi
     c->device = device;
     c->ny = ny; c->nx = nx; c->nxh = nx / 2 + 1; c->S = ny * nx; c->F = ny * c->nxh;
     c->n_fields = n_fields; c->n_psf_field = n_psf;
+    c->acc_more.assign(n_fields - 1, 0);
     c->n_psf = n_fields * n_psf; c->n_ps = n_ps; c->n_sersic = n_sersic;
     c->max_walkers = max_walkers; c->backend = backend;
     c->rlen = row_len(n_ps, n_sersic);
@@ -1040,7 +1050,7 @@ extern "C" int psfmc_ctx_destroy(psfmc_ctx* c) {
     void* bufs[] = {c->d_sci,  c->d_var,  c->d_bad,     c->d_pspec, c->d_vspec, c->d_rows, c->d_prep,
                     c->d_like, c->d_skip, c->d_partial, c->d_real,  c->d_spec,  c->d_Ts[0], c->d_Kraw,
                     c->d_Kt,   c->d_twx,  c->d_twy,     c->d_img0,  c->d_img1, c->d_rho,   c->d_field, c->d_Ts[1], c->d_acc, c->d_lin, c->d_linpart,
-                    c->d_layout_blob, c->d_theta, c->d_extra, c->d_lnprior, c->d_rawstage,
+                    c->d_layout_blob, c->d_theta, c->d_extra, c->d_lnprior, c->d_rawstage, c->d_field_layouts,
                     c->d_Ts[2], c->d_Ts[3], c->stretch.pos, c->stretch.lnp, c->stretch.q, c->stretch.newlnp,
                     c->stretch.rand, c->stretch.chain, c->stretch.lnchain, c->stretch.partner, c->stretch.iter,
                     c->stretch.nacc};
@@ -1270,7 +1280,7 @@ static int run_pipeline(psfmc_ctx* c, int W, const uint8_t* d_skip, hipStream_t 
 static int eval_device(psfmc_ctx* c, int W, const double* d_rows, const uint8_t* d_skip,
                        double* d_like, hipStream_t st) {
     hipLaunchKernelGGL(k_prep, dim3((W + 127) / 128), dim3(128), 0, st, d_rows, c->d_prep, W, c->n_ps,
-                       c->n_sersic, c->ny, c->nx, c->d_rho, c->n_psf);
+                       c->n_sersic, c->ny, c->nx, c->d_rho, c->n_psf, 0);
     RC_TRY(run_pipeline(c, W, d_skip, st));
     hipLaunchKernelGGL(k_finish, dim3(finish_blocks(W)), dim3(kFinishThreads), 0, st, c->d_partial, d_skip, d_like,
                        W, c->nblk);
@@ -1282,13 +1292,18 @@ static int eval_device(psfmc_ctx* c, int W, const double* d_rows, const uint8_t*
 // records, log-priors and skip flags of W walkers
 // `field` / `w_off`: walkers [w_off, w_off + W) of the batch belong to observed field `field` (0, 0
 // for the usual one-field context): its layout, its block of kernel spectra
+// `n_seg` > 1: ONE launch for the fields `field` .. `field + n_seg - 1`, W walkers each (blockIdx.y = field):
+// the same per-walker arrays with field f's block at offset f W, every field's own layout
 static void launch_theta_prep(psfmc_ctx* c, int W, const double* d_theta, const double* d_extra,
-                              double* d_rows, hipStream_t st, const StretchIn& sp, int field = 0, int w_off = 0) {
+                              double* d_rows, hipStream_t st, const StretchIn& sp, int field = 0, int w_off = 0,
+                              int n_seg = 1) {
     const ThetaLayout& L = field == 0 ? c->layout : c->more_layouts[field - 1];
-    hipLaunchKernelGGL(k_theta_prep, dim3((W + kThetaThreads - 1) / kThetaThreads),
+    FieldSegs segs{nullptr, 0};
+    if (n_seg > 1) segs = FieldSegs{c->d_field_layouts + field, c->n_psf_field};
+    hipLaunchKernelGGL(k_theta_prep, dim3((W + kThetaThreads - 1) / kThetaThreads, n_seg),
                        dim3(kThetaThreads, theta_task_waves(c->n_ps, c->n_sersic)), c->theta_lds, st,
                        L, d_theta, d_extra, d_rows, c->d_prep + (size_t)w_off * c->plen, c->d_lnprior + w_off,
-                       c->d_skip + w_off, W, c->ny, c->nx, c->d_rho, sp, field * c->n_psf_field);
+                       c->d_skip + w_off, W, c->ny, c->nx, c->d_rho, sp, field * c->n_psf_field, segs);
 }
 
 // raw vectors -> log-posterior, everything on the device
@@ -1348,18 +1363,20 @@ static int ensure_image_staging(psfmc_ctx* c) {
     return PSFMC_OK;
 }
 
-extern "C" int psfmc_eval_images(psfmc_ctx* c, int W, const double* rows, double* raw, double* conv,
-                                 double* resid, double* ivm, double* ps_sub) {
-    if (c && c->n_fields > 1) return fail(PSFMC_EINVAL, "this entry point serves contexts of one field");
+static int eval_images_impl(psfmc_ctx* c, int field, int W, const double* rows, double* raw, double* conv,
+                            double* resid, double* ivm, double* ps_sub) {
     int rc = check_call(c, W, rows, rows);
     if (rc != PSFMC_OK || W == 0) return rc;
+    if (field < 0 || field >= c->n_fields) return fail(PSFMC_EINVAL, "field %d of %d", field, c->n_fields);
+    const double* f_sci = c->d_sci + (size_t)field * c->S;      // this field's pixels
+    const double* f_var = c->d_var + (size_t)field * c->S;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const bool fused = c->backend == PSFMC_BACKEND_FUSED;
     const size_t img = (size_t)c->S * sizeof(double);
     HIP_TRY(hipMemcpyAsync(c->d_rows, rows, (size_t)W * c->rlen * sizeof(double), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_prep, dim3((W + 127) / 128), dim3(128), 0, st, c->d_rows, c->d_prep, W, c->n_ps,
-                       c->n_sersic, c->ny, c->nx, c->d_rho, c->n_psf);
+                       c->n_sersic, c->ny, c->nx, c->d_rho, c->n_psf_field, field * c->n_psf_field);
     RC_TRY(ensure_image_staging(c));
     double* d_out = nullptr;     // [chunk][S] staging for derived images
     HIP_TRY(hipMalloc(&d_out, (size_t)c->chunk * img));
@@ -1372,7 +1389,7 @@ extern "C" int psfmc_eval_images(psfmc_ctx* c, int W, const double* rows, double
         const double* prep = c->d_prep + (size_t)w0 * c->plen;
         auto emit = [&](double* host, const double* src, int strd, int comp, int op) -> int {
             if (!host) return PSFMC_OK;
-            hipLaunchKernelGGL(k_image_out, dim3(64, n), dim3(256), 0, st, src, c->d_sci, c->d_var, d_out,
+            hipLaunchKernelGGL(k_image_out, dim3(64, n), dim3(256), 0, st, src, f_sci, f_var, d_out,
                                c->S, strd, comp, op);
             HIP_TRY(hipMemcpyAsync(host + (size_t)w0 * c->S, d_out, (size_t)n * img,
                                    hipMemcpyDeviceToHost, st));
@@ -1414,6 +1431,19 @@ extern "C" int psfmc_eval_images(psfmc_ctx* c, int W, const double* rows, double
     (void)hipFree(d_out);
     if (rc == PSFMC_OK) HIP_TRY(hipGetLastError());
     return rc;
+}
+
+extern "C" int psfmc_eval_images(psfmc_ctx* c, int W, const double* rows, double* raw, double* conv,
+                                 double* resid, double* ivm, double* ps_sub) {
+    if (c && c->n_fields > 1) return fail(PSFMC_EINVAL, "this entry point serves contexts of one field");
+    return eval_images_impl(c, 0, W, rows, raw, conv, resid, ivm, ps_sub);
+}
+
+// the five images of walkers of ONE field of a psfmc_ctx_create_fields context (rows as for
+// psfmc_eval_images; their PSF index counts within the field)
+extern "C" int psfmc_eval_images_field(psfmc_ctx* c, int field, int W, const double* rows, double* raw,
+                                       double* conv, double* resid, double* ivm, double* ps_sub) {
+    return eval_images_impl(c, field, W, rows, raw, conv, resid, ivm, ps_sub);
 }
 
 // ---------------------------------------------------------------------------
@@ -1476,6 +1506,10 @@ static int set_layout_impl(psfmc_ctx* c, int field, int n_sky, int n_params, con
     L.family = dip + ns + c->n_ps + c->n_sersic;
     L.slot_const = ddp; L.pa = ddp + ns; L.pb = ddp + ns + n_params; L.pc = ddp + ns + 2 * n_params;
     L.pk = ddp + ns + 3 * n_params;
+    if (c->n_fields > 1) {
+        if (!c->d_field_layouts) HIP_TRY(hipMalloc(&c->d_field_layouts, (size_t)c->n_fields * sizeof(ThetaLayout)));
+        HIP_TRY(hipMemcpy(c->d_field_layouts + field, &L, sizeof(ThetaLayout), hipMemcpyHostToDevice));
+    }
     if (field > 0) {
         c->more_has[field - 1] = 1;
         return PSFMC_OK;
@@ -1627,18 +1661,49 @@ extern "C" int psfmc_debug_theta_rows(psfmc_ctx* c, int W, const double* theta, 
 extern "C" int psfmc_reset_accumulated(psfmc_ctx* c) {
     if (!c) return fail(PSFMC_EINVAL, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
-    if (!c->d_acc) HIP_TRY(hipMalloc(&c->d_acc, (size_t)4 * c->S * sizeof(double)));
-    HIP_TRY(hipMemsetAsync(c->d_acc, 0, (size_t)4 * c->S * sizeof(double), c->stream));
+    const size_t acc_bytes = (size_t)c->n_fields * 4 * c->S * sizeof(double);
+    if (!c->d_acc) HIP_TRY(hipMalloc(&c->d_acc, acc_bytes));
+    HIP_TRY(hipMemsetAsync(c->d_acc, 0, acc_bytes, c->stream));
     if (c->d_lin) HIP_TRY(hipMemsetAsync(c->d_lin, 0, (size_t)c->n_psf * 3 * c->S * sizeof(double), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->acc_count = 0;
+    for (int f = 0; f < c->n_fields; ++f) acc_n(c, f) = 0;
     c->lin_pending = 0;
+    return PSFMC_OK;
+}
+
+// one field of a psfmc_ctx_create_fields context: its image sums, the linear sums of its kernel spectra
+// (pending samples of OTHER fields stay pending) and its count
+extern "C" int psfmc_reset_accumulated_field(psfmc_ctx* c, int field) {
+    if (!c) return fail(PSFMC_EINVAL, "ctx is NULL");
+    if (field < 0 || field >= c->n_fields) return fail(PSFMC_EINVAL, "field %d of %d", field, c->n_fields);
+    if (!c->d_acc) return psfmc_reset_accumulated(c);
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t S = (size_t)c->S;
+    HIP_TRY(hipMemsetAsync(c->d_acc + (size_t)field * 4 * S, 0, 4 * S * sizeof(double), c->stream));
+    if (c->d_lin)
+        HIP_TRY(hipMemsetAsync(c->d_lin + (size_t)field * c->n_psf_field * 3 * S, 0,
+                               (size_t)c->n_psf_field * 3 * S * sizeof(double), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    acc_n(c, field) = 0;
     return PSFMC_OK;
 }
 
 // buffers of the linear sums (fused back end): allocated outside any stream capture
 static int ensure_linear_sums(psfmc_ctx* c) {
     if (c->backend != PSFMC_BACKEND_FUSED || c->d_lin) return PSFMC_OK;
+    if (c->n_fields > 1) {
+        // several fields: a group's partial holds ONE field's sums; `lin_groups` = groups per field
+        const size_t field_el = (size_t)c->n_psf_field * 3 * c->S;
+        int gpf = (2048 + c->nblk * c->n_fields - 1) / (c->nblk * c->n_fields);
+        const size_t budget = (size_t)96 << 20;
+        while (gpf > 1 && (size_t)gpf * c->n_fields * field_el * sizeof(double) > budget) --gpf;
+        if (gpf < 1) gpf = 1;
+        HIP_TRY(hipMalloc(&c->d_lin, (size_t)c->n_fields * field_el * sizeof(double)));
+        HIP_TRY(hipMemset(c->d_lin, 0, (size_t)c->n_fields * field_el * sizeof(double)));
+        HIP_TRY(hipMalloc(&c->d_linpart, (size_t)gpf * c->n_fields * field_el * sizeof(double)));
+        c->lin_groups = gpf;
+        return PSFMC_OK;
+    }
     const size_t per_group = (size_t)c->n_psf * 3 * c->S * sizeof(double);
     // walker groups of one call: enough waves to fill the chip (row groups x groups >= ~2048), the
     // partials within ~96 MB
@@ -1654,8 +1719,44 @@ static int ensure_linear_sums(psfmc_ctx* c) {
     return PSFMC_OK;
 }
 
-// fused back end: add the W walkers whose prep records are in c->d_prep to the linear sums
-static int accumulate_linear(psfmc_ctx* c, int W, hipStream_t st) {
+// fused back end: add the W walkers whose prep records are in c->d_prep to the linear sums.  The sums are
+// kept per kernel spectrum, i.e. per (field, PSF): walkers of several fields (`nf` consecutive fields from
+// `f0`, `per` walkers each, W = nf * per) land in their own fields' sums by themselves.
+static int accumulate_linear(psfmc_ctx* c, int W, hipStream_t st, int f0 = 0, int nf = 1, int per = -1) {
+    if (per < 0) per = W;
+    if (c->n_fields > 1) {
+        // field-contiguous walkers: whole groups per field, each looking only at its field's kernel spectra
+        // (with every group scanning all n_fields x PSFs for its walkers, eight fields accumulated at half the
+        // rate of eight contexts)
+        if ((long long)nf * per != W) return fail(PSFMC_EINVAL, "accumulation: %d fields x %d walkers != %d", nf, per, W);
+        int gpf = c->lin_groups < per ? c->lin_groups : per;           // groups per field
+        const int group_size = (per + gpf - 1) / gpf;
+        gpf = (per + group_size - 1) / group_size;
+        if (per % group_size) {
+            // a field's last group is short: the next field's groups must still start at its first walker, which
+            // g * group_size does not give -- one launch per field then
+            for (int j = 0; j < nf; ++j) {
+                SizeCall a;
+                a.c = c; a.n = per; a.prep = c->d_prep + (size_t)j * per * c->plen; a.groups = gpf;
+                a.group_size = group_size; a.st = st; a.per_field = per; a.field = f0 + j;
+                RC_TRY(size_call(SZ_RASTER_SUMS, c->nx, a));
+                const size_t n_el = (size_t)c->n_psf_field * 3 * c->S;
+                hipLaunchKernelGGL(k_sum_partials_fields, dim3(512), dim3(256), 0, st, c->d_linpart, gpf, 1,
+                                   c->d_lin + (size_t)(f0 + j) * n_el, n_el);
+            }
+        } else {
+            SizeCall a;
+            a.c = c; a.n = W; a.prep = c->d_prep; a.groups = gpf * nf; a.group_size = group_size; a.st = st;
+            a.per_field = per; a.field = f0;
+            RC_TRY(size_call(SZ_RASTER_SUMS, c->nx, a));
+            const size_t n_el = (size_t)c->n_psf_field * 3 * c->S;
+            hipLaunchKernelGGL(k_sum_partials_fields, dim3(512), dim3(256), 0, st, c->d_linpart, gpf, nf,
+                               c->d_lin + (size_t)f0 * n_el, n_el);
+        }
+        c->lin_pending += W;
+        for (int i = 0; i < nf; ++i) acc_n(c, f0 + i) += per;
+        return PSFMC_OK;
+    }
     const size_t n_el = (size_t)c->n_psf * 3 * c->S;
     int groups = c->lin_groups < W ? c->lin_groups : W;
     const int group_size = (W + groups - 1) / groups;
@@ -1667,7 +1768,7 @@ static int accumulate_linear(psfmc_ctx* c, int W, hipStream_t st) {
     }
     hipLaunchKernelGGL(k_sum_partials, dim3(512), dim3(256), 0, st, c->d_linpart, groups, c->d_lin, n_el);
     c->lin_pending += W;
-    c->acc_count += W;
+    acc_n(c, f0) += W;
     return PSFMC_OK;
 }
 
@@ -1691,8 +1792,10 @@ static int flush_linear_sums(psfmc_ctx* c) {
         hipMalloc(&d_fprep, (size_t)c->plen * sizeof(double)) != hipSuccess ||
         hipMalloc(&d_out, 2 * S * sizeof(double)) != hipSuccess)
         rc = fail(PSFMC_ENOMEM, "hipMalloc (posterior-image flush)");
+    int field_of_p = 0;       // the field whose sums the current kernel spectrum's images go to
     auto acc = [&](const double* src, int slot) {
-        hipLaunchKernelGGL(k_accumulate, dim3(256), dim3(256), 0, st, src, c->d_acc + (size_t)slot * S, (int)S, 1, 1, 0);
+        hipLaunchKernelGGL(k_accumulate, dim3(256), dim3(256), 0, st, src,
+                           c->d_acc + ((size_t)field_of_p * 4 + slot) * S, (int)S, 1, 1, 0);
     };
     // one pseudo-walker: z = img0 + i scale img1 through rows_fwd (from memory), cols, rows_inv;
     // d_out[0] = convolution of img0 with the PSF, d_out[1] = of img1 with the PSF variance map
@@ -1719,6 +1822,7 @@ static int flush_linear_sums(psfmc_ctx* c) {
         return PSFMC_OK;
     };
     for (int p = 0; p < c->n_psf && rc == PSFMC_OK; ++p) {
+        field_of_p = p / c->n_psf_field;
         const double* lin = c->d_lin + (size_t)p * 3 * S;
         // the variance channel's power-of-two scale, and whether any sample used this PSF
         if (hipMemcpy(host.data(), lin + S, S * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
@@ -1765,12 +1869,13 @@ static int flush_linear_sums(psfmc_ctx* c) {
 }
 
 // add the images of the W walkers whose prep records are in c->d_prep to the sums
-static int accumulate_from_prep(psfmc_ctx* c, int W, hipStream_t st) {
+static int accumulate_from_prep(psfmc_ctx* c, int W, hipStream_t st, int f0 = 0, int nf = 1, int per = -1) {
     const bool fused = c->backend == PSFMC_BACKEND_FUSED;
     if (fused && c->linear_acc) {
         if (!c->d_lin) return fail(PSFMC_EINVAL, "linear sums not allocated");
-        return accumulate_linear(c, W, st);
+        return accumulate_linear(c, W, st, f0, nf, per);
     }
+    if (c->n_fields > 1) return fail(PSFMC_EINVAL, "contexts of several fields accumulate images as linear sums only");
     RC_TRY(ensure_image_staging(c));
     if (fused && !c->d_rawstage) HIP_TRY(hipMalloc(&c->d_rawstage, (size_t)c->img_cap * c->S * sizeof(double)));
     const double* conv_src = fused ? c->d_img0 : c->d_real;
@@ -1818,7 +1923,7 @@ extern "C" int psfmc_accumulate_images(psfmc_ctx* c, int W, const double* rows) 
     hipStream_t st = c->stream;
     HIP_TRY(hipMemcpyAsync(c->d_rows, rows, (size_t)W * c->rlen * sizeof(double), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_prep, dim3((W + 127) / 128), dim3(128), 0, st, c->d_rows, c->d_prep, W, c->n_ps,
-                       c->n_sersic, c->ny, c->nx, c->d_rho, c->n_psf);
+                       c->n_sersic, c->ny, c->nx, c->d_rho, c->n_psf, 0);
     rc = accumulate_from_prep(c, W, st);
     (void)hipStreamSynchronize(st);
     if (rc == PSFMC_OK) HIP_TRY(hipGetLastError());
@@ -1828,10 +1933,12 @@ extern "C" int psfmc_accumulate_images(psfmc_ctx* c, int W, const double* rows) 
 // raw parameter vectors (host) -> posterior-image sums: the records are derived on the device like
 // psfmc_eval_theta does (no host-side gammaincinv per sample when the images of a whole database
 // are recomputed, analysis/images.py:62-74)
-extern "C" int psfmc_accumulate_theta(psfmc_ctx* c, int W, const double* theta) {
-    if (c && c->n_fields > 1) return fail(PSFMC_EINVAL, "this entry point serves contexts of one field");
+static int accumulate_theta_impl(psfmc_ctx* c, int field, int W, const double* theta) {
     int rc = check_theta_call(c, W, theta, theta ? (const void*)theta : (const void*)c);
     if (rc != PSFMC_OK || W == 0) return rc;
+    if (field < 0 || field >= c->n_fields) return fail(PSFMC_EINVAL, "field %d of %d", field, c->n_fields);
+    if (field > 0 && ((size_t)field > c->more_has.size() || !c->more_has[field - 1]))
+        return fail(PSFMC_EINVAL, "field %d has no layout (psfmc_set_layout_field)", field);
     HIP_TRY(hipSetDevice(c->device));
     if (!c->d_acc) RC_TRY(psfmc_reset_accumulated(c));
     RC_TRY(ensure_linear_sums(c));
@@ -1839,11 +1946,21 @@ extern "C" int psfmc_accumulate_theta(psfmc_ctx* c, int W, const double* theta) 
     if (c->layout.n_params)
         HIP_TRY(hipMemcpyAsync(c->d_theta, theta, (size_t)W * c->layout.n_params * sizeof(double),
                                hipMemcpyHostToDevice, st));
-    launch_theta_prep(c, W, c->d_theta, nullptr, nullptr, st, StretchIn{});
-    rc = accumulate_from_prep(c, W, st);
+    launch_theta_prep(c, W, c->d_theta, nullptr, nullptr, st, StretchIn{}, field, 0);
+    rc = accumulate_from_prep(c, W, st, field, 1, W);
     (void)hipStreamSynchronize(st);
     if (rc == PSFMC_OK) HIP_TRY(hipGetLastError());
     return rc;
+}
+
+extern "C" int psfmc_accumulate_theta(psfmc_ctx* c, int W, const double* theta) {
+    if (c && c->n_fields > 1) return fail(PSFMC_EINVAL, "this entry point serves contexts of one field");
+    return accumulate_theta_impl(c, 0, W, theta);
+}
+
+// the same for one field of a psfmc_ctx_create_fields context
+extern "C" int psfmc_accumulate_theta_field(psfmc_ctx* c, int field, int W, const double* theta) {
+    return accumulate_theta_impl(c, field, W, theta);
 }
 
 // ---------------------------------------------------------------------------
@@ -1860,52 +1977,64 @@ static int grow(Tp** p, size_t* cap, size_t need) {
     return PSFMC_OK;
 }
 
-static int stretch_check(psfmc_ctx* c, int W) {
+// F: ensembles of the run -- 1 (an ordinary context), or every field of a psfmc_ctx_create_fields context
+static int stretch_check(psfmc_ctx* c, int W, int F = 1) {
     if (!c) return fail(PSFMC_EINVAL, "ctx is NULL");
-    if (c && c->n_fields > 1) return fail(PSFMC_EINVAL, "this entry point serves contexts of one field");
+    if (F != c->n_fields)
+        return fail(PSFMC_EINVAL, F == 1 ? "this entry point serves contexts of one field"
+                                         : "psfmc_stretch_run_fields samples every field of the context");
     if (!c->has_layout) return fail(PSFMC_EINVAL, "psfmc_set_layout has not been called");
-    if (W < 2 || (W & 1) || W > c->max_walkers) return fail(PSFMC_EINVAL, "W must be even, 2..max_walkers");
+    if (W < 2 || (W & 1) || (long long)W * F > c->max_walkers)
+        return fail(PSFMC_EINVAL, "W must be even and fields x W within max_walkers");
     const int P = c->layout.n_params;
     if (P < 1) return fail(PSFMC_EINVAL, "model has no free parameter");
     // every prior must be evaluated on the device
     std::vector<int> fam(P);
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemcpy(fam.data(), c->layout.family, P * sizeof(int), hipMemcpyDeviceToHost));
-    for (int f : fam)
-        if (f == PRIOR_HOST) return fail(PSFMC_EINVAL, "a prior is evaluated on the host; use the host sampler");
+    for (int f = 0; f < F; ++f) {
+        if (f > 0 && ((size_t)f > c->more_has.size() || !c->more_has[f - 1]))
+            return fail(PSFMC_EINVAL, "field %d has no layout (psfmc_set_layout_field)", f);
+        const ThetaLayout& L = f == 0 ? c->layout : c->more_layouts[f - 1];
+        HIP_TRY(hipMemcpy(fam.data(), L.family, P * sizeof(int), hipMemcpyDeviceToHost));
+        for (int v : fam)
+            if (v == PRIOR_HOST) return fail(PSFMC_EINVAL, "a prior is evaluated on the host; use the host sampler");
+    }
     return PSFMC_OK;
 }
 
-// upload the walkers, counters and the block's random numbers; size the chain buffers
+// upload the walkers, counters and the block's random numbers; size the chain buffers.  F ensembles of W
+// walkers each: host arrays carry the ensemble as their leading dimension (pos [F][W][P], z [F][n_iter][2][half],
+// ...); on the device the three random arrays are [3][F][n_iter W].
 static int stretch_upload(psfmc_ctx* c, int W, int n_iter, const double* pos, const double* lnprob,
                           int lnprob_valid, const double* z, const double* lz, const int* partner,
-                          const double* log_u, const long long* naccepted, bool store, hipStream_t st) {
+                          const double* log_u, const long long* naccepted, bool store, hipStream_t st, int F = 1) {
     psfmc_ctx::Stretch& S = c->stretch;
     const int P = c->layout.n_params, half = W / 2;
-    const size_t n_rand = (size_t)n_iter * W;
-    RC_TRY(grow(&S.pos, &S.cap_pos, (size_t)W * P));
-    RC_TRY(grow(&S.lnp, &S.cap_lnp, (size_t)W));
-    RC_TRY(grow(&S.q, &S.cap_q, (size_t)half * P));
-    RC_TRY(grow(&S.newlnp, &S.cap_new, (size_t)half));
-    RC_TRY(grow(&S.nacc, &S.cap_nacc, (size_t)W));
+    const size_t n_rand = (size_t)n_iter * W * F;             // per random array, all ensembles
+    const size_t WF = (size_t)W * F;
+    RC_TRY(grow(&S.pos, &S.cap_pos, WF * P));
+    RC_TRY(grow(&S.lnp, &S.cap_lnp, WF));
+    RC_TRY(grow(&S.q, &S.cap_q, (size_t)half * F * P));
+    RC_TRY(grow(&S.newlnp, &S.cap_new, (size_t)half * F));
+    RC_TRY(grow(&S.nacc, &S.cap_nacc, WF));
     RC_TRY(grow(&S.rand, &S.cap_rand, 3 * n_rand));
     RC_TRY(grow(&S.partner, &S.cap_partner, n_rand));
     RC_TRY(grow(&S.iter, &S.cap_iter, (size_t)1));
     if (store && n_iter) {
-        RC_TRY(grow(&S.chain, &S.cap_chain, (size_t)W * n_iter * P));
-        RC_TRY(grow(&S.lnchain, &S.cap_lnchain, (size_t)W * n_iter));
+        RC_TRY(grow(&S.chain, &S.cap_chain, WF * n_iter * P));
+        RC_TRY(grow(&S.lnchain, &S.cap_lnchain, WF * n_iter));
     }
-    S.W = W; S.n_iter = n_iter; S.store = store && n_iter; S.open = true;
+    S.W = W; S.n_iter = n_iter; S.F = F; S.store = store && n_iter; S.open = true;
     if (n_rand) {
         HIP_TRY(hipMemcpyAsync(S.rand, z, n_rand * sizeof(double), hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(S.rand + n_rand, lz, n_rand * sizeof(double), hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(S.rand + 2 * n_rand, log_u, n_rand * sizeof(double), hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(S.partner, partner, n_rand * sizeof(int), hipMemcpyHostToDevice, st));
     }
-    HIP_TRY(hipMemcpyAsync(S.pos, pos, (size_t)W * P * sizeof(double), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(S.nacc, naccepted, (size_t)W * sizeof(long long), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(S.pos, pos, WF * P * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(S.nacc, naccepted, WF * sizeof(long long), hipMemcpyHostToDevice, st));
     if (lnprob_valid)
-        HIP_TRY(hipMemcpyAsync(S.lnp, lnprob, (size_t)W * sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(S.lnp, lnprob, WF * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(S.iter, 0, sizeof(int), st));
     return PSFMC_OK;
 }
@@ -1913,14 +2042,15 @@ static int stretch_upload(psfmc_ctx* c, int W, int n_iter, const double* pos, co
 static int stretch_download(psfmc_ctx* c, double* pos, double* lnprob, double* chain, double* lnprob_chain,
                             long long* naccepted, hipStream_t st) {
     psfmc_ctx::Stretch& S = c->stretch;
-    const int P = c->layout.n_params, W = S.W;
-    HIP_TRY(hipMemcpyAsync(pos, S.pos, (size_t)W * P * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(lnprob, S.lnp, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(naccepted, S.nacc, (size_t)W * sizeof(long long), hipMemcpyDeviceToHost, st));
+    const int P = c->layout.n_params;
+    const size_t W = (size_t)S.W * S.F;
+    HIP_TRY(hipMemcpyAsync(pos, S.pos, W * P * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(lnprob, S.lnp, W * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(naccepted, S.nacc, W * sizeof(long long), hipMemcpyDeviceToHost, st));
     if (S.store && chain) {
-        HIP_TRY(hipMemcpyAsync(chain, S.chain, (size_t)W * S.n_iter * P * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(chain, S.chain, W * S.n_iter * P * sizeof(double), hipMemcpyDeviceToHost, st));
         if (lnprob_chain)
-            HIP_TRY(hipMemcpyAsync(lnprob_chain, S.lnchain, (size_t)W * S.n_iter * sizeof(double),
+            HIP_TRY(hipMemcpyAsync(lnprob_chain, S.lnchain, W * S.n_iter * sizeof(double),
                                    hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipStreamSynchronize(st));
@@ -1931,19 +2061,24 @@ static int stretch_download(psfmc_ctx* c, double* pos, double* lnprob, double* c
 // priors and prep records (every walker of the half: the accept step needs every proposal)
 static void stretch_propose(psfmc_ctx* c, int it, int h, bool graph_iter, hipStream_t st) {
     psfmc_ctx::Stretch& S = c->stretch;
-    launch_theta_prep(c, S.W / 2, nullptr, nullptr, nullptr, st,
-                      StretchIn{S.pos, S.q, S.rand, S.partner, graph_iter ? S.iter : nullptr, it, S.W / 2, h});
+    const int half = S.W / 2, P = c->layout.n_params;
+    const size_t per_field = (size_t)S.n_iter * S.W;          // random numbers of one ensemble
+    launch_theta_prep(c, half, nullptr, nullptr, nullptr, st,
+                      StretchIn{S.pos, S.q, S.rand, S.partner, graph_iter ? S.iter : nullptr, it, half, h,
+                                (size_t)S.W * P, (size_t)half * P, per_field},
+                      0, 0, S.F);
 }
 
 // last stage: sum (or take the gathered values), accept, move, chain entry
 static void stretch_accept(psfmc_ctx* c, int it, int h, const double* d_newlnp, bool graph_iter, hipStream_t st) {
     psfmc_ctx::Stretch& S = c->stretch;
     const int half = S.W / 2;
-    const size_t n_rand = (size_t)S.n_iter * S.W;
-    hipLaunchKernelGGL(k_stretch_finish, dim3(finish_blocks(half)), dim3(kFinishThreads), 0, st, c->d_partial,
+    const size_t per_field = (size_t)S.n_iter * S.W;
+    const size_t n_rand = per_field * S.F;
+    hipLaunchKernelGGL(k_stretch_finish, dim3(finish_blocks(half), S.F), dim3(kFinishThreads), 0, st, c->d_partial,
                        c->d_skip, c->d_lnprior, c->nblk, d_newlnp, S.pos, S.lnp, S.q, S.rand + n_rand,
                        S.rand + 2 * n_rand, S.nacc, S.store ? S.chain : nullptr, S.store ? S.lnchain : nullptr,
-                       graph_iter ? S.iter : nullptr, it, S.n_iter, half, h, c->layout.n_params);
+                       graph_iter ? S.iter : nullptr, it, S.n_iter, half, h, c->layout.n_params, per_field);
 }
 
 static int stretch_prepare_accumulation(psfmc_ctx* c) {
@@ -1955,36 +2090,49 @@ static int stretch_prepare_accumulation(psfmc_ctx* c) {
     return PSFMC_OK;
 }
 
-extern "C" int psfmc_stretch_run(psfmc_ctx* c, int W, int n_iter, double* pos, double* lnprob,
-                                 int lnprob_valid, const double* z, const double* lz, const int* partner,
-                                 const double* log_u, double* chain, double* lnprob_chain,
-                                 long long* naccepted, int accumulate) {
-    RC_TRY(stretch_check(c, W));
+// log-posteriors of the F ensembles' current positions (S.pos -> S.lnp): one record derivation per field,
+// one pass of the likelihood pipeline over all F W walkers
+static int stretch_eval_positions(psfmc_ctx* c, hipStream_t st) {
+    psfmc_ctx::Stretch& S = c->stretch;
+    if (S.F == 1) return eval_theta_device(c, S.W, S.pos, nullptr, S.lnp, st);
+    launch_theta_prep(c, S.W, S.pos, nullptr, nullptr, st, StretchIn{}, 0, 0, S.F);
+    RC_TRY(run_pipeline(c, S.W * S.F, c->d_skip, st));
+    hipLaunchKernelGGL(k_finish_posterior, dim3(finish_blocks(S.W * S.F)), dim3(kFinishThreads), 0, st, c->d_partial,
+                       c->d_skip, c->d_lnprior, S.lnp, S.W * S.F, c->nblk);
+    HIP_TRY(hipGetLastError());
+    return PSFMC_OK;
+}
+
+static int stretch_run_impl(psfmc_ctx* c, int F, int W, int n_iter, double* pos, double* lnprob,
+                            int lnprob_valid, const double* z, const double* lz, const int* partner,
+                            const double* log_u, double* chain, double* lnprob_chain,
+                            long long* naccepted, int accumulate) {
+    RC_TRY(stretch_check(c, W, F));
     if (n_iter < 0 || !pos || !lnprob || !naccepted || (n_iter && (!z || !lz || !partner || !log_u)))
         return fail(PSFMC_EINVAL, "NULL buffer");
     const int half = W / 2;
     hipStream_t st = c->stream;
     psfmc_ctx::Stretch& S = c->stretch;
     RC_TRY(stretch_upload(c, W, n_iter, pos, lnprob, lnprob_valid, z, lz, partner, log_u, naccepted,
-                          chain != nullptr, st));
-    if (!lnprob_valid) RC_TRY(eval_theta_device(c, W, S.pos, nullptr, S.lnp, st));
+                          chain != nullptr, st, F));
+    if (!lnprob_valid) RC_TRY(stretch_eval_positions(c, st));
     if (accumulate) RC_TRY(stretch_prepare_accumulation(c));
     // one iteration: two half-ensemble proposals (chain entries included), optional image
     // sums.  A half-step is three stages: proposals + priors + prep records (one kernel), the
     // likelihood pipeline, and sum + accept + move + chain entry (one kernel).  The kernels take
     // the iteration number by value, or from *S.iter when one captured iteration is replayed as
     // a hipGraph.
-    const bool use_d_iter = n_iter > 2 && c->use_graph && !c->profile && c->backend == PSFMC_BACKEND_FUSED;
+    const bool use_d_iter = n_iter > 2 && c->use_graph && !c->profile && c->backend == PSFMC_BACKEND_FUSED && F == 1;
     int it_host = 0;
     auto iteration = [&]() -> int {
         for (int h = 0; h < 2; ++h) {
             stretch_propose(c, it_host, h, use_d_iter, st);
-            RC_TRY(run_pipeline(c, half, c->d_skip, st));
+            RC_TRY(run_pipeline(c, half * F, c->d_skip, st));
             stretch_accept(c, it_host, h, nullptr, use_d_iter, st);
         }
         if (accumulate) {
-            launch_theta_prep(c, W, S.pos, nullptr, nullptr, st, StretchIn{});
-            RC_TRY(accumulate_from_prep(c, W, st));
+            launch_theta_prep(c, W, S.pos, nullptr, nullptr, st, StretchIn{}, 0, 0, F);
+            RC_TRY(accumulate_from_prep(c, W * F, st, 0, F, W));
         }
         if (use_d_iter) hipLaunchKernelGGL(k_stretch_next, dim3(1), dim3(1), 0, st, S.iter);
         ++it_host;
@@ -1998,7 +2146,7 @@ extern "C" int psfmc_stretch_run(psfmc_ctx* c, int W, int n_iter, double* pos, d
         hipGraph_t graph = nullptr;
         // un-captured warm-up of the pipeline: one-time attribute calls must not fall
         // inside the capture
-        rc = eval_theta_device(c, half, S.pos, nullptr, S.newlnp, st);
+        rc = eval_theta_device(c, half, S.pos, nullptr, S.newlnp, st);      // (F == 1 here)
         const long long count_before = c->acc_count, pending_before = c->lin_pending;
         if (rc == PSFMC_OK && hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
             const int crc = iteration();
@@ -2036,6 +2184,30 @@ extern "C" int psfmc_stretch_run(psfmc_ctx* c, int W, int n_iter, double* pos, d
     if (rc == PSFMC_OK && hipGetLastError() != hipSuccess) rc = fail(PSFMC_EHIP, "kernel launch failed");
     S.open = false;
     return rc;
+}
+
+extern "C" int psfmc_stretch_run(psfmc_ctx* c, int W, int n_iter, double* pos, double* lnprob,
+                                 int lnprob_valid, const double* z, const double* lz, const int* partner,
+                                 const double* log_u, double* chain, double* lnprob_chain,
+                                 long long* naccepted, int accumulate) {
+    return stretch_run_impl(c, 1, W, n_iter, pos, lnprob, lnprob_valid, z, lz, partner, log_u, chain, lnprob_chain,
+                            naccepted, accumulate);
+}
+
+// Every field of a psfmc_ctx_create_fields context sampled together: n_fields independent ensembles of W
+// walkers, each with its own random numbers, their half-step proposals evaluated in ONE batch of
+// n_fields W / 2 walkers.  All arrays carry the field as their leading dimension: pos [F][W][P],
+// lnprob [F][W], z / lz / log_u / partner [F][n_iter][2][W/2], chain [F][W][n_iter][P],
+// lnprob_chain [F][W][n_iter], naccepted [F][W].  A field's chain equals the chain of its own
+// one-field context given the same start and random numbers, bit for bit (per-walker results do not
+// depend on the batch).
+extern "C" int psfmc_stretch_run_fields(psfmc_ctx* c, int W, int n_iter, double* pos, double* lnprob,
+                                        int lnprob_valid, const double* z, const double* lz, const int* partner,
+                                        const double* log_u, double* chain, double* lnprob_chain,
+                                        long long* naccepted, int accumulate) {
+    if (!c) return fail(PSFMC_EINVAL, "ctx is NULL");
+    return stretch_run_impl(c, c->n_fields, W, n_iter, pos, lnprob, lnprob_valid, z, lz, partner, log_u, chain,
+                            lnprob_chain, naccepted, accumulate);
 }
 
 // ---------------------------------------------------------------------------
@@ -2125,6 +2297,7 @@ extern "C" int psfmc_stretch_close(psfmc_ctx* c, double* pos, double* lnprob, do
 // convolved) and their sample count, for adding up the ranks' shares
 extern "C" int psfmc_get_accumulated_sums(psfmc_ctx* c, double* sums, long long* count) {
     if (!c || !sums || !count) return fail(PSFMC_EINVAL, "NULL argument");
+    if (c->n_fields > 1) return fail(PSFMC_EINVAL, "this entry point serves contexts of one field");
     HIP_TRY(hipSetDevice(c->device));
     RC_TRY(flush_linear_sums(c));
     *count = c->acc_count;
@@ -2136,6 +2309,7 @@ extern "C" int psfmc_get_accumulated_sums(psfmc_ctx* c, double* sums, long long*
 
 extern "C" int psfmc_set_accumulated_sums(psfmc_ctx* c, const double* sums, long long count) {
     if (!c || !sums || count < 0) return fail(PSFMC_EINVAL, "bad argument");
+    if (c->n_fields > 1) return fail(PSFMC_EINVAL, "this entry point serves contexts of one field");
     HIP_TRY(hipSetDevice(c->device));
     if (!c->d_acc) RC_TRY(psfmc_reset_accumulated(c));
     if (c->d_lin) HIP_TRY(hipMemset(c->d_lin, 0, (size_t)c->n_psf * 3 * c->S * sizeof(double)));
@@ -2145,23 +2319,27 @@ extern "C" int psfmc_set_accumulated_sums(psfmc_ctx* c, const double* sums, long
     return PSFMC_OK;
 }
 
-extern "C" int psfmc_get_accumulated(psfmc_ctx* c, double* raw, double* conv, double* resid, double* ivm,
-                                     double* ps_sub, long long* count) {
+static int get_accumulated_impl(psfmc_ctx* c, int field, double* raw, double* conv, double* resid, double* ivm,
+                                double* ps_sub, long long* count) {
     if (!c) return fail(PSFMC_EINVAL, "ctx is NULL");
-    if (count) *count = c->acc_count;
-    if (c->acc_count == 0 || !c->d_acc) return PSFMC_OK;
+    if (field < 0 || field >= c->n_fields) return fail(PSFMC_EINVAL, "field %d of %d", field, c->n_fields);
+    const long long n = acc_n(c, field);
+    if (count) *count = n;
+    if (n == 0 || !c->d_acc) return PSFMC_OK;
     HIP_TRY(hipSetDevice(c->device));
     RC_TRY(flush_linear_sums(c));
     double* d_out = nullptr;
     HIP_TRY(hipMalloc(&d_out, (size_t)c->S * sizeof(double)));
-    const double inv_n = 1.0 / (double)c->acc_count;
+    const double inv_n = 1.0 / (double)n;
+    const size_t px = (size_t)field * c->S;                 // this field's pixels in d_sci / d_var
     struct { double* host; int slot, op; } outs[] = {{raw, 0, 0}, {conv, 1, 0}, {resid, 1, 1},
                                                      {ivm, 2, 2}, {ps_sub, 3, 1}};
     int rc = PSFMC_OK;
     for (auto& o : outs) {
         if (!o.host) continue;
         hipLaunchKernelGGL(k_accumulated_out, dim3(256), dim3(256), 0, c->stream,
-                           c->d_acc + (size_t)o.slot * c->S, c->d_sci, c->d_var, d_out, c->S, inv_n, o.op);
+                           c->d_acc + ((size_t)field * 4 + o.slot) * c->S, c->d_sci + px, c->d_var + px, d_out, c->S,
+                           inv_n, o.op);
         if (hipMemcpyAsync(o.host, d_out, (size_t)c->S * sizeof(double), hipMemcpyDeviceToHost, c->stream) !=
                 hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
             rc = fail(PSFMC_EHIP, "accumulated image copy failed");
@@ -2170,6 +2348,17 @@ extern "C" int psfmc_get_accumulated(psfmc_ctx* c, double* raw, double* conv, do
     }
     (void)hipFree(d_out);
     return rc;
+}
+
+extern "C" int psfmc_get_accumulated(psfmc_ctx* c, double* raw, double* conv, double* resid, double* ivm,
+                                     double* ps_sub, long long* count) {
+    return get_accumulated_impl(c, 0, raw, conv, resid, ivm, ps_sub, count);
+}
+
+// the posterior images of one field of a psfmc_ctx_create_fields context
+extern "C" int psfmc_get_accumulated_field(psfmc_ctx* c, int field, double* raw, double* conv, double* resid,
+                                           double* ivm, double* ps_sub, long long* count) {
+    return get_accumulated_impl(c, field, raw, conv, resid, ivm, ps_sub, count);
 }
 
 extern "C" int psfmc_get_spectra(psfmc_ctx* c, double* psf_spec, double* var_spec) {

@@ -10,11 +10,12 @@ namespace psfmc {
 
 // rows [W][row_len] -> prep [W][prep_len]
 __global__ void k_prep(const double* __restrict__ rows, double* __restrict__ prep, int W,
-                       int n_ps, int n_sersic, int ny, int nx, const double* __restrict__ rho, int n_psf) {
+                       int n_ps, int n_sersic, int ny, int nx, const double* __restrict__ rho, int n_psf,
+                       int psf_base) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= W) return;
     build_prep(rows + (size_t)w * row_len(n_ps, n_sersic),
-               prep + (size_t)w * prep_len(n_ps, n_sersic), n_ps, n_sersic, ny, nx, rho, n_psf);
+               prep + (size_t)w * prep_len(n_ps, n_sersic), n_ps, n_sersic, ny, nx, rho, n_psf, psf_base);
 }
 
 // raw model and its square: real[(2w)][S] = raw, real[(2w+1)][S] = raw^2

@@ -237,6 +237,17 @@ struct StretchIn {
     const int* partner;     // [n_iter][2][half]
     const int* d_iter;
     int it, half, h;
+    // Several fields in one launch (contexts of psfmc_ctx_create_fields; blockIdx.y = field): every
+    // field is its own ensemble of 2 half walkers with its own random numbers.  Element strides
+    // between consecutive fields of pos / q / z (and partner); 0 in a one-field launch.
+    size_t pos_stride, q_stride, rand_stride;
+};
+
+// the fields of one k_theta_prep launch (gridDim.y > 1): field f takes layouts[f], walkers
+// [f W, (f + 1) W) of every per-walker array, kernel spectra from f * psf_stride on
+struct FieldSegs {
+    const ThetaLayout* layouts;   // device array [gridDim.y], or nullptr: one field, the layout passed by value
+    int psf_stride;
 };
 
 __device__ inline double stretch_point(double s, double c, double z) {
@@ -271,8 +282,26 @@ k_theta_prep(ThetaLayout G, const double* __restrict__ theta,
              const double* __restrict__ extra, double* __restrict__ rows,
              double* __restrict__ prep, double* __restrict__ lnprior,
              uint8_t* __restrict__ skip, int W, int ny, int nx,
-             const double* __restrict__ rho, StretchIn sp, int psf_base) {
+             const double* __restrict__ rho, StretchIn sp, int psf_base, FieldSegs segs) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
+    if (segs.layouts) {                                 // (wave-uniform) this workgroup's field
+        const int f = blockIdx.y;
+        G = segs.layouts[f];
+        const size_t first = (size_t)f * W;             // its first walker in the per-walker arrays
+        if (theta) theta += first * G.n_params;
+        if (extra) extra += first;
+        if (rows) rows += first * row_len(G.n_ps, G.n_sersic);
+        prep += first * prep_len(G.n_ps, G.n_sersic);
+        lnprior += first;
+        skip += first;
+        psf_base += f * segs.psf_stride;
+        if (sp.pos) {
+            sp.pos += (size_t)f * sp.pos_stride;
+            sp.q += (size_t)f * sp.q_stride;
+            sp.z += (size_t)f * sp.rand_stride;
+            sp.partner += (size_t)f * sp.rand_stride;
+        }
+    }
     const int ns = n_slots(G.n_sky, G.n_ps, G.n_sersic);
     const int n_int = ((ns + G.n_ps + G.n_sersic + G.n_params + 1) / 2) * 2;
     const int n_dbl = ns + 4 * G.n_params;
@@ -450,11 +479,28 @@ __global__ void k_stretch_finish(const double* __restrict__ partial, const uint8
                                  const double* __restrict__ log_u, long long* __restrict__ nacc,
                                  double* __restrict__ chain, double* __restrict__ lnchain,
                                  const int* __restrict__ d_iter, int it_val, int n_iter, int half, int h,
-                                 int P) {
+                                 int P, size_t rand_stride) {
 #pragma clang fp contract(off)
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * (kFinishThreads / 64) + (threadIdx.x >> 6);
     if (w >= half) return;                                   // wave-uniform
+    if (gridDim.y > 1) {                                     // several fields (psfmc_stretch_run_fields): blockIdx.y's ensemble
+        const size_t f = blockIdx.y;
+        partial += f * half * nblk;
+        skip += f * half;
+        lnprior += f * half;
+        if (newlnp_in) newlnp_in += f * half;
+        pos += f * 2 * half * P;
+        lnprob += f * 2 * half;
+        q += f * half * P;
+        lz += f * rand_stride;
+        log_u += f * rand_stride;
+        nacc += f * 2 * half;
+        if (chain) {
+            chain += f * 2 * half * n_iter * P;
+            lnchain += f * 2 * half * n_iter;
+        }
+    }
     const int it = d_iter ? *d_iter : it_val;
     const double newlnp = newlnp_in ? newlnp_in[w] : walker_lnprob(partial, skip, lnprior, nblk, w, lane);
     const size_t off = ((size_t)it * 2 + h) * half;

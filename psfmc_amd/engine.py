@@ -134,6 +134,16 @@ def load_library():
                                       ip, _c_double_p, _c_double_p, _c_double_p,
                                       ctypes.POINTER(ctypes.c_longlong), ci]
     llp = ctypes.POINTER(ctypes.c_longlong)
+    lib.psfmc_stretch_run_fields.restype = ci
+    lib.psfmc_stretch_run_fields.argtypes = lib.psfmc_stretch_run.argtypes
+    lib.psfmc_accumulate_theta_field.restype = ci
+    lib.psfmc_accumulate_theta_field.argtypes = [vp, ci, ci, _c_double_p]
+    lib.psfmc_reset_accumulated_field.restype = ci
+    lib.psfmc_reset_accumulated_field.argtypes = [vp, ci]
+    lib.psfmc_get_accumulated_field.restype = ci
+    lib.psfmc_get_accumulated_field.argtypes = [vp, ci] + [_c_double_p] * 5 + [llp]
+    lib.psfmc_eval_images_field.restype = ci
+    lib.psfmc_eval_images_field.argtypes = [vp, ci, ci, _c_double_p] + [_c_double_p] * 5
     lib.psfmc_stretch_open.restype = ci
     lib.psfmc_stretch_open.argtypes = [vp, ci, ci, _c_double_p, _c_double_p, _c_double_p, _c_double_p, ip,
                                        _c_double_p, llp, ci]
@@ -502,7 +512,8 @@ class Context(object):
 class FieldSetContext(object):
     """Several observed fields of ONE shape resident on one GPU in one context (wraps
     `psfmc_ctx_create_fields`): their walkers share the batches, so many small ensembles run at the
-    rate of one large one.  Log-posteriors of raw parameter vectors only.
+    rate of one large one -- log-posteriors, the device-resident sampler (every field's ensemble stepped
+    together), posterior-image sums and per-sample images.
 
     fields: sequence of (sci, obs_var, bad_px, psfs [n_psf, py, px], psf_vars) with the same shapes."""
 
@@ -611,6 +622,118 @@ class FieldSetContext(object):
         self._check(self._lib.psfmc_eval_theta_device_fields(
             self._ctx, len(f), fp, np_, ctypes.c_void_p(d_theta), None, ctypes.c_void_p(d_out),
             ctypes.c_void_p(stream) if stream else None))
+
+    IMAGE_KINDS = Context.IMAGE_KINDS
+
+    def stretch_run(self, pos, lnprob, z, lz, partner, log_u, naccepted, store=True, accumulate=False):
+        """Every field's ensemble stepped together on the device (psfmc_stretch_run_fields).
+        pos [F, W, P], lnprob [F, W] or None, z / lz / log_u / partner [F, n_iter, 2, W/2], naccepted
+        int64 [F, W] (updated).  Returns (pos, lnprob, chain [F, W, n_iter, P] | None, lnprob_chain
+        [F, W, n_iter] | None)."""
+        pos = np.array(pos, dtype=np.float64, order='C')
+        if pos.ndim != 3 or pos.shape[0] != self.n_fields:
+            raise ValueError('pos must be [n_fields, W, P]')
+        n_f, n_w, n_p = pos.shape
+        n_iter = int(np.shape(z)[1])
+        have = lnprob is not None
+        lnp = np.array(lnprob, dtype=np.float64).reshape(n_f, n_w) if have else np.empty((n_f, n_w))
+        z, lz, log_u = (_f64(a).reshape(n_f, n_iter, 2, n_w // 2) for a in (z, lz, log_u))
+        partner = np.ascontiguousarray(partner, dtype=np.int32).reshape(n_f, n_iter, 2, n_w // 2)
+        if naccepted.dtype != np.int64 or naccepted.shape != (n_f, n_w) or not naccepted.flags.c_contiguous:
+            raise ValueError('naccepted must be a contiguous int64 [n_fields, W]')
+        chain = np.empty((n_f, n_w, n_iter, n_p)) if store and n_iter else None
+        lnchain = np.empty((n_f, n_w, n_iter)) if store and n_iter else None
+        self._check(self._lib.psfmc_stretch_run_fields(
+            self._ctx, n_w, n_iter, _dp(pos), _dp(lnp), int(have), _dp(z), _dp(lz),
+            partner.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), _dp(log_u),
+            _dp(chain) if chain is not None else None, _dp(lnchain) if lnchain is not None else None,
+            naccepted.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), int(bool(accumulate))))
+        return pos, lnp, chain, lnchain
+
+    def accumulate_theta(self, field, theta):
+        """Add the images of [W, P] raw parameter vectors of one field to its posterior sums."""
+        theta = _f64(theta)
+        if theta.ndim != 2 or theta.shape[1] != self.n_params:
+            raise ValueError('theta must be [W, {}]'.format(self.n_params))
+        for lo in range(0, len(theta), self.max_walkers):
+            part = _f64(theta[lo:lo + self.max_walkers])
+            self._check(self._lib.psfmc_accumulate_theta_field(self._ctx, int(field), len(part), _dp(part)))
+
+    def accumulated(self, field):
+        """(dict kind -> mean image, sample count) of one field's posterior sums."""
+        bufs = {k: np.empty(self.shape, dtype=np.float64) for k in self.IMAGE_KINDS}
+        count = ctypes.c_longlong(0)
+        self._check(self._lib.psfmc_get_accumulated_field(
+            self._ctx, int(field), *[_dp(bufs[k]) for k in self.IMAGE_KINDS], ctypes.byref(count)))
+        return bufs, int(count.value)
+
+    def reset_accumulated(self, field=None):
+        """Clear the posterior sums of one field, or (None) of every field."""
+        if field is None:
+            self._check(self._lib.psfmc_reset_accumulated(self._ctx))
+        else:
+            self._check(self._lib.psfmc_reset_accumulated_field(self._ctx, int(field)))
+
+    def view(self, field):
+        """The part of `Context`'s interface a `MultiComponentModel` uses, for ONE field of this context."""
+        return FieldView(self, field)
+
+    def images(self, field, rows, kinds=None):
+        """dict kind -> [W, ny, nx] of the requested per-sample images for derived rows of one field."""
+        rows = _f64(rows)
+        kinds = self.IMAGE_KINDS if kinds is None else tuple(kinds)
+        n_w = rows.shape[0]
+        bufs, args = {}, []
+        for k in self.IMAGE_KINDS:
+            if k in kinds:
+                bufs[k] = np.empty((n_w,) + tuple(self.shape), dtype=np.float64)
+                args.append(_dp(bufs[k]))
+            else:
+                args.append(None)
+        if n_w:
+            self._check(self._lib.psfmc_eval_images_field(self._ctx, int(field), n_w, _dp(rows), *args))
+        return bufs
+
+
+class FieldView(object):
+    """One field of a `FieldSetContext` behind the interface of a one-field `Context`, so that a
+    `MultiComponentModel` of a `FieldSet` (images, posterior sums, log-posteriors) works on the shared
+    context instead of creating its own."""
+
+    IMAGE_KINDS = Context.IMAGE_KINDS
+
+    def __init__(self, owner, field):
+        self.owner, self.field = owner, int(field)
+        self.shape, self.n_psf = tuple(owner.shape), owner.n_psf
+        self.max_walkers, self.device = owner.max_walkers, owner.device
+
+    def close(self):                       # the FieldSet owns the context
+        pass
+
+    def set_option(self, key, value):
+        self.owner.set_option(key, value)
+
+    def get_option(self, key):
+        return self.owner.get_option(key)
+
+    def logpost_theta(self, theta, extra_lnprior=None):
+        if extra_lnprior is not None:
+            raise ValueError('a FieldSet evaluates priors on the GPU only')
+        thetas = [None] * self.owner.n_fields
+        thetas[self.field] = theta
+        return self.owner.logpost_theta(thetas)[self.field]
+
+    def images(self, rows, kinds=None):
+        return self.owner.images(self.field, rows, kinds)
+
+    def accumulate_theta(self, theta):
+        self.owner.accumulate_theta(self.field, theta)
+
+    def accumulated(self):
+        return self.owner.accumulated(self.field)
+
+    def reset_accumulated(self):
+        self.owner.reset_accumulated(self.field)
 
 
 class ContextGroup(object):

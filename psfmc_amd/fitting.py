@@ -155,3 +155,91 @@ def model_galaxy_mcmc(model_file, output_name=None, write_fits=default_filetypes
     if ranks is not None:
         ranks.broadcast_object(True)              # outputs written
     return mc_model, database
+
+
+def model_fields_mcmc(model_files, output_names=None, write_fits=default_filetypes, iterations=0, burn=0,
+                      chains=None, max_iterations=1, convergence_check=check_convergence_autocorr,
+                      device=0, random_states=None, start_positions=None, accumulate=True, quiet=False):
+    """`model_galaxy_mcmc` for SEVERAL fields of one image shape and one model structure at once, in
+    one GPU context (`models.FieldSet`): every field is fitted exactly as its own `model_galaxy_mcmc`
+    run would fit it -- its own ensemble of `chains` walkers, its own random stream, burn-in, sampling
+    with posterior images accumulated, convergence check, trace database `<output_name>_db.fits` and
+    posterior images -- but all fields advance together and every half-step's proposals of all fields
+    are evaluated as ONE batch.  For surveys of many small fields (BASELINE config 5: 64 fields of
+    256 x 256 with 256 walkers each, 8 per GPU), where a fit per field is dominated by fixed costs.
+    The reference has no counterpart: one field per process (psfMC/fitting.py:13-113).
+
+    model_files      model files (or MultiComponentModel objects) with the same component lists
+    output_names     one per field (default 'out_<model file>')
+    random_states    one RandomState state tuple or seed per field (default: numpy's global generator
+                     seeds them in field order)
+    start_positions  optional [F][chains, P] start positions (default: drawn from each field's priors)
+    Returns a list of (model, database), one per field."""
+    from .models import FieldSet
+    from .sampler import FieldSetSampler
+    n_f = len(model_files)
+    if output_names is None:
+        output_names = ['out_' + str(f).replace('.py', '') for f in model_files]
+    if len(output_names) != n_f:
+        raise ValueError('one output name per field')
+    output_names = [o + '_{}' for o in output_names]
+    first = model_files[0] if isinstance(model_files[0], MultiComponentModel) else None
+    if chains is None:
+        if first is None:
+            first = MultiComponentModel(model_files[0], device=device, backend='fused', max_walkers=1)
+            model_files = [first] + list(model_files[1:])
+        chains = 2 * first.num_params + 2
+    chains += chains % 2
+    fieldset = FieldSet(model_files, max_walkers=chains * n_f, device=device)
+    models = fieldset.models
+    sampler = FieldSetSampler(chains, fieldset, accumulate=False)
+    for f, sub in enumerate(sampler.fields):
+        state = None if random_states is None else random_states[f]
+        if state is None:
+            state = int(np.random.randint(0, 2 ** 31 - 1))
+        if isinstance(state, (int, np.integer)):
+            state = np.random.RandomState(int(state)).get_state()
+        sub.random_state = state
+
+    db_names = [o.format('db') + '.fits' for o in output_names]
+    have = [os.path.exists(d) for d in db_names]
+    if any(have) and not all(have):
+        raise ValueError('some of the fields already have a database and some do not: {}'.format(
+            [d for d, h in zip(db_names, have) if h]))
+    if not all(have):
+        if start_positions is None:
+            start_positions = [m.init_params_from_priors(chains) for m in models]
+        pos = np.array([np.asarray(p, dtype=np.float64) for p in start_positions])
+        lnprob = None
+        for step, result in enumerate(sampler.sample(pos, iterations=burn)):
+            pos = np.array([r[0] for r in result])
+            lnprob = np.array([r[1] for r in result])
+            if not quiet:
+                print_progress(step, burn, 'Burning')
+        sampler.reset()
+        sampler.accumulate = bool(accumulate)
+        converged = [False] * n_f
+        for sampling_iter in range(max_iterations):
+            for step, result in enumerate(sampler.sample(pos, lnprob0=lnprob, iterations=iterations)):
+                pos = np.array([r[0] for r in result])
+                lnprob = np.array([r[1] for r in result])
+                if not quiet:
+                    print_progress(step, iterations, 'Sampling')
+            converged = [bool(convergence_check(sub)) for sub in sampler.fields]
+            if all(converged):
+                break
+            warn('Not yet converged after {:d} iterations: fields {}'.format(
+                (sampling_iter + 1) * iterations, [f for f, ok in enumerate(converged) if not ok]))
+        databases = []
+        for f, sub in enumerate(sampler.fields):
+            meta = OrderedDict([('MCITER', sub.chain.shape[1]), ('MCBURN', burn), ('MCCHAINS', chains),
+                                ('MCCONVRG', converged[f]),
+                                ('MCACCEPT', float(sub.acceptance_fraction.mean()))])
+            databases.append(save_database(sub, models[f], db_names[f], meta_dict=meta))
+    else:
+        if not quiet:
+            print('Databases already contain sampled chains, skipping sampling')
+        databases = [load_database(d) for d in db_names]
+    for m, db, out in zip(models, databases, output_names):
+        save_posterior_images(m, db, output_name=out, filetypes=write_fits)
+    return list(zip(models, databases))

@@ -494,7 +494,14 @@ class FieldSet(object):
             if m._host_priors:
                 raise ValueError('field {}: a prior has no device form; a FieldSet evaluates priors on the '
                                  'GPU only'.format(f))
+            # the model's images, posterior sums and log-posteriors go through ITS field of the shared
+            # context (it never creates a context of its own)
+            if m._engine is not None:
+                m._engine.close()
+            m._engine = self.context.view(f)
+            m._max_walkers = int(max_walkers)
         self.num_params = first.num_params
+        self.max_walkers = int(max_walkers)
 
     def log_posterior_batch(self, thetas):
         """thetas: one [W_f, num_params] array per field -> list of [W_f] log-posteriors."""

@@ -24,7 +24,7 @@ import threading
 
 import numpy as np
 
-__all__ = ['EnsembleSampler', 'DeviceEnsembleSampler', 'AutocorrError', 'integrated_time']
+__all__ = ['EnsembleSampler', 'DeviceEnsembleSampler', 'FieldSetSampler', 'AutocorrError', 'integrated_time']
 
 
 class AutocorrError(Exception):
@@ -440,4 +440,103 @@ class DeviceEnsembleSampler(EnsembleSampler):
             self.iterations += n
             for j in range(n):
                 yield chain[:, j, :].copy(), lnchain[:, j].copy(), block_states[j]
+            done += n
+
+
+class _FieldChain(EnsembleSampler):
+    """One field's share of a `FieldSetSampler`: the emcee-style state (chain, lnprobability,
+    acceptance counters, random state) of that field's ensemble -- what `save_database`,
+    `check_convergence_autocorr` and the reference's own post-processing read."""
+
+    def __init__(self, nwalkers, model, a=2.0):
+        super(_FieldChain, self).__init__(nwalkers, model.num_params, a=a,
+                                          batch_lnpostfn=model.log_posterior_batch)
+        self.model = model
+
+    _state_snapshotter = DeviceEnsembleSampler._state_snapshotter
+    _draw = DeviceEnsembleSampler._draw
+
+
+class FieldSetSampler(object):
+    """The device-resident stretch-move sampler for every field of a `models.FieldSet` at once
+    (`psfmc_stretch_run_fields`): each field is its own ensemble of `nwalkers` walkers with its own
+    `RandomState` -- exactly the `DeviceEnsembleSampler` of that field alone -- but the half-step
+    proposals of all fields are evaluated as ONE batch, so many small ensembles sample at the rate of one
+    large one (BASELINE config 5 as a fit).  `fields[f]` is field f's emcee-style sampler object (`.chain`,
+    `.lnprobability`, `.acceptance_fraction`, `.random_state`, ...).  A field's chain equals the chain its
+    own one-field `DeviceEnsembleSampler` produces from the same start and random state, bit for bit.
+    The reference fits one field per process (psfMC/fitting.py:13-113)."""
+
+    def __init__(self, nwalkers, fieldset, a=2.0, block=64, accumulate=False):
+        if nwalkers % 2:
+            raise ValueError('The number of walkers must be even.')
+        if nwalkers * len(fieldset.models) > fieldset.max_walkers:
+            raise ValueError('the FieldSet was built for at most {} walkers in all'.format(fieldset.max_walkers))
+        self.fieldset = fieldset
+        self.k, self.dim = int(nwalkers), fieldset.num_params
+        self.block = int(block)
+        self.accumulate = bool(accumulate)
+        self.fields = [_FieldChain(nwalkers, m, a=a) for m in fieldset.models]
+
+    def reset(self):
+        for f in self.fields:
+            f.reset()
+
+    def clear_blobs(self):
+        pass
+
+    def sample(self, p0, lnprob0=None, iterations=1, thin=1, storechain=True):
+        """p0: [F, W, P] (or a list of [W, P]) start positions; lnprob0 likewise or None.  Yields, once per
+        iteration, the list over fields of (pos, lnprob, rstate)."""
+        ctx = self.fieldset.context
+        n_f = len(self.fields)
+        p = np.array([np.asarray(q, dtype=np.float64) for q in p0])
+        if p.shape != (n_f, self.k, self.dim):
+            raise ValueError('p0 must have shape ({}, {}, {})'.format(n_f, self.k, self.dim))
+        if np.any(~np.isfinite(p)):
+            raise ValueError('At least one parameter value was infinite or NaN.')
+        lnprob = None if lnprob0 is None else np.array([np.asarray(q, dtype=np.float64) for q in lnprob0])
+        if lnprob is None:
+            lnprob = np.array(self.fieldset.log_posterior_batch(list(p)))
+        if np.any(np.isnan(lnprob)):
+            raise ValueError('The initial lnprob was NaN.')
+        i0 = [f._chain.shape[1] for f in self.fields]
+        if storechain:
+            n_keep = int(iterations // thin)
+            for f in self.fields:
+                f._chain = np.concatenate((f._chain, np.zeros((self.k, n_keep, self.dim))), axis=1)
+                f._lnprob = np.concatenate((f._lnprob, np.zeros((self.k, n_keep))), axis=1)
+        nacc = np.ascontiguousarray([f.naccepted.astype(np.int64) for f in self.fields])
+        done = 0
+
+        def draw(n):
+            per = [f._draw(n) for f in self.fields]            # every field from its own generator
+            arrays = [np.ascontiguousarray([d[0][j] for d in per]) for j in range(4)]
+            return arrays, [d[1] for d in per]
+
+        draws, states = draw(min(self.block, iterations)) if iterations > 0 else (None, None)
+        while done < iterations:
+            n = min(self.block, iterations - done)
+            n_next = min(self.block, iterations - done - n)
+            block_states = states
+            job = _run_async(ctx.stretch_run, p, lnprob, *draws, nacc, store=True, accumulate=self.accumulate)
+            try:
+                draws, states = draw(n_next) if n_next > 0 else (None, None)
+            finally:
+                p, lnprob, chain, lnchain = job()
+            first = (-done) % thin
+            for i, f in enumerate(self.fields):
+                if self.accumulate:
+                    f.model._device_samples += n * self.k
+                    f.model.accumulated_samples += n * self.k
+                if storechain and first < n:
+                    count = (n - first + thin - 1) // thin
+                    dst = i0[i] + (done + first) // thin
+                    f._chain[:, dst:dst + count, :] = chain[i][:, first::thin, :]
+                    f._lnprob[:, dst:dst + count] = lnchain[i][:, first::thin]
+                f.naccepted = nacc[i].astype(np.float64)
+                f.iterations += n
+            for j in range(n):
+                yield [(chain[i][:, j, :].copy(), lnchain[i][:, j].copy(), block_states[i][j])
+                       for i in range(n_f)]
             done += n
