@@ -333,14 +333,45 @@ __device__ __forceinline__ double fast_exp2_poly(double r) {
 //     At dx = dy = 0 the reciprocal produces NaN like the reference's 0/0.
 // (Sersic.py:98-134 + :136-153, PointSource.py:24-57, Sky.py:14-16.)
 // ---------------------------------------------------------------------------
+// An image side the transforms are not built for (a prime factor above 13, ...) is EMBEDDED in the next
+// built side M >= L + Pk - 1 (L the image side, Pk the PSF's): the rasteriser fills transform pixel x' <
+// L + Pk - 1 with model pixel (x' - a) mod L -- the image followed by a wrap-around margin of Pk - 1 pixels,
+// zeros after it -- and the circular convolution of length M then equals the circular convolution of
+// length L (utils.py:25-32) on the pixels [a, a + L), which are the only ones the likelihood looks at
+// (overlap-save: every output there only reaches back over pixels that hold what the periodic image
+// holds).  a = Pk - 1 - c, c = the kernel's origin inside the padded PSF (psfmc_hip.hip embed_axis).
+// l = 0: no embedding on this axis.
+struct WrapDesc {
+    int lx, ax, ex;     // image side, margin before the image, extent of the filled pixels (lx + Pk - 1)
+    int ly, ay, ey;
+};
+// the image's own [ly][lx] window at (ay, ax) of a transform-shaped [..][nx] pixel array (the whole of it
+// unless the image is embedded)
+struct ImgWindow { int nx, ly, lx, ay, ax; };
+__device__ __forceinline__ int wrap_coord(int p, int a, int l) {
+    int m = p - a;
+    m += m < 0 ? l : 0;
+    m -= m >= l ? l : 0;
+    return m;
+}
+
 // K0: the lane's pixels are x = T (K0 + k) + t, k < P (a segment of a longer row; 0 for whole rows)
-template <int P, int T, int K0 = 0>
+// WRAP: `iy` and x are transform coordinates of an embedded image (see WrapDesc)
+template <int P, int T, int K0 = 0, bool WRAP = false>
 __device__ __forceinline__ void raster_row(const double* __restrict__ prep, int n_ps, int n_sersic,
                                            int t, int iy, bool ps_only, const double* __restrict__ log_tab,
-                                           double (&r)[P]) {
+                                           double (&r)[P], const WrapDesc& wr = WrapDesc{0, 0, 0, 0, 0, 0}) {
     const double sky = ps_only ? 0.0 : prep[0];
 #pragma unroll
     for (int k = 0; k < P; ++k) r[k] = sky;
+    int xm[WRAP ? P : 1];              // model column of pixel k
+    bool live_row = true;
+    if constexpr (WRAP) {
+        live_row = iy < wr.ey;
+        iy = wrap_coord(iy, wr.ay, wr.ly);
+#pragma unroll
+        for (int k = 0; k < P; ++k) xm[k] = wrap_coord(T * (K0 + k) + t, wr.ax, wr.lx);
+    }
     const double* p = prep + kPrepHead;
     for (int c = 0; c < n_ps; ++c, p += kPrepPs) {
         const int ty = iy - (int)p[0];
@@ -350,14 +381,24 @@ __device__ __forceinline__ void raster_row(const double* __restrict__ prep, int 
             const int xlo = (int)p[2], xn = (int)p[3];
 #pragma unroll
             for (int k = 0; k < P; ++k) {
-                const int tx = T * (K0 + k) + t - xlo;
+                const int tx = (WRAP ? xm[k] : T * (K0 + k) + t) - xlo;
                 const bool in = (unsigned)tx < (unsigned)xn;
                 const double wx = p[4 + kTaps + (in ? tx : 0)];
                 r[k] += in ? wy * wx : 0.0;
             }
         }
     }
-    if (ps_only) return;
+    // beyond the wrap-around margin of an embedded image the transform pixels are zero
+    auto blank_margin = [&]() {
+        if constexpr (WRAP) {
+#pragma unroll
+            for (int k = 0; k < P; ++k) r[k] = (live_row && T * (K0 + k) + t < wr.ex) ? r[k] : 0.0;
+        }
+    };
+    if (ps_only) {
+        blank_margin();
+        return;
+    }
     constexpr double kLog2e = 1.44269504088896340736;
     const double y = (double)iy;
     for (int c = 0; c < n_sersic; ++c, p += kPrepSersic) {
@@ -370,7 +411,7 @@ __device__ __forceinline__ void raster_row(const double* __restrict__ prep, int 
         const double gk = -2.0 * kappa * pw * 0.28867513459481288225;   // sqrt(1/12)
 #pragma unroll
         for (int k = 0; k < P; ++k) {
-            const double dx = (double)(T * (K0 + k) + t) - x0;   // exact pixel coordinate, one rounding
+            const double dx = (double)(WRAP ? xm[k] : T * (K0 + k) + t) - x0;   // exact pixel coordinate, one rounding
             const double u = __builtin_fma(m00, dx, uy);
             const double v = __builtin_fma(m10, dx, vy);
             const double rho2 = __builtin_fma(u, u, v * v);
@@ -382,6 +423,7 @@ __device__ __forceinline__ void raster_row(const double* __restrict__ prep, int 
             r[k] = __builtin_fma(sbeff * sb, __builtin_fma(gt * gt, fast_rcp1(d2), 1.0), r[k]);
         }
     }
+    blank_margin();
 }
 
 // ---------------------------------------------------------------------------

@@ -179,12 +179,14 @@ __global__ void k_pack_field(const double* __restrict__ sci, const double* __res
 //   FROM_IMAGE = true : z = img0 + i img_scale[w] img1 from memory (PSF spectra at setup)
 // raw_out (optional): [n][ny][nx] copy of the raw model (psfmc_eval_images)
 // ---------------------------------------------------------------------------
-template <int NX, bool FROM_IMAGE, typename TS = cd, bool FAST = FftShape<NX>::kPlain>
+// WRAP: the image is embedded in a larger transform size (psfmc_device.h WrapDesc); ny, NX are the
+// transform's sides
+template <int NX, bool FROM_IMAGE, typename TS = cd, bool FAST = FftShape<NX>::kPlain, bool WRAP = false>
 __global__ void __launch_bounds__((row_threads<NX, FAST>()), fused_min_waves<NX>())
 k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
            const cd* __restrict__ twx, TS* __restrict__ Tbuf, int n_ps, int n_sersic, int ny,
            int ps_only, const double* __restrict__ img, const double* __restrict__ img_scale,
-           double* __restrict__ raw_out) {
+           double* __restrict__ raw_out, WrapDesc wr) {
     using S = FftShape<NX>;
     constexpr int P = S::P, T = S::T, R = S::R, RG = row_group<NX>();
     constexpr int NXH = NX / 2 + 1;
@@ -229,7 +231,7 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
             wave_lds_sync();
         }
         double r[P];
-        raster_row<P, T>(wprep, n_ps, n_sersic, t, iy, ps_only != 0, log_tab, r);
+        raster_row<P, T, 0, WRAP>(wprep, n_ps, n_sersic, t, iy, ps_only != 0, log_tab, r, wr);
         wave_lds_sync();
 #pragma unroll
         for (int k = 0; k < P; ++k) v[k] = cd{r[k], mu * r[k] * r[k]};
@@ -782,11 +784,11 @@ k_rows_inv(const TS* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
 // ---------------------------------------------------------------------------
 template <int P> constexpr int raster_seg() { return P <= 16 ? P : (P % 16 == 0 ? 16 : P % 15 == 0 ? 15 : P % 12 == 0 ? 12 : P % 10 == 0 ? 10 : P % 9 == 0 ? 9 : P % 7 == 0 ? 7 : P % 5 == 0 ? 5 : P); }
 
-template <int NX, int K0, int SEG>
+template <int NX, int K0, int SEG, bool WRAP>
 __device__ __forceinline__ void raster_sums_segment(const double* __restrict__ prep, int plen, int w0, int w1, int psf,
                                                     int n_ps, int n_sersic, int t, int iy, bool row_on,
                                                     const double* __restrict__ log_tab, double* __restrict__ out,
-                                                    size_t S) {
+                                                    size_t S, const WrapDesc& wr) {
     constexpr int T = FftShape<NX>::T;
     double a[SEG], b[SEG], cps[SEG];
 #pragma unroll
@@ -795,14 +797,14 @@ __device__ __forceinline__ void raster_sums_segment(const double* __restrict__ p
         const double* wprep = prep + (size_t)w * plen;                   // wave-uniform
         if ((int)wprep[kPrepPsfIdx] != psf) continue;
         double r[SEG];
-        raster_row<SEG, T, K0>(wprep, n_ps, n_sersic, t, iy, false, log_tab, r);
+        raster_row<SEG, T, K0, WRAP>(wprep, n_ps, n_sersic, t, iy, false, log_tab, r, wr);
 #pragma unroll
         for (int k = 0; k < SEG; ++k) {
             a[k] += r[k];
             b[k] = __builtin_fma(r[k], r[k], b[k]);
         }
         if (n_ps) {
-            raster_row<SEG, T, K0>(wprep, n_ps, n_sersic, t, iy, true, log_tab, r);
+            raster_row<SEG, T, K0, WRAP>(wprep, n_ps, n_sersic, t, iy, true, log_tab, r, wr);
 #pragma unroll
             for (int k = 0; k < SEG; ++k) cps[k] += r[k];
         }
@@ -818,14 +820,16 @@ __device__ __forceinline__ void raster_sums_segment(const double* __restrict__ p
     }
 }
 
-template <int NX, int K0>
+template <int NX, int K0, bool WRAP>
 __device__ __forceinline__ void raster_sums_all(const double* __restrict__ prep, int plen, int w0, int w1, int psf,
                                                 int n_ps, int n_sersic, int t, int iy, bool row_on,
-                                                const double* __restrict__ log_tab, double* __restrict__ out, size_t S) {
+                                                const double* __restrict__ log_tab, double* __restrict__ out, size_t S,
+                                                const WrapDesc& wr) {
     constexpr int P = FftShape<NX>::P, SEG = raster_seg<P>();
     if constexpr (K0 < P) {
-        raster_sums_segment<NX, K0, SEG>(prep, plen, w0, w1, psf, n_ps, n_sersic, t, iy, row_on, log_tab, out, S);
-        raster_sums_all<NX, K0 + SEG>(prep, plen, w0, w1, psf, n_ps, n_sersic, t, iy, row_on, log_tab, out, S);
+        raster_sums_segment<NX, K0, SEG, WRAP>(prep, plen, w0, w1, psf, n_ps, n_sersic, t, iy, row_on, log_tab, out, S,
+                                               wr);
+        raster_sums_all<NX, K0 + SEG, WRAP>(prep, plen, w0, w1, psf, n_ps, n_sersic, t, iy, row_on, log_tab, out, S, wr);
     }
 }
 
@@ -833,10 +837,11 @@ __device__ __forceinline__ void raster_sums_all(const double* __restrict__ prep,
 // field f0) and a group never straddles two fields: the group then only looks at its own field's npf
 // kernel spectra and writes part[group][npf][3][ny][NX] (k_sum_partials_fields adds a field's groups up).
 // per_field == 0: any mixture of kernel spectra, part[group][n_psf][3][ny][NX].
-template <int NX>
+template <int NX, bool WRAP = false>
 __global__ void __launch_bounds__(64) k_raster_sums(const double* __restrict__ prep, int plen, int n_w, int group_size,
                                                     int n_ps, int n_sersic, int ny, int n_psf,
-                                                    double* __restrict__ part, int per_field, int f0, int npf) {
+                                                    double* __restrict__ part, int per_field, int f0, int npf,
+                                                    WrapDesc wr) {
     using S = FftShape<NX>;
     constexpr int T = S::T, RG = S::TPW;
     static_assert(S::P % raster_seg<S::P>() == 0, "segment");
@@ -853,8 +858,8 @@ __global__ void __launch_bounds__(64) k_raster_sums(const double* __restrict__ p
     const int psf0 = per_field > 0 ? (f0 + w0 / per_field) * npf : 0;      // (wave-uniform)
     const int n_here = per_field > 0 ? npf : n_psf;
     for (int p = 0; p < n_here; ++p)
-        raster_sums_all<NX, 0>(prep, plen, w0, w1, psf0 + p, n_ps, n_sersic, t, row_on ? iy : 0, row_on, log_tab,
-                               part + ((size_t)g * n_here + p) * 3 * Spx, Spx);
+        raster_sums_all<NX, 0, WRAP>(prep, plen, w0, w1, psf0 + p, n_ps, n_sersic, t, row_on ? iy : 0, row_on, log_tab,
+                                     part + ((size_t)g * n_here + p) * 3 * Spx, Spx, wr);
 }
 
 // lin[i] += part[0][i] + part[1][i] + ... (fixed order)

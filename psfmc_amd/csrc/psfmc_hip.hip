@@ -294,6 +294,12 @@ struct psfmc_ctx {
     int device = 0;
     int ny = 0, nx = 0, nxh = 0, S = 0, F = 0;
     int nyp = 0;                  // column length of the T layout: ny rounded up to whole row groups
+    // An image side the transforms are not built for is EMBEDDED in the next built side >= side + PSF side - 1
+    // (psfmc_device.h WrapDesc): ny, nx above are then the TRANSFORM's sides, ly, lx the image's; every pixel
+    // array that crosses the C ABI has the image's shape, every internal one the transform's.
+    bool embed = false;
+    int ly = 0, lx = 0;           // the image's own sides (= ny, nx without embedding)
+    WrapDesc wrap{0, 0, 0, 0, 0, 0};
     int n_psf = 0, n_ps = 0, n_sersic = 0;   // n_psf: kernel spectra in all (fields x PSFs per field)
     int n_fields = 1, n_psf_field = 0;       // observed fields of this context (psfmc_ctx_create_fields), PSFs of each
     size_t field_len = 0;                    // packed pixels (FieldPx) of one field
@@ -384,6 +390,9 @@ struct psfmc_ctx {
     } stretch;
 };
 
+// the image's window inside the transform-shaped pixel arrays (all of them unless the image is embedded)
+static ImgWindow img_window(const psfmc_ctx* c) { return ImgWindow{c->nx, c->ly, c->lx, c->wrap.ay, c->wrap.ax}; }
+
 // samples in the posterior-image sums of one field
 static long long& acc_n(psfmc_ctx* c, int field) { return field == 0 ? c->acc_count : c->acc_more[field - 1]; }
 
@@ -397,24 +406,40 @@ struct RowShape { int rg, fast_waves, fast_rg_log2, regs; bool plain; };
 // built for the power-of-two shapes only)
 template <int N, typename TS> constexpr bool storage_built() { return sizeof(TS) == sizeof(cd) || FftShape<N>::kPlain; }
 
-template <int NX, bool FROM_IMAGE, typename TS, bool FAST>
-static int launch_rows_fwd_impl(psfmc_ctx* c, int n, const double* prep, const uint8_t* skip, TS* Tbuf,
-                                int ps_only, const double* img, const double* img_scale, double* raw_out,
-                                hipStream_t st) {
+template <int NX, bool FROM_IMAGE, typename TS, bool FAST, bool WRAP>
+static int launch_rows_fwd_kernel(psfmc_ctx* c, int n, const double* prep, const uint8_t* skip, TS* Tbuf,
+                                  int ps_only, const double* img, const double* img_scale, double* raw_out,
+                                  hipStream_t st) {
     constexpr size_t lds = fused_row_lds_bytes<NX, FAST>();
     if constexpr (lds > 64 * 1024) {
         static thread_local int attr_device = -1;
         if (attr_device != c->device) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows_fwd<NX, FROM_IMAGE, TS, FAST>),
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows_fwd<NX, FROM_IMAGE, TS, FAST, WRAP>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_device = c->device;
         }
     }
     constexpr int waves = row_waves<NX, FAST>();
-    hipLaunchKernelGGL((k_rows_fwd<NX, FROM_IMAGE, TS, FAST>), dim3((c->nblk + waves - 1) / waves, n),
+    hipLaunchKernelGGL((k_rows_fwd<NX, FROM_IMAGE, TS, FAST, WRAP>), dim3((c->nblk + waves - 1) / waves, n),
                        dim3((row_threads<NX, FAST>())), lds, st, prep, skip, c->d_twx, Tbuf, c->n_ps, c->n_sersic,
-                       c->ny, ps_only, img, img_scale, raw_out);
+                       c->ny, ps_only, img, img_scale, raw_out, c->wrap);
     return PSFMC_OK;
+}
+
+template <int NX, bool FROM_IMAGE, typename TS, bool FAST>
+static int launch_rows_fwd_impl(psfmc_ctx* c, int n, const double* prep, const uint8_t* skip, TS* Tbuf,
+                                int ps_only, const double* img, const double* img_scale, double* raw_out,
+                                hipStream_t st) {
+    // the rasteriser of an embedded image wraps its coordinates (images from memory -- the PSF canvases at
+    // set-up, the posterior sums -- are in transform coordinates already)
+    if constexpr (!FROM_IMAGE && sizeof(TS) == sizeof(cd)) {
+        if (c->embed)
+            return launch_rows_fwd_kernel<NX, FROM_IMAGE, TS, FAST, true>(c, n, prep, skip, Tbuf, ps_only, img,
+                                                                          img_scale, raw_out, st);
+    }
+    if (!FROM_IMAGE && c->embed) return fail(PSFMC_EINVAL, "single-precision storage does not serve embedded images");
+    return launch_rows_fwd_kernel<NX, FROM_IMAGE, TS, FAST, false>(c, n, prep, skip, Tbuf, ps_only, img, img_scale,
+                                                                   raw_out, st);
 }
 
 // c->row_fast: the unguarded power-of-two row kernels (ny a whole number of their workgroups);
@@ -536,9 +561,15 @@ template <int NX>
 static int launch_raster_sums(psfmc_ctx* c, int n, const double* prep, int groups, int group_size, hipStream_t st,
                               int per_field, int f0) {
     constexpr int RG = FftShape<NX>::TPW;
-    hipLaunchKernelGGL((k_raster_sums<NX>), dim3((c->ny + RG - 1) / RG, groups), dim3(64), 0, st, prep, c->plen, n,
+    if (c->embed) {
+        hipLaunchKernelGGL((k_raster_sums<NX, true>), dim3((c->ny + RG - 1) / RG, groups), dim3(64), 0, st, prep,
+                           c->plen, n, group_size, c->n_ps, c->n_sersic, c->ny, c->n_psf, c->d_linpart, per_field,
+                           f0, c->n_psf_field, c->wrap);
+        return PSFMC_OK;
+    }
+    hipLaunchKernelGGL((k_raster_sums<NX, false>), dim3((c->ny + RG - 1) / RG, groups), dim3(64), 0, st, prep, c->plen, n,
                        group_size, c->n_ps, c->n_sersic, c->ny, c->n_psf, c->d_linpart, per_field, f0,
-                       c->n_psf_field);
+                       c->n_psf_field, c->wrap);
     return PSFMC_OK;
 }
 
@@ -931,6 +962,25 @@ static int ctx_init(psfmc_ctx* c, const double* sci, const double* obs_var, cons
     return PSFMC_OK;
 }
 
+// the built sides in ascending order
+static const int kFusedSides[] = {64,84,88,96,98,100,104,110,112,120,126,128,130,132,140,144,150,156,160,168,176,180,192,196,200,208,210,220,224,240,250,252,256,260,264,280,286,288,294,300,308,312,320,330,336,350,352,360,364,384,390,392,400,416,420,440,448,480,484,500,504,512,520,528,560,572,576,600,616,624,630,640,650,660,672,676,700,704,720,728,768,780,784,800,832,840,896,900,960,1024};
+
+// One axis of an image whose side `l` the transforms are not built for: the smallest built side
+// m >= l + pk - 1 (pk the PSF's side on that axis), the margin a in front of the image and the extent e of
+// the filled transform pixels (psfmc_device.h WrapDesc).  The kernel's origin inside the centre-padded
+// PSF, c = m/2 - (m - pk)/2 (utils.py:9-22 + the ifftshift of :32), is the same for every even m, so
+// outputs [a, a + l) of the length-m circular convolution are those of the length-l one when a = pk - 1 - c.
+static bool embed_axis(int l, int pk, int* m, int* a, int* e) {
+    const int need = l + pk - 1;
+    for (int v : kFusedSides)
+        if (v >= need) {
+            const int c = v / 2 - (v - pk) / 2;
+            *m = v; *a = pk - 1 - c; *e = need;
+            return true;
+        }
+    return false;
+}
+
 static int ctx_create_impl(psfmc_ctx** out, int device, int ny, int nx, int n_fields, const double* sci,
                            const double* obs_var, const uint8_t* bad_px, int n_psf,
                            int psf_ny, int psf_nx, const double* psf, const double* psf_var,
@@ -953,10 +1003,37 @@ static int ctx_create_impl(psfmc_ctx** out, int device, int ny, int nx, int n_fi
         return fail(PSFMC_EINVAL, "unknown backend %d", backend);
     int row_tiles = 0;
     RowShape rs{};
+    const int ly = ny, lx = nx;                       // the image's own sides
+    WrapDesc wrap{0, 0, 0, 0, 0, 0};
+    bool embed = false;
+    std::vector<double> pad_sci, pad_var;
+    std::vector<uint8_t> pad_bad;
     if (backend == PSFMC_BACKEND_FUSED) {
-        if (!fused_side(ny) || !fused_side(nx))
-            return fail(PSFMC_EINVAL, "fused backend: sides must be among " PSFMC_FUSED_SIDES " (got %d x %d)",
-                        ny, nx);
+        if (!fused_side(ny) || !fused_side(nx)) {
+            // embed the axes the transforms are not built for (a built axis stays as it is: a = 0, e = l = m)
+            embed = true;
+            wrap = WrapDesc{lx, 0, lx, ly, 0, ly};
+            if (!fused_side(nx) && !embed_axis(lx, psf_nx, &nx, &wrap.ax, &wrap.ex))
+                return fail(PSFMC_EINVAL, "fused backend: image width %d + PSF width %d - 1 exceeds the largest "
+                            "built side (1024)", lx, psf_nx);
+            if (!fused_side(ny) && !embed_axis(ly, psf_ny, &ny, &wrap.ay, &wrap.ey))
+                return fail(PSFMC_EINVAL, "fused backend: image height %d + PSF height %d - 1 exceeds the largest "
+                            "built side (1024)", ly, psf_ny);
+            // the field arrays in transform coordinates: the image at (ay, ax), every other pixel excluded
+            const size_t S_t = (size_t)ny * nx, S_l = (size_t)ly * lx;
+            pad_sci.assign((size_t)n_fields * S_t, 0.0);
+            pad_var.assign((size_t)n_fields * S_t, 1.0);
+            pad_bad.assign((size_t)n_fields * S_t, 1);
+            for (int f = 0; f < n_fields; ++f)
+                for (int y = 0; y < ly; ++y) {
+                    const size_t dst = (size_t)f * S_t + (size_t)(y + wrap.ay) * nx + wrap.ax;
+                    const size_t src = (size_t)f * S_l + (size_t)y * lx;
+                    memcpy(&pad_sci[dst], sci + src, (size_t)lx * sizeof(double));
+                    memcpy(&pad_var[dst], obs_var + src, (size_t)lx * sizeof(double));
+                    memcpy(&pad_bad[dst], bad_px + src, (size_t)lx);
+                }
+            sci = pad_sci.data(); obs_var = pad_var.data(); bad_px = pad_bad.data();
+        }
         RC_TRY(row_shape_for(nx, &rs));
         row_tiles = (ny + rs.rg - 1) / rs.rg;
     }
@@ -974,6 +1051,7 @@ static int ctx_create_impl(psfmc_ctx** out, int device, int ny, int nx, int n_fi
     psfmc_ctx* c = new psfmc_ctx;
     c->device = device;
     c->ny = ny; c->nx = nx; c->nxh = nx / 2 + 1; c->S = ny * nx; c->F = ny * c->nxh;
+    c->ly = ly; c->lx = lx; c->embed = embed; c->wrap = wrap;
     c->n_fields = n_fields; c->n_psf_field = n_psf;
     c->acc_more.assign(n_fields - 1, 0);
     c->n_psf = n_fields * n_psf; c->n_ps = n_ps; c->n_sersic = n_sersic;
@@ -1094,7 +1172,7 @@ extern "C" int psfmc_set_option(psfmc_ctx* c, const char* key, double value) {
         // traffic of every kernel, ~1e-7 relative error in the log-posterior -- the class of the
         // reference's own float32 raw model (psfMC/models.py:249), not an fp64 result
         const bool on = value != 0;
-        if (on && (c->backend != PSFMC_BACKEND_FUSED || !c->plain_shape || !c->row_fast))
+        if (on && (c->backend != PSFMC_BACKEND_FUSED || !c->plain_shape || !c->row_fast || c->embed))
             return fail(PSFMC_EINVAL, "storage_f32 needs the fused back end and power-of-two sides");
         HIP_TRY(hipSetDevice(c->device));
         HIP_TRY(hipDeviceSynchronize());
@@ -1280,7 +1358,7 @@ static int run_pipeline(psfmc_ctx* c, int W, const uint8_t* d_skip, hipStream_t 
 static int eval_device(psfmc_ctx* c, int W, const double* d_rows, const uint8_t* d_skip,
                        double* d_like, hipStream_t st) {
     hipLaunchKernelGGL(k_prep, dim3((W + 127) / 128), dim3(128), 0, st, d_rows, c->d_prep, W, c->n_ps,
-                       c->n_sersic, c->ny, c->nx, c->d_rho, c->n_psf, 0);
+                       c->n_sersic, c->ly, c->lx, c->d_rho, c->n_psf, 0);
     RC_TRY(run_pipeline(c, W, d_skip, st));
     hipLaunchKernelGGL(k_finish, dim3(finish_blocks(W)), dim3(kFinishThreads), 0, st, c->d_partial, d_skip, d_like,
                        W, c->nblk);
@@ -1303,7 +1381,7 @@ static void launch_theta_prep(psfmc_ctx* c, int W, const double* d_theta, const 
     hipLaunchKernelGGL(k_theta_prep, dim3((W + kThetaThreads - 1) / kThetaThreads, n_seg),
                        dim3(kThetaThreads, theta_task_waves(c->n_ps, c->n_sersic)), c->theta_lds, st,
                        L, d_theta, d_extra, d_rows, c->d_prep + (size_t)w_off * c->plen, c->d_lnprior + w_off,
-                       c->d_skip + w_off, W, c->ny, c->nx, c->d_rho, sp, field * c->n_psf_field, segs);
+                       c->d_skip + w_off, W, c->ly, c->lx, c->d_rho, sp, field * c->n_psf_field, segs);
 }
 
 // raw vectors -> log-posterior, everything on the device
@@ -1373,13 +1451,18 @@ static int eval_images_impl(psfmc_ctx* c, int field, int W, const double* rows, 
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const bool fused = c->backend == PSFMC_BACKEND_FUSED;
-    const size_t img = (size_t)c->S * sizeof(double);
+    const size_t S_img = (size_t)c->ly * c->lx;                 // pixels of a host image
+    const size_t img = S_img * sizeof(double);
     HIP_TRY(hipMemcpyAsync(c->d_rows, rows, (size_t)W * c->rlen * sizeof(double), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_prep, dim3((W + 127) / 128), dim3(128), 0, st, c->d_rows, c->d_prep, W, c->n_ps,
-                       c->n_sersic, c->ny, c->nx, c->d_rho, c->n_psf_field, field * c->n_psf_field);
+                       c->n_sersic, c->ly, c->lx, c->d_rho, c->n_psf_field, field * c->n_psf_field);
     RC_TRY(ensure_image_staging(c));
-    double* d_out = nullptr;     // [chunk][S] staging for derived images
+    double *d_out = nullptr, *d_rawdev = nullptr;     // [chunk] staging for derived images / the raw models (transform shape)
     HIP_TRY(hipMalloc(&d_out, (size_t)c->chunk * img));
+    if (raw && fused && hipMalloc(&d_rawdev, (size_t)c->chunk * c->S * sizeof(double)) != hipSuccess) {
+        (void)hipFree(d_out);
+        return fail(PSFMC_ENOMEM, "hipMalloc (raw-model staging)");
+    }
     // where the convolved model / model variance of walker w live after a pass
     const double* conv_src = fused ? c->d_img0 : c->d_real;
     const double* var_src = fused ? c->d_img1 : c->d_real;
@@ -1390,8 +1473,8 @@ static int eval_images_impl(psfmc_ctx* c, int field, int W, const double* rows, 
         auto emit = [&](double* host, const double* src, int strd, int comp, int op) -> int {
             if (!host) return PSFMC_OK;
             hipLaunchKernelGGL(k_image_out, dim3(64, n), dim3(256), 0, st, src, f_sci, f_var, d_out,
-                               c->S, strd, comp, op);
-            HIP_TRY(hipMemcpyAsync(host + (size_t)w0 * c->S, d_out, (size_t)n * img,
+                               c->S, strd, comp, op, img_window(c));
+            HIP_TRY(hipMemcpyAsync(host + (size_t)w0 * S_img, d_out, (size_t)n * img,
                                    hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             return PSFMC_OK;
@@ -1403,11 +1486,6 @@ static int eval_images_impl(psfmc_ctx* c, int field, int W, const double* rows, 
             }
             return hipfft_convolve(c, n, prep, nullptr, st, ps_only);
         };
-        auto fetch = [&](double* host, const double* dev) -> int {
-            HIP_TRY(hipMemcpyAsync(host + (size_t)w0 * c->S, dev, (size_t)n * img, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            return PSFMC_OK;
-        };
         if (raw && !fused) {   // raw model before the inverse transform overwrites it
             hipLaunchKernelGGL(k_raster, dim3((c->S + 1023) / 1024, n), dim3(256),
                                (size_t)c->plen * sizeof(double), st, prep, (const uint8_t*)nullptr,
@@ -1416,8 +1494,8 @@ static int eval_images_impl(psfmc_ctx* c, int field, int W, const double* rows, 
             if (rc != PSFMC_OK) break;
         }
         if (conv || resid || ivm || (raw && fused)) {
-            rc = pass(0, (raw && fused) ? d_out : nullptr);
-            if (rc == PSFMC_OK && raw && fused) rc = fetch(raw, d_out);
+            rc = pass(0, (raw && fused) ? d_rawdev : nullptr);
+            if (rc == PSFMC_OK && raw && fused) rc = emit(raw, d_rawdev, 1, 0, IMG_COPY);
             if (rc == PSFMC_OK) rc = emit(conv, conv_src, stride, 0, IMG_COPY);
             if (rc == PSFMC_OK) rc = emit(resid, conv_src, stride, 0, IMG_RESID);
             if (rc == PSFMC_OK) rc = emit(ivm, var_src, stride, var_c, IMG_IVM);
@@ -1429,6 +1507,7 @@ static int eval_images_impl(psfmc_ctx* c, int field, int W, const double* rows, 
     }
     (void)hipStreamSynchronize(st);
     (void)hipFree(d_out);
+    if (d_rawdev) (void)hipFree(d_rawdev);
     if (rc == PSFMC_OK) HIP_TRY(hipGetLastError());
     return rc;
 }
@@ -1923,7 +2002,7 @@ extern "C" int psfmc_accumulate_images(psfmc_ctx* c, int W, const double* rows) 
     hipStream_t st = c->stream;
     HIP_TRY(hipMemcpyAsync(c->d_rows, rows, (size_t)W * c->rlen * sizeof(double), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_prep, dim3((W + 127) / 128), dim3(128), 0, st, c->d_rows, c->d_prep, W, c->n_ps,
-                       c->n_sersic, c->ny, c->nx, c->d_rho, c->n_psf, 0);
+                       c->n_sersic, c->ly, c->lx, c->d_rho, c->n_psf, 0);
     rc = accumulate_from_prep(c, W, st);
     (void)hipStreamSynchronize(st);
     if (rc == PSFMC_OK) HIP_TRY(hipGetLastError());
@@ -2301,9 +2380,19 @@ extern "C" int psfmc_get_accumulated_sums(psfmc_ctx* c, double* sums, long long*
     HIP_TRY(hipSetDevice(c->device));
     RC_TRY(flush_linear_sums(c));
     *count = c->acc_count;
-    if (!c->d_acc) { memset(sums, 0, (size_t)4 * c->S * sizeof(double)); return PSFMC_OK; }
+    const size_t S_img = (size_t)c->ly * c->lx;
+    if (!c->d_acc) { memset(sums, 0, 4 * S_img * sizeof(double)); return PSFMC_OK; }
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(sums, c->d_acc, (size_t)4 * c->S * sizeof(double), hipMemcpyDeviceToHost));
+    if (!c->embed) {
+        HIP_TRY(hipMemcpy(sums, c->d_acc, 4 * S_img * sizeof(double), hipMemcpyDeviceToHost));
+        return PSFMC_OK;
+    }
+    std::vector<double> full((size_t)4 * c->S);              // transform shape -> the image's window
+    HIP_TRY(hipMemcpy(full.data(), c->d_acc, full.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 4; ++k)
+        for (int y = 0; y < c->ly; ++y)
+            memcpy(sums + k * S_img + (size_t)y * c->lx,
+                   &full[(size_t)k * c->S + (size_t)(y + c->wrap.ay) * c->nx + c->wrap.ax], (size_t)c->lx * sizeof(double));
     return PSFMC_OK;
 }
 
@@ -2314,7 +2403,17 @@ extern "C" int psfmc_set_accumulated_sums(psfmc_ctx* c, const double* sums, long
     if (!c->d_acc) RC_TRY(psfmc_reset_accumulated(c));
     if (c->d_lin) HIP_TRY(hipMemset(c->d_lin, 0, (size_t)c->n_psf * 3 * c->S * sizeof(double)));
     c->lin_pending = 0;                                  // the new sums replace everything gathered so far
-    HIP_TRY(hipMemcpy(c->d_acc, sums, (size_t)4 * c->S * sizeof(double), hipMemcpyHostToDevice));
+    if (!c->embed) {
+        HIP_TRY(hipMemcpy(c->d_acc, sums, (size_t)4 * c->S * sizeof(double), hipMemcpyHostToDevice));
+    } else {
+        const size_t S_img = (size_t)c->ly * c->lx;
+        std::vector<double> full((size_t)4 * c->S, 0.0);     // only the image's window is ever read back
+        for (int k = 0; k < 4; ++k)
+            for (int y = 0; y < c->ly; ++y)
+                memcpy(&full[(size_t)k * c->S + (size_t)(y + c->wrap.ay) * c->nx + c->wrap.ax],
+                       sums + k * S_img + (size_t)y * c->lx, (size_t)c->lx * sizeof(double));
+        HIP_TRY(hipMemcpy(c->d_acc, full.data(), full.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     c->acc_count = count;
     return PSFMC_OK;
 }
@@ -2329,7 +2428,8 @@ static int get_accumulated_impl(psfmc_ctx* c, int field, double* raw, double* co
     HIP_TRY(hipSetDevice(c->device));
     RC_TRY(flush_linear_sums(c));
     double* d_out = nullptr;
-    HIP_TRY(hipMalloc(&d_out, (size_t)c->S * sizeof(double)));
+    const size_t S_img = (size_t)c->ly * c->lx;
+    HIP_TRY(hipMalloc(&d_out, S_img * sizeof(double)));
     const double inv_n = 1.0 / (double)n;
     const size_t px = (size_t)field * c->S;                 // this field's pixels in d_sci / d_var
     struct { double* host; int slot, op; } outs[] = {{raw, 0, 0}, {conv, 1, 0}, {resid, 1, 1},
@@ -2338,9 +2438,9 @@ static int get_accumulated_impl(psfmc_ctx* c, int field, double* raw, double* co
     for (auto& o : outs) {
         if (!o.host) continue;
         hipLaunchKernelGGL(k_accumulated_out, dim3(256), dim3(256), 0, c->stream,
-                           c->d_acc + ((size_t)field * 4 + o.slot) * c->S, c->d_sci + px, c->d_var + px, d_out, c->S,
-                           inv_n, o.op);
-        if (hipMemcpyAsync(o.host, d_out, (size_t)c->S * sizeof(double), hipMemcpyDeviceToHost, c->stream) !=
+                           c->d_acc + ((size_t)field * 4 + o.slot) * c->S, c->d_sci + px, c->d_var + px, d_out,
+                           inv_n, o.op, img_window(c));
+        if (hipMemcpyAsync(o.host, d_out, S_img * sizeof(double), hipMemcpyDeviceToHost, c->stream) !=
                 hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
             rc = fail(PSFMC_EHIP, "accumulated image copy failed");
             break;
@@ -2363,6 +2463,8 @@ extern "C" int psfmc_get_accumulated_field(psfmc_ctx* c, int field, double* raw,
 
 extern "C" int psfmc_get_spectra(psfmc_ctx* c, double* psf_spec, double* var_spec) {
     if (!c || !psf_spec || !var_spec) return fail(PSFMC_EINVAL, "NULL argument");
+    if (c->embed) return fail(PSFMC_EINVAL, "the image is embedded in a %d x %d transform: its kernel spectra are not "
+                              "those of the %d x %d image", c->ny, c->nx, c->ly, c->lx);
     HIP_TRY(hipSetDevice(c->device));
     const size_t bytes = (size_t)c->n_psf * c->F * sizeof(double2);
     if (c->backend == PSFMC_BACKEND_HIPFFT) {

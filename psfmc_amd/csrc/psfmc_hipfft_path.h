@@ -111,16 +111,21 @@ __global__ void k_pad(const double* __restrict__ src, double* __restrict__ dst, 
 }
 
 // image outputs: out = real[(2w+c)] or a pointwise function of it
+// `real`, `sci`, `obs_var` are [ny][nx] (the transform's shape); the output is the image's own window of it
+// (ImgWindow, psfmc_device.h)
 enum ImgOp { IMG_COPY = 0, IMG_RESID = 1, IMG_IVM = 2 };
 __global__ void k_image_out(const double* __restrict__ real, const double* __restrict__ sci,
                             const double* __restrict__ obs_var, double* __restrict__ out,
-                            int S, int stride, int c, int op) {
+                            int S, int stride, int c, int op, ImgWindow win) {
     const int w = blockIdx.y;
     const double* src = real + (size_t)(stride * w + c) * S;
-    double* dst = out + (size_t)w * S;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < S; i += gridDim.x * blockDim.x) {
-        const double v = src[i];
-        dst[i] = op == IMG_COPY ? v : op == IMG_RESID ? sci[i] - v : 1.0 / (v + obs_var[i]);
+    const int S_out = win.ly * win.lx;
+    double* dst = out + (size_t)w * S_out;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < S_out; i += gridDim.x * blockDim.x) {
+        const int y = i / win.lx, x = i - y * win.lx;
+        const int j = (y + win.ay) * win.nx + x + win.ax;
+        const double v = src[j];
+        dst[i] = op == IMG_COPY ? v : op == IMG_RESID ? sci[j] - v : 1.0 / (v + obs_var[j]);
     }
 }
 
@@ -136,11 +141,14 @@ __global__ void k_accumulate(const double* __restrict__ src, double* __restrict_
 
 // means from the sums: op 0 mean, 1 sci - mean, 2 1 / (mean + obs_var)
 __global__ void k_accumulated_out(const double* __restrict__ acc, const double* __restrict__ sci,
-                                  const double* __restrict__ obs_var, double* __restrict__ out, int S,
-                                  double inv_n, int op) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < S; i += gridDim.x * blockDim.x) {
-        const double m = acc[i] * inv_n;
-        out[i] = op == 0 ? m : op == 1 ? sci[i] - m : 1.0 / (m + obs_var[i]);
+                                  const double* __restrict__ obs_var, double* __restrict__ out,
+                                  double inv_n, int op, ImgWindow win) {
+    const int S_out = win.ly * win.lx;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < S_out; i += gridDim.x * blockDim.x) {
+        const int y = i / win.lx, x = i - y * win.lx;
+        const int j = (y + win.ay) * win.nx + x + win.ax;
+        const double m = acc[j] * inv_n;
+        out[i] = op == 0 ? m : op == 1 ? sci[j] - m : 1.0 / (m + obs_var[j]);
     }
 }
 

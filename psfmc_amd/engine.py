@@ -31,10 +31,26 @@ def nearest_fused_sides(n):
     return (below[-1] if below else None), (above[0] if above else None)
 
 
-def fused_supports(ny, nx):
-    """Whether psfmc_ctx_create accepts this image shape for the fused back end: both sides
-    from FUSED_SIDES, in any combination."""
-    return ny in FUSED_SIDES and nx in FUSED_SIDES
+def embedding_side(side, psf_side):
+    """The transform side an image side the kernels are not built for is EMBEDDED in: the smallest
+    built side >= side + psf_side - 1 (the image, a wrap-around margin of psf_side - 1 pixels, zeros:
+    the circular convolution of that length equals the image's own on the image's pixels --
+    csrc/psfmc_device.h WrapDesc), or None when there is none (side + psf_side - 1 > 1024)."""
+    need = side + psf_side - 1
+    fits = [v for v in FUSED_SIDES if v >= need]
+    return fits[0] if fits else None
+
+
+def fused_supports(ny, nx, psf_shape=None):
+    """Whether psfmc_ctx_create accepts this image shape for the fused back end: both sides from
+    FUSED_SIDES in any combination -- or, with the PSF's (py, px) given, any even side that can be
+    embedded in a built one (`embedding_side`)."""
+    if ny in FUSED_SIDES and nx in FUSED_SIDES:
+        return True
+    if psf_shape is None or ny % 2 or nx % 2:
+        return False
+    return all(side in FUSED_SIDES or embedding_side(side, pk) is not None
+               for side, pk in ((ny, psf_shape[0]), (nx, psf_shape[1])))
 
 
 _LIB_NAME = 'libpsfmc_hip.so'

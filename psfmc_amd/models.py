@@ -105,7 +105,8 @@ class MultiComponentModel(object):
         self._sersic = [c for c in components if isinstance(c, Sersic)]
         if backend == 'auto':
             ny, nx = config.obs_data.shape
-            backend = 'fused' if engine.fused_supports(ny, nx) else 'hipfft'
+            psf_shape = np.shape(config.psf_selector.psf_data[0])
+            backend = 'fused' if engine.fused_supports(ny, nx, psf_shape) else 'hipfft'
         if storage not in ('f64', 'f32'):
             raise ValueError("storage must be 'f64' or 'f32'")
         self._device, self._backend, self._storage = device, backend, storage

@@ -110,11 +110,14 @@ def test_many_fields_each_with_its_own_context():
         model.close()
 
 
-def test_auto_backend_falls_back_to_hipfft_for_unbuilt_sides():
-    """backend='auto': a side outside the built list (170 = 2 * 5 * 17) runs on the hipFFT back end,
-    a built one (140) on the fused kernels; both against the oracle."""
+def test_auto_backend_keeps_unbuilt_sides_on_the_fused_kernels():
+    """backend='auto': a side outside the built list (170 = 2 * 5 * 17) runs on the fused kernels embedded in
+    the next built side (round 2: the hipFFT back end), like a built one (140); a side too large to embed
+    with its 64-pixel PSF (1000 + 63 > 1024) still goes to hipFFT.  All against the oracle."""
     import psfmc_oracle as orc
-    for side, want_backend in ((170, 'hipfft'), (140, 'fused')):
+    from psfmc_amd import engine
+    assert not engine.fused_supports(1000, 1000, (64, 64))
+    for side, want_backend in ((170, 'fused'), (140, 'fused')):
         model, fld = make_model(side, 1, 'auto', max_walkers=8)
         assert model._backend == want_backend
         theta = synth_field.draw_walkers(side, 1, 4, seed=3, near_truth=fld['truth'])
@@ -190,10 +193,10 @@ def test_degenerate_component_sets(backend):
     model.close()
 
 
-def test_hipfft_backend_handles_any_even_size_and_fused_refuses():
-    """Even sides with a prime factor above 5 (here 90 = 2 * 3^2 * 5 is fine as a number but is
-    not among the built sides): the hipFFT back end evaluates them, the fused one says clearly
-    that it cannot; odd sizes are rejected by the setup like in the reference."""
+def test_unbuilt_even_sizes_on_both_back_ends():
+    """An even side that is not among the built ones (90): the hipFFT back end transforms it as it is, the
+    fused one embeds it in the next built side -- both against the oracle; a side too large to embed is
+    refused with a clear message; odd sizes are rejected by the setup like in the reference."""
     from psfmc_amd import MultiComponentModel, engine
     from psfmc_amd.ModelComponents import Configuration, Sky, PointSource, Sersic
     rng = np.random.RandomState(12)
@@ -217,8 +220,14 @@ def test_hipfft_backend_handles_any_even_size_and_fused_refuses():
     want = orc.log_likelihood(field, comps, raw_dtype=np.float64)
     assert abs(got[0] - want) <= 1e-11 * abs(want)
     model.close()
+    model = build('fused')
+    got = model.log_likelihood_batch(np.zeros((2, 0)))
+    assert abs(got[0] - want) <= 1e-11 * abs(want)
+    model.close()
+    big = np.zeros((64, 1010), dtype=np.float32)
     with pytest.raises(engine.NativeError) as err:
-        build('fused').log_likelihood_batch(np.zeros((1, 0)))
-    assert 'sides must be among' in str(err.value)
+        cfg = Configuration(big, big + 400.0, psf, pivm, mag_zeropoint=24.0)
+        MultiComponentModel([cfg, Sky(adu=0.01)], backend='fused', max_walkers=4).log_likelihood_batch(np.zeros((1, 0)))
+    assert 'exceeds the largest built side' in str(err.value)
     with pytest.raises(ValueError):
         Configuration(sci[:99], ivm[:99], psf, pivm)

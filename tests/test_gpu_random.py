@@ -150,9 +150,11 @@ def general_shapes():
     # the claim above, enforced: every built side runs as the column length AND as the row length
     assert {ny for ny, _ in shapes} >= set(engine.FUSED_SIDES), sorted(set(engine.FUSED_SIDES) - {ny for ny, _ in shapes})
     assert {nx for _, nx in shapes} >= set(engine.FUSED_SIDES), sorted(set(engine.FUSED_SIDES) - {nx for _, nx in shapes})
-    # a side with a prime factor > 13 (or factors the shapes cannot split into P, T <= 32) goes to
-    # the hipFFT back end under backend='auto'
+    # a side with a prime factor > 13 (or factors the shapes cannot split into P, T <= 32) is not built ...
     assert not engine.fused_supports(170, 170) and not engine.fused_supports(256, 90) and not engine.fused_supports(490, 64)
+    # ... but given the PSF's shape it is embedded in the next built side (test_embedded_sides_match_oracle)
+    assert engine.fused_supports(170, 170, (33, 33)) and engine.fused_supports(490, 64, (16, 9))
+    assert not engine.fused_supports(1000, 1000, (64, 64)) and not engine.fused_supports(171, 170, (9, 9))
     return shapes
 
 
@@ -231,5 +233,94 @@ def test_general_sides_with_distinct_walkers(n_side):
     assert np.array_equal(model.log_posterior_batch(theta[perm]), got[perm])
     assert np.array_equal(model.log_posterior_batch(theta[2:5]), got[2:5])
     assert np.array_equal(model.log_posterior_batch(theta[-1:]), got[-1:])
+    model.close()
+    ref.close()
+
+
+# even sides the transforms are NOT built for (prime factors above 13, or no P x T split with P, T <= 32):
+# embedded in the next built side >= side + PSF side - 1 (psfmc_device.h WrapDesc), each axis on its own
+EMBEDDED_SHAPES = [(170, 170), (256, 90), (490, 64), (64, 490), (74, 74), (134, 256), (200, 134), (166, 226),
+                   (238, 340), (68, 1000), (958, 70), (290, 292), (990, 82), (94, 102), (502, 514), (686, 98)]
+
+
+@pytest.mark.parametrize('shape', EMBEDDED_SHAPES, ids=lambda s: '%dx%d' % s)
+def test_embedded_sides_match_oracle(shape):
+    """Image sides outside the built list on the fused kernels (round-2 review: `backend='auto'` left them
+    to hipFFT): the log-likelihood and all five images against the fp64 oracle at the SAME tolerances as
+    the built sides -- the circular convolution of the image's own size, not of a padded one
+    (psfMC/utils.py:25-32) -- and against the hipFFT back end, which transforms at the image's size."""
+    from psfmc_amd import engine
+    seed = 3000 + shape[0] * 7 + shape[1]
+    case = random_case(seed, shape)
+    psf_shape = case['psfs'][0].shape
+    assert engine.fused_supports(shape[0], shape[1], psf_shape) and not engine.fused_supports(*shape)
+    field = orc.make_field(case['sci'], case['ivm'], case['psfs'], case['pivms'], mask=case['mask'],
+                           mag_zp=case['zp'])
+    want, imgs = orc.evaluate(field, case['comps'], case['psf_index'], raw_dtype=np.float64, want_ps_sub=True)
+    want = want if np.isfinite(want) else -np.inf
+    n_free = 1 if len(case['psfs']) > 1 else 0
+    theta = np.full((3, n_free), float(case['psf_index']))
+    model = build(case, 'auto')
+    assert model._backend == 'fused'
+    got = model.log_likelihood_batch(theta)
+    assert got[0] == got[1] == got[2]
+    ref = build(case, 'hipfft')
+    if np.isfinite(want):
+        assert abs(got[0] - want) <= 2e-10 * abs(want), (shape, got[0], want)
+        assert abs(got[0] - ref.log_likelihood_batch(theta)[0]) <= 2e-10 * abs(want)
+        dev = model.sample_images(theta[:1])
+        for kind, img in imgs.items():
+            assert dev[kind][0].shape == tuple(shape)
+            fin = np.isfinite(img)
+            assert np.array_equal(np.isfinite(dev[kind][0]), fin), (shape, kind)
+            scale = max(np.abs(img[fin]).max(), 1e-300)
+            peak = np.nanmax(np.abs(imgs['raw_model']))
+            tol = 5e-9 * max(1.0, (peak / 2e3) ** 2) if kind == 'composite_ivm' else 1e-11
+            assert np.abs(dev[kind][0][fin] - img[fin]).max() <= tol * scale, (shape, kind)
+        # posterior-image sums (the linear-sum route rasterises with the wrapped coordinates too)
+        model.accumulate_samples(theta[:2])
+        post = model.collect_posterior_images()
+        for kind, img in imgs.items():
+            fin = np.isfinite(img)
+            scale = max(np.abs(img[fin]).max(), 1e-300)
+            peak = np.nanmax(np.abs(imgs['raw_model']))
+            tol = 5e-9 * max(1.0, (peak / 2e3) ** 2) if kind == 'composite_ivm' else 1e-11
+            assert np.abs(post[kind][fin] - img[fin]).max() <= tol * scale, (shape, kind, 'posterior')
+    else:
+        assert got[0] == -np.inf
+    model.close()
+    ref.close()
+
+
+def test_embedded_side_with_distinct_walkers_and_priors():
+    """170 x 170 (2 x 5 x 17) through the raw-vector path: priors, early-out, a batch of distinct walkers,
+    the device sampler -- against the hipFFT back end and the oracle."""
+    from test_gpu_fullsize import make_model
+    n_side, n_sersic, n_w = 170, 1, 24
+    model, fld = make_model(n_side, n_sersic, 'auto', max_walkers=n_w)
+    assert model._backend == 'fused'
+    ref, _ = make_model(n_side, n_sersic, 'hipfft', max_walkers=n_w)
+    theta = np.vstack([synth_field.draw_walkers(n_side, n_sersic, n_w // 2, seed=n_side),
+                       synth_field.draw_walkers(n_side, n_sersic, n_w - n_w // 2, seed=n_side + 1,
+                                                near_truth=fld['truth'])])
+    got = model.log_posterior_batch(theta)
+    assert np.isfinite(got).all()
+    assert helpers.rel_err(got, ref.log_posterior_batch(theta)) <= 1e-11
+    field = orc.make_field(fld['sci'], fld['ivm'], [fld['psf']], [fld['psf_ivm']], mag_zp=fld['mag_zp'])
+    prior = model.log_priors_batch(theta[[0, n_w - 1]])
+    for i, p in zip((0, n_w - 1), prior):
+        want = helpers.oracle_loglike(field, helpers.synth_layout(n_sersic), theta[i]) + p
+        assert abs(got[i] - want) <= 1e-10 * abs(want), i
+    perm = np.random.RandomState(n_side).permutation(n_w)
+    assert np.array_equal(model.log_posterior_batch(theta[perm]), got[perm])
+    from psfmc_amd import DeviceEnsembleSampler
+    samp = DeviceEnsembleSampler(n_w, model, block=3)
+    samp.random_state = np.random.RandomState(5).get_state()
+    for res in samp.sample(theta, iterations=4):
+        pass
+    assert np.isfinite(res[1]).all() and samp.naccepted.sum() > 0
+    assert np.array_equal(model.log_posterior_batch(res[0]), res[1])
+    with pytest.raises(Exception):
+        model.engine.spectra()
     model.close()
     ref.close()

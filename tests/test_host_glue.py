@@ -214,3 +214,5 @@ def test_nearest_fused_sides():
     assert engine.nearest_fused_sides(50) == (None, 64)
     assert engine.nearest_fused_sides(2000) == (1024, None)
     assert engine.fused_supports(140, 256) and not engine.fused_supports(134, 256)
+    assert engine.fused_supports(134, 256, (64, 64)) and engine.embedding_side(134, 64) == 200
+    assert engine.embedding_side(1000, 64) is None and engine.embedding_side(170, 33) == 208
