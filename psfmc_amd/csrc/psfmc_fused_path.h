@@ -50,6 +50,9 @@ constexpr int kColThreads = 256;     // column kernel: 4 waves, persistent
 #ifndef PSFMC_INV_PRIO
 #define PSFMC_INV_PRIO 0
 #endif
+#ifndef PSFMC_INV_CHUNK
+#define PSFMC_INV_CHUNK 8             /* field pixels per load chunk of k_rows_inv at nx = 512, 1024 */
+#endif
 #ifndef PSFMC_COLS_PREFETCH
 #define PSFMC_COLS_PREFETCH 1         /* register double-buffering of the column loads */
 #endif
@@ -640,6 +643,11 @@ k_rows_inv(const TS* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
         // the owner of NX - k is lane (T - t) % T at a' = P-1-a (t != 0) or P-a (t == 0);
         // mbuf is [P/2][T] complex
         const unsigned off0 = (unsigned)t_elem(iy, 0, RGL2) * kEl + (unsigned)t * kstride;
+        // (nx = 1024: a wave holds 2 rows = 64-byte halves of the 128-byte lines [kx][2 row groups], and the
+        // kernel fetches 1.42x its bytes.  Round 3 tried whole lines per wave -- the two waves that share lines
+        // each loading every other block of 32 kx columns for both, four consecutive 32-byte pieces per line,
+        // and swapping rows through LDS behind one workgroup barrier: the fetch went UP to 1.82x and the kernel
+        // from 33.8 to 40.4 us.  The over-fetch is not a matter of which wave touches a line when.)
 #pragma unroll
         for (int a = 0; a < P / 2; ++a) {
             const TS* p = at_bytes(wbase, off0 + (unsigned)(T * a) * kstride);
@@ -725,40 +733,67 @@ k_rows_inv(const TS* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
     if (MULTI || (NX < 1024 && n_psf_field > 0))
         fbase += (size_t)((int)prep[(size_t)w * plen + kPrepPsfIdx] / n_psf_field) * field_stride;
     const unsigned foff = (unsigned)lane * (unsigned)sizeof(FieldPx);
-    FieldPx px[R];
-    bool any_bad = false;
-#pragma unroll
-    for (int e = 0; e < R; ++e) {
-        px[e] = *at_bytes(fbase, foff + (unsigned)(e * 64 * sizeof(FieldPx)));
-        any_bad |= px[e].sci != px[e].sci;
-    }
+    // The field pixels arrive in chunks of CH registers, the next chunk's loads in flight while this
+    // one is summed.  One chunk = all R for the small shapes; at R = 32 (nx = 512, 1024) four chunks of
+    // 8: all 32 pixels at once were 128 registers on top of the transform's 128 -- the whole budget of a
+    // wave at two per SIMD, with scalar registers spilling into what was left.  The sums do not depend
+    // on the chunking: good pixels are added in register order by the same instructions either way.
+    constexpr int CH = (FAST && R == 32) ? PSFMC_INV_CHUNK : R, NCH = R / CH;
+    static_assert(R % CH == 0, "chunks");
     double acc = 0.0, mant = 1.0;
-    int expo = 0, n_good = R;
+    int expo = 0, n_good = 0;
     bool invalid = false;
-    if (!__any(any_bad)) {
+    auto load_chunk = [&](FieldPx (&px)[CH], int c) {
 #pragma unroll
-        for (int e = 0; e < R; ++e) {
-            const double d = __builtin_fma(v[e].y, inv_lambda, px[e].var);
-            const double r = px[e].sci - v[e].x;
-            acc = __builtin_fma(r * r, fast_rcp(d), acc);
-            invalid |= !(d > 0.0);
-            mant *= __builtin_amdgcn_frexp_mant(d);
-            expo += __builtin_amdgcn_frexp_exp(d);
+        for (int j = 0; j < CH; ++j) px[j] = *at_bytes(fbase, foff + (unsigned)((c * CH + j) * 64 * sizeof(FieldPx)));
+    };
+    auto sum_chunk = [&](const FieldPx (&px)[CH], int c) {
+        bool any_bad = false;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) any_bad |= px[j].sci != px[j].sci;
+        if (!__any(any_bad)) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int e = c * CH + j;
+                const double d = __builtin_fma(v[e].y, inv_lambda, px[j].var);
+                const double r = px[j].sci - v[e].x;
+                acc = __builtin_fma(r * r, fast_rcp(d), acc);
+                invalid |= !(d > 0.0);
+                mant *= __builtin_amdgcn_frexp_mant(d);
+                expo += __builtin_amdgcn_frexp_exp(d);
+            }
+            n_good += CH;
+        } else {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int e = c * CH + j;
+                const bool good = px[j].sci == px[j].sci;
+                const double d = __builtin_fma(v[e].y, inv_lambda, px[j].var);
+                const double r = px[j].sci - v[e].x;
+                const double a1 = __builtin_fma(r * r, fast_rcp(d), acc);
+                acc = good ? a1 : acc;
+                const double dd = good ? d : 1.0;                // neutral factor
+                invalid |= !(dd > 0.0);
+                mant *= __builtin_amdgcn_frexp_mant(dd);
+                expo += __builtin_amdgcn_frexp_exp(dd);
+                n_good += good ? 1 : 0;
+            }
         }
+    };
+    if constexpr (NCH == 1) {
+        FieldPx px[CH];
+        load_chunk(px, 0);
+        sum_chunk(px, 0);
     } else {
-        n_good = 0;
+        static_assert(NCH % 2 == 0, "chunk pairs");
+        FieldPx pa[CH], pb[CH];
+        load_chunk(pa, 0);
 #pragma unroll
-        for (int e = 0; e < R; ++e) {
-            const bool good = px[e].sci == px[e].sci;
-            const double d = __builtin_fma(v[e].y, inv_lambda, px[e].var);
-            const double r = px[e].sci - v[e].x;
-            const double q = r * r * fast_rcp(d);
-            acc += good ? q : 0.0;
-            const double dd = good ? d : 1.0;                // neutral factor
-            invalid |= !(dd > 0.0);
-            mant *= __builtin_amdgcn_frexp_mant(dd);
-            expo += __builtin_amdgcn_frexp_exp(dd);
-            n_good += good ? 1 : 0;
+        for (int c = 0; c < NCH; c += 2) {
+            load_chunk(pb, c + 1);
+            sum_chunk(pa, c);
+            if (c + 2 < NCH) load_chunk(pa, c + 2);
+            sum_chunk(pb, c + 1);
         }
     }
     acc += 0.69314718055994530942 * (fast_log2(mant) + (double)expo) +

@@ -17,11 +17,13 @@ export TMPDIR=/tmp
 cp $R/profiles/pmc_traffic.json $OUT/pmc_traffic.json 2>/dev/null || true
 for N in $CONFIGS; do
   case $N in
-    256)  ARGS="--size 256 --sersic 1 --walkers 4096"; CH=128 ;;
-    512)  ARGS="--size 512 --sersic 2 --walkers 1024"; CH=24 ;;
-    1024) ARGS="--size 1024 --sersic 4 --walkers 256"; CH=6 ;;
-    200)  ARGS="--size 200 --sersic 1 --walkers 4096"; CH=184 ;;
-    300)  ARGS="--size 300 --sersic 1 --walkers 2048"; CH=80 ;;
+    # CH = walkers per launch of the bench's own kernel-profile pass (one pass in flight, the library's
+    # own pass size): batch / passes
+    256)  ARGS="--size 256 --sersic 1 --walkers 4096"; CH=110.7027 ;;     # 4096 / 37
+    512)  ARGS="--size 512 --sersic 2 --walkers 1024"; CH=23.8140 ;;      # 1024 / 43
+    1024) ARGS="--size 1024 --sersic 4 --walkers 256"; CH=5.9535 ;;       # 256 / 43
+    200)  ARGS="--size 200 --sersic 1 --walkers 4096"; CH=178.0870 ;;     # 4096 / 23
+    300)  ARGS="--size 300 --sersic 1 --walkers 2048"; CH=78.7692 ;;      # 2048 / 26
     *) echo "unknown config $N"; exit 1 ;;
   esac
   COMMON="$ARGS --no-cpu --no-example --no-extras"
@@ -33,10 +35,10 @@ for N in $CONFIGS; do
   #     bench's in-library HIP-event pass (roofline object) measures
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats_${N}_s1 -- python3 $R/bench.py $COMMON --steps 5 --warmup 2 --opt streams=1 > /dev/null 2>&1
   cp $R/gpurun_out/${TAG}_stats_${N}_s1/*/*kernel_stats.csv $OUT/${TAG}_kernel_stats_${N}_streams1.csv
-  # (3) PMC passes (own runs, no trace domains), one pass in flight, CH walkers per launch
+  # (3) PMC passes (own runs, no trace domains), one pass in flight at the library's own pass size: the
+  #     launches the bench's roofline object times (CH walkers per launch on average)
   cd $R
-  tools/prof_pmc.sh ${TAG}_pmc_$N $COMMON --batches 1 --opt streams=1 --chunk $CH > $OUT/${TAG}_pmc_${N}_summary.txt 2>&1
-  for n in sq1 sq2 fetch write rdreq wrreq; do cp gpurun_out/${TAG}_pmc_$N/$n/*/*counter_collection.csv $OUT/${TAG}_pmc_${N}_${n}_counter_collection.csv 2>/dev/null || true; done
+  tools/prof_pmc.sh ${TAG}_pmc_$N $COMMON --batches 1 --opt streams=1 > $OUT/${TAG}_pmc_${N}_summary.txt 2>&1
   python3 tools/pmc_to_json.py gpurun_out/${TAG}_pmc_$N $N $CH $OUT/pmc_traffic.json > /dev/null
   echo "config $N done"
 done
@@ -45,7 +47,7 @@ cp $OUT/pmc_traffic.json $R/profiles/pmc_traffic.json
 cd $R
 for N in $CONFIGS; do
   case $N in
-    256)  python3 bench.py > $OUT/${TAG}_bench.json 2>$OUT/${TAG}_bench.err ;;
+    256)  python3 bench.py > $OUT/${TAG}_bench.json 2>$OUT/${TAG}_bench.err ;;   # (the default line, CPU legs included)
     512)  python3 bench.py --size 512 --sersic 2 --walkers 1024 --no-example --cpu-seconds 6 > $OUT/${TAG}_bench_512.json 2>$OUT/${TAG}_bench_512.err ;;
     1024) python3 bench.py --size 1024 --sersic 4 --walkers 256 --no-example --cpu-seconds 6 --cpu-procs 0 > $OUT/${TAG}_bench_1024.json 2>$OUT/${TAG}_bench_1024.err ;;
     200)  python3 bench.py --size 200 --sersic 1 --walkers 4096 --no-example --cpu-seconds 6 --cpu-procs 0 > $OUT/${TAG}_bench_200.json 2>$OUT/${TAG}_bench_200.err ;;
@@ -65,3 +67,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_sam
 cp $R/gpurun_out/${TAG}_sampler/s256_kernel_stats.csv $OUT/${TAG}_sampler_256_kernel_stats.csv 2>/dev/null || true
 cd $R
 cat $OUT/${TAG}_small_ensemble_timeline.txt
+# only the summaries travel back (gpurun merges at most 64 MiB; the raw traces are hundreds)
+rm -rf $R/gpurun_out/${TAG}_stats_* $R/gpurun_out/${TAG}_pmc_* $R/gpurun_out/${TAG}_small $R/gpurun_out/${TAG}_sampler
