@@ -221,6 +221,27 @@ def sweep_ceiling(engine, device, nbytes, walkers, rate_gpu, reps=20):
     return out
 
 
+def valu_ceiling(engine, device, table, walkers, rate_gpu, n_simd):
+    """The other ceiling: the vector-instruction issue rate of THIS chip with every SIMD busy (psfmc_debug_valu_rate:
+    64 v_fma_f64 per loop iteration, two waves per SIMD, HIP events) times the vector wave-instructions the three
+    kernels issue per walker (SQ_INSTS_VALU of the committed PMC passes, profiles/pmc_traffic.json).  With two and
+    four Sersic components the 512^2 / 1024^2 passes carry more VALU time than sweep time."""
+    per_walker = [rec.get('valu_wave_instructions_per_walker') for name, rec in table.items()
+                  if name.startswith(('k_rows_fwd<', 'k_cols', 'k_rows_inv<'))]
+    if len(per_walker) != 3 or not all(per_walker):
+        return None
+    ns = engine.debug_valu_rate(2, 20000, device)
+    instr = float(sum(per_walker))
+    floor_us = instr * walkers * ns / n_simd / 1e3
+    step_us = walkers / rate_gpu * 1e6
+    return {'ns_per_fp64_wave_instruction_per_simd': ns, 'valu_wave_instructions_per_walker': instr,
+            'simds': n_simd, 'walkers_per_pass': walkers, 'pass_floor_us': floor_us, 'step_us_per_pass': step_us,
+            'step_over_valu_floor': step_us / floor_us,
+            'note': 'fp64 vector issue rate measured on every SIMD of the chip at two waves per SIMD x the PMC '
+                    'instruction counts of the three kernels; a floor only if the instruction mix issued like v_fma_f64 '
+                    '(v_rcp_f64 takes 4x as long)'}
+
+
 def small_ensembles(eng, args, torch, dev, theta_dev, out_dev, stream):
     """Half-steps of the reference's default ensembles (chains = 2 P + 2, psfMC/fitting.py:
     52-53 -> 11 and 19 walkers per half-step for 10 / 18 parameters) and a few more: device
@@ -769,6 +790,12 @@ def main():
                 t_bytes = 2 * (args.size // 2 + 1) * args.size * 16
                 from psfmc_amd import engine as engine_mod
                 line['sweep_ceiling'] = sweep_ceiling(engine_mod, local, t_bytes * per_pass, per_pass, rate_gpu)
+                n_simd = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+                vc = valu_ceiling(engine_mod, local, table, per_pass, rate_gpu, n_simd)
+                if vc:
+                    vc['step_over_larger_floor'] = vc['step_us_per_pass'] / max(vc['pass_floor_us'],
+                                                                               line['sweep_ceiling']['pass_floor_us'])
+                    line['valu_ceiling'] = vc
             if args.backend == 'fused' and args.size in (64, 128, 256, 512, 1024):
                 # opt-in storage mode, NOT the headline: complex64 half-spectra between the kernels,
                 # fp64 arithmetic (include/psfmc_hip.h "storage_f32")

@@ -345,6 +345,9 @@ int psfmc_debug_math(int device, int op, int n, const double* in, double* out);
  * bench.py reports them beside the timed step ("sweep_ceiling").
  */
 int psfmc_debug_sweep(int device, int mode, size_t nbytes, int reps, double* us_per_sweep);
+/* measurement hook: nanoseconds per fp64 vector wave-instruction per SIMD with `waves_per_simd` waves on every
+ * SIMD of the chip (64 v_fma_f64 per loop iteration): the VALU ceiling next to psfmc_debug_sweep's memory one */
+int psfmc_debug_valu_rate(int device, int waves_per_simd, int iters, double* ns_per_instruction);
 
 /* message of the last failing call on this thread ("" if none) */
 const char* psfmc_last_error(void);

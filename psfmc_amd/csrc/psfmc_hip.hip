@@ -2683,6 +2683,58 @@ extern "C" int psfmc_debug_sweep(int device, int mode, size_t nbytes, int reps, 
     return rc;
 }
 
+// ---------------------------------------------------------------------------
+// diagnostic: the rate at which THIS chip issues fp64 vector instructions when every SIMD is busy -- the
+// other ceiling of the path besides the memory sweeps (psfmc_debug_sweep): with two and four Sersic components
+// the 512^2 / 1024^2 passes carry more VALU time than sweep time.  64 v_fma_f64 per loop iteration (8 chains
+// x 8, inline asm), `waves` waves per SIMD on every CU, timed with HIP events: nanoseconds per wave-instruction
+// per SIMD.  (tools/clock_probe.hip is the stand-alone version with the in-kernel clock.)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_valu_rate(double* __restrict__ out, int iters) {
+    double a[8];
+    for (int i = 0; i < 8; ++i) a[i] = 1.0 + 1e-9 * (threadIdx.x + i);
+    double m = 1.0000001, c = 1e-12;
+    asm volatile("" : "+v"(m), "+v"(c));
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int rep = 0; rep < 8; ++rep)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+    }
+    double acc = 0.0;
+    for (int i = 0; i < 8; ++i) acc += a[i];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
+extern "C" int psfmc_debug_valu_rate(int device, int waves_per_simd, int iters, double* ns_per_instruction) {
+    if (waves_per_simd < 1 || waves_per_simd > 8 || iters < 1 || !ns_per_instruction) return fail(PSFMC_EINVAL, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    const int blocks = prop.multiProcessorCount * waves_per_simd;        // 4 waves per block: one per SIMD
+    double* out = nullptr;
+    HIP_TRY(hipMalloc(&out, (size_t)blocks * 256 * sizeof(double)));
+    int rc = PSFMC_OK;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+        rc = fail(PSFMC_ENOMEM, "hipEventCreate");
+    } else {
+        hipLaunchKernelGGL(k_valu_rate, dim3(blocks), dim3(256), 0, 0, out, iters);          // warm-up (clocks settle)
+        (void)hipEventRecord(a, 0);
+        hipLaunchKernelGGL(k_valu_rate, dim3(blocks), dim3(256), 0, 0, out, iters);
+        (void)hipEventRecord(b, 0);
+        float ms = 0.f;
+        if (hipEventSynchronize(b) != hipSuccess || hipEventElapsedTime(&ms, a, b) != hipSuccess)
+            rc = fail(PSFMC_EHIP, "rate probe failed: %s", hipGetErrorString(hipGetLastError()));
+        // every SIMD issued waves_per_simd x iters x 64 wave-instructions
+        *ns_per_instruction = (double)ms * 1e6 / ((double)waves_per_simd * iters * 64.0);
+    }
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+    (void)hipFree(out);
+    return rc;
+}
+
 extern "C" int psfmc_debug_math(int device, int op, int n, const double* in, double* out) {
     if (n < 0 || op < 0 || op > 6 || (n > 0 && (!in || !out))) return fail(PSFMC_EINVAL, "bad argument");
     if (n == 0) return PSFMC_OK;

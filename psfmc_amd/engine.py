@@ -199,6 +199,8 @@ def load_library():
     lib.psfmc_debug_math.argtypes = [ci, ci, ci, _c_double_p, _c_double_p]
     lib.psfmc_debug_sweep.restype = ci
     lib.psfmc_debug_sweep.argtypes = [ci, ci, ctypes.c_size_t, ci, _c_double_p]
+    lib.psfmc_debug_valu_rate.restype = ci
+    lib.psfmc_debug_valu_rate.argtypes = [ci, ci, ci, _c_double_p]
     if lib.psfmc_abi_version() != 1:
         raise ImportError('libpsfmc_hip ABI version mismatch')
     _lib = lib
@@ -236,6 +238,17 @@ def debug_sweep(mode, nbytes, reps=20, device=0):
     if rc != 0:
         raise NativeError(rc, lib.psfmc_last_error().decode('utf-8', 'replace'))
     return us.value
+
+
+def debug_valu_rate(waves_per_simd=2, iters=20000, device=0):
+    """Nanoseconds per fp64 vector wave-instruction per SIMD with every SIMD of the chip busy
+    (psfmc_debug_valu_rate): the VALU ceiling of the path on this GPU, measured."""
+    lib = load_library()
+    out = ctypes.c_double(0.0)
+    rc = lib.psfmc_debug_valu_rate(int(device), int(waves_per_simd), int(iters), ctypes.byref(out))
+    if rc != 0:
+        raise NativeError(rc, lib.psfmc_last_error().decode('utf-8', 'replace'))
+    return float(out.value)
 
 
 class Context(object):

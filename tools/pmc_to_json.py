@@ -38,6 +38,7 @@ fetch = per_kernel('fetch', 'FETCH_SIZE')
 write = per_kernel('write', 'WRITE_SIZE')
 rd = {c: optional('rdreq', 'TCC_EA0_RDREQ' + c + '_sum') for c in ('', '_32B', '_64B', '_128B')}
 wr = {c: optional('wrreq', 'TCC_EA0_WRREQ' + c + '_sum') for c in ('', '_64B')}
+valu = optional('sq2', 'SQ_INSTS_VALU')          # vector wave-instructions per launch
 table = {}
 for k in sorted(set(fetch) | set(write)):
     if not any(s in k for s in ('k_rows_fwd<%d, false' % side, 'k_cols<%d, true' % side,
@@ -47,6 +48,8 @@ for k in sorted(set(fetch) | set(write)):
     table[k] = {'FETCH_SIZE_KiB_per_launch': f_kib, 'WRITE_SIZE_KiB_per_launch': w_kib,
                 'walkers_per_launch': walkers,
                 'hbm_bytes_per_walker': (2.0 * f_kib + w_kib) * 1024.0 / walkers}
+    if k in valu:
+        table[k]['valu_wave_instructions_per_walker'] = valu[k] / walkers
     if k in rd['']:
         # exact request sizes (cross-check of the x2 rule): requests not tallied as 32- / 64- /
         # 128-byte ones are taken as 64-byte
