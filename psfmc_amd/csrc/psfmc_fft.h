@@ -753,4 +753,135 @@ __device__ __forceinline__ void fft_wave3(cd (&v)[Fft3Shape<N>::R1], const cd (&
     }
 }
 
+// ---------------------------------------------------------------------------
+// The wave-wide three-stage transform for ANY N = R1 * 64 (round 3: R1 = 9 ... 15, the sides 576, 640, 704,
+// 768, 832, 896, 960, whose columns ran on the two-stage engine at 24 ... 32 complex registers per lane and one
+// wave per SIMD).  Same scheme as fft_wave3: lane t = 8 n2 + n3 holds v[a] = x[64 a + t] (a < R1) on entry;
+//   stage 1  radix-R1 over a, twiddle W_N^(t k1);        exchange E1[k1][t]
+//   stage 2  8 R1 radix-8 transforms over n2 on 64 lanes: lane (g = t >> 3, n3) takes k1 = g + 8 i, i < NB =
+//            ceil(R1 / 8), where k1 < R1; twiddle W_64^(n3 k2);   exchange E2[k2][n3][k1]
+//   stage 3  8 R1 radix-8 transforms over n3: lane t takes c = t + 64 q = k1 + R1 k2, q < NB, where c < 8 R1
+// and on exit   o[q][k3] = X[(t + 64 q) + 8 R1 k3]   (valid iff t + 64 q < 8 R1).
+// That is t + 64 e only when 8 divides R1: a caller that transforms again regroups through LDS (fft3g_regroup).
+// ---------------------------------------------------------------------------
+template <int N> struct Fft3gShape {
+    static constexpr int R1 = N / 64, NB = (R1 + 7) / 8, S1 = 72, S2 = R1 | 1;
+    static_assert(N % 64 == 0 && R1 >= 8 && R1 <= 16, "N = R1 * 64, R1 = 8 ... 16");
+};
+template <int N> constexpr int fft3g_lds_doubles() {
+    using S = Fft3gShape<N>;
+    constexpr int a = S::R1 * S::S1, b = 64 * S::S2, c = a > b ? a : b;
+    return c > N ? c : N;                                   // (the regroup needs N)
+}
+template <int N> __device__ __forceinline__ bool fft3g_valid(int t, int q) { return t + 64 * q < 8 * Fft3gShape<N>::R1; }
+template <int N> __device__ __forceinline__ int fft3g_index(int t, int q, int k3) {
+    return t + 64 * q + 8 * Fft3gShape<N>::R1 * k3;
+}
+
+// `w1_lds`: the workgroup's stage-1 twiddle table [k1][t] = W_N^(t k1) in LDS; w2[k2] = W_N^(R1 n3 k2)
+template <int N, int SIGN>
+__device__ __forceinline__ void fft_wave3g(cd (&v)[Fft3gShape<N>::R1], cd (&o)[Fft3gShape<N>::NB][8], const cd (&w2)[8],
+                                           int t, double* __restrict__ lds, const cd* __restrict__ w1_lds) {
+    using S = Fft3gShape<N>;
+    constexpr int R1 = S::R1, NB = S::NB, S1 = S::S1, S2 = S::S2;
+    const int n3 = t & 7, g = t >> 3;
+    Dft<R1, SIGN>::run(v);
+#pragma unroll
+    for (int k = 1; k < R1; ++k) {
+        const cd wk = w1_lds[k * 64 + t];
+        v[k] = cmul(v[k], SIGN < 0 ? wk : cconj(wk));
+    }
+    cd z[NB][8];
+    int k1s[NB];
+    bool ok2[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        ok2[i] = g + 8 * i < R1;
+        k1s[i] = ok2[i] ? g + 8 * i : 0;                       // an idle slot works on a valid row and is never stored
+    }
+#pragma unroll
+    for (int k = 0; k < R1; ++k) lds[k * S1 + t] = v[k].x;
+    wave_lds_sync();
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int n2 = 0; n2 < 8; ++n2) z[i][n2].x = lds[k1s[i] * S1 + n2 * 8 + n3];
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < R1; ++k) lds[k * S1 + t] = v[k].y;
+    wave_lds_sync();
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int n2 = 0; n2 < 8; ++n2) z[i][n2].y = lds[k1s[i] * S1 + n2 * 8 + n3];
+    wave_lds_sync();
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        Dft<8, SIGN>::run(z[i]);
+#pragma unroll
+        for (int k2 = 1; k2 < 8; ++k2) z[i][k2] = cmul(z[i][k2], SIGN < 0 ? w2[k2] : cconj(w2[k2]));
+    }
+    int k1o[NB], k2o[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        const int c = fft3g_valid<N>(t, q) ? t + 64 * q : 0;
+        k1o[q] = c % R1;
+        k2o[q] = c / R1;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+        if (ok2[i]) {
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) lds[(k2 * 8 + n3) * S2 + k1s[i]] = z[i][k2].x;
+        }
+    wave_lds_sync();
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+#pragma unroll
+        for (int m = 0; m < 8; ++m) o[q][m].x = lds[(k2o[q] * 8 + m) * S2 + k1o[q]];
+    wave_lds_sync();
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+        if (ok2[i]) {
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) lds[(k2 * 8 + n3) * S2 + k1s[i]] = z[i][k2].y;
+        }
+    wave_lds_sync();
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+#pragma unroll
+        for (int m = 0; m < 8; ++m) o[q][m].y = lds[(k2o[q] * 8 + m) * S2 + k1o[q]];
+    wave_lds_sync();
+#pragma unroll
+    for (int q = 0; q < NB; ++q) Dft<8, SIGN>::run(o[q]);
+}
+
+// output order of fft_wave3g -> its input order (v[a] = X[64 a + t]), through the wave's LDS region, one
+// component at a time
+template <int N>
+__device__ __forceinline__ void fft3g_regroup(const cd (&o)[Fft3gShape<N>::NB][8], cd (&v)[Fft3gShape<N>::R1], int t,
+                                              double* __restrict__ lds) {
+    using S = Fft3gShape<N>;
+#pragma unroll
+    for (int q = 0; q < S::NB; ++q)
+        if (fft3g_valid<N>(t, q)) {
+#pragma unroll
+            for (int k3 = 0; k3 < 8; ++k3) lds[fft3g_index<N>(t, q, k3)] = o[q][k3].x;
+        }
+    wave_lds_sync();
+#pragma unroll
+    for (int a = 0; a < S::R1; ++a) v[a].x = lds[64 * a + t];
+    wave_lds_sync();
+#pragma unroll
+    for (int q = 0; q < S::NB; ++q)
+        if (fft3g_valid<N>(t, q)) {
+#pragma unroll
+            for (int k3 = 0; k3 < 8; ++k3) lds[fft3g_index<N>(t, q, k3)] = o[q][k3].y;
+        }
+    wave_lds_sync();
+#pragma unroll
+    for (int a = 0; a < S::R1; ++a) v[a].y = lds[64 * a + t];
+    wave_lds_sync();
+}
+
 }  // namespace psfmc

@@ -589,6 +589,79 @@ k_cols3(TS* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restri
 }
 
 // ---------------------------------------------------------------------------
+// cols3g: the column kernel of ny = 576 ... 960 in steps of 64 (R1 = ny / 64 = 9 ... 15) on the general
+// wave-wide three-stage engine (psfmc_fft.h fft_wave3g): one wave per column, 4 waves per workgroup,
+// persistent.  (Round 2 ran these on the two-stage engine: 24 ... 32 complex registers per lane, one wave per
+// SIMD, 1.7 ... 2.9 TB/s.)  The forward transform leaves X[(t + 64 q) + 8 R1 k3] in register (q, k3): the
+// kernel spectrum is indexed by that k, the regroup in front of the inverse transform goes through LDS, and
+// the inverse transform's output lands at row (t + 64 q) + 8 R1 k3 -- consecutive lanes, consecutive rows.
+// ---------------------------------------------------------------------------
+template <int NY> constexpr size_t fused_col3g_lds_bytes() {
+    return ((size_t)(kColThreads / 64) * fft3g_lds_doubles<NY>() + (size_t)Fft3gShape<NY>::R1 * 64 * 2) * sizeof(double);
+}
+template <int NY> constexpr bool cols3g_side() { return NY % 64 == 0 && NY > 512 && NY < 1024; }
+
+template <int NY, bool CONVOLVE>
+__global__ void __launch_bounds__(kColThreads, 2)
+k_cols3g(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restrict__ prep,
+         const uint8_t* __restrict__ skip, const cd* __restrict__ twy, int plen, int nxh, int n_w, int rg_log2) {
+    using S = Fft3gShape<NY>;
+    constexpr int R1 = S::R1, NB = S::NB, WPB = kColThreads / 64;
+    extern __shared__ __align__(16) double smem[];
+#if PSFMC_COLS_PRIO
+    __builtin_amdgcn_s_setprio(PSFMC_COLS_PRIO);
+#endif
+    const int t = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* lds = smem + (size_t)wave * fft3g_lds_doubles<NY>();
+    cd* tab = reinterpret_cast<cd*>(smem + (size_t)WPB * fft3g_lds_doubles<NY>());
+    for (int i = threadIdx.x; i < R1 * 64; i += kColThreads) tab[i] = twy[(i & 63) * (i >> 6)];
+    __syncthreads();                                   // once, before any wave can leave
+    cd w2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w2[k] = twy[R1 * (t & 7) * k];
+    const int rg_mask = (1 << rg_log2) - 1;
+    auto row_off = [&](int y) -> int { return 2 * y - (y & rg_mask); };      // element offset of row y in a column
+    const int n_cols = n_w * 2 * nxh;
+    const int nyp = t_col_len(NY, rg_log2);
+    const GroupRange gr = xcd_group_range((n_cols + WPB - 1) / WPB);
+    for (int grp = gr.first; grp < gr.end; grp += gr.step) {
+        const int col = grp * WPB + wave;
+        if (col >= n_cols) continue;                     // wave-uniform
+        const int pr = col >> 1, c = col & 1;           // kx * n_w + walker, component
+        const int kx = pr / n_w, w = pr - kx * n_w;
+        const bool skipped = skip && skip[w];            // wave-uniform; tested once the column's loads are issued
+        cd* base = Tbuf + ((size_t)w * nxh + kx) * 2 * nyp + (c << rg_log2);
+        cd v[R1];
+#pragma unroll
+        for (int a = 0; a < R1; ++a) v[a] = load_stream(base + row_off(64 * a + t));
+        if (skipped) continue;
+        cd o[NB][8];
+        fft_wave3g<NY, -1>(v, o, w2, t, lds, tab);
+        if constexpr (CONVOLVE) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int psf = (int)prep[(size_t)w * plen + kPrepPsfIdx];
+            const cd* k = Kt + (((size_t)psf * nxh + kx) * 2 + c) * NY;
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const bool ok = fft3g_valid<NY>(t, q);
+#pragma unroll
+                for (int k3 = 0; k3 < 8; ++k3) o[q][k3] = cmul(o[q][k3], k[ok ? fft3g_index<NY>(t, q, k3) : 0]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            fft3g_regroup<NY>(o, v, t, lds);
+            fft_wave3g<NY, +1>(v, o, w2, t, lds, tab);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+            if (fft3g_valid<NY>(t, q)) {
+#pragma unroll
+                for (int k3 = 0; k3 < 8; ++k3) base[row_off(fft3g_index<NY>(t, q, k3))] = o[q][k3];
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // rows_inv.  grid (ny / RG, n_walkers); one wave per workgroup.
 // partial[w][yg] = sum over the wave's good pixels of the chi^2 term.
 // conv_out / var_out (optional): [n][ny][nx] images (psfmc_eval_images)

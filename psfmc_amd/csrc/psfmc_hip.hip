@@ -485,6 +485,23 @@ static int launch_cols(psfmc_ctx* c, void* Tvoid, int n_w, const double* prep, c
             return PSFMC_OK;
         }
     }
+    if constexpr (cols3g_side<NY>() && sizeof(TS) == sizeof(cd)) {   // multiples of 64 between 512 and 1024: general three-stage engine
+        if (c->cols3) {
+            constexpr size_t lds3 = fused_col3g_lds_bytes<NY>();
+            static thread_local int attr3_device = -1;
+            if (attr3_device != c->device) {
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cols3g<NY, CONVOLVE>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+                attr3_device = c->device;
+            }
+            const int per_block = kColThreads / 64;
+            const int blocks = (n_cols + per_block - 1) / per_block;
+            const int grid3 = blocks < 4 * c->cols_grid ? blocks : 4 * c->cols_grid;
+            hipLaunchKernelGGL((k_cols3g<NY, CONVOLVE>), dim3(grid3), dim3(kColThreads), lds3, st, Tbuf, c->d_Kt, prep,
+                               skip, c->d_twy, c->plen, c->nxh, n_w, c->rg_log2);
+            return PSFMC_OK;
+        }
+    }
     constexpr size_t lds = fused_col_lds_bytes<NY>();
     static thread_local int attr_device = -1;          // raise the dynamic-LDS limit once per device
     if (attr_device != c->device) {
