@@ -165,6 +165,11 @@ def build_problem(args, device, seed=0):
     return model, draw_theta(args, fld, args.walkers), fld
 
 
+def engine_mod_column_engine(n):
+    from psfmc_amd.engine import column_engine
+    return column_engine(n)[0]
+
+
 def kernel_profile(eng, args, one_batch, torch, dev, reps):
     """Per-kernel device time from HIP events recorded inside the library around
     every launch (set_option 'profile').  Run with ONE pass in flight so that a
@@ -175,7 +180,7 @@ def kernel_profile(eng, args, one_batch, torch, dev, reps):
     t_bytes = 2 * nxh * n * 16                  # transposed half-spectra of one walker
     designed = {'rows_fwd': t_bytes, 'cols': 2 * t_bytes, 'rows_inv': t_bytes}
     names = {'rows_fwd': 'k_rows_fwd<%d, false>' % n, 'rows_inv': 'k_rows_inv<%d>' % n,
-             'cols': ('k_cols3<%d, true>' if n in (512, 1024) else 'k_cols<%d, true>') % n}
+             'cols': '%s<%d, true>' % (engine_mod_column_engine(n), n)}
     streams = eng.get_option('streams')
     eng.set_option('streams', 1)
     eng.set_option('profile', 1)

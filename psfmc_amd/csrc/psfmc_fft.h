@@ -754,133 +754,250 @@ __device__ __forceinline__ void fft_wave3(cd (&v)[Fft3Shape<N>::R1], const cd (&
 }
 
 // ---------------------------------------------------------------------------
-// The wave-wide three-stage transform for ANY N = R1 * 64 (round 3: R1 = 9 ... 15, the sides 576, 640, 704,
-// 768, 832, 896, 960, whose columns ran on the two-stage engine at 24 ... 32 complex registers per lane and one
-// wave per SIMD).  Same scheme as fft_wave3: lane t = 8 n2 + n3 holds v[a] = x[64 a + t] (a < R1) on entry;
+// The wave-wide three-stage transform for N = R1 * R2 * R3 on L = R2 * R3 <= 64 lanes of a wave (round 3: the
+// columns of every built side above 512, which ran on the two-stage engine at 20 ... 32 complex registers per
+// lane and one wave per SIMD).  Same scheme as fft_wave3: lane t = R3 n2 + n3 (t < L) holds v[a] = x[L a + t]
+// (a < R1) on entry;
 //   stage 1  radix-R1 over a, twiddle W_N^(t k1);        exchange E1[k1][t]
-//   stage 2  8 R1 radix-8 transforms over n2 on 64 lanes: lane (g = t >> 3, n3) takes k1 = g + 8 i, i < NB =
-//            ceil(R1 / 8), where k1 < R1; twiddle W_64^(n3 k2);   exchange E2[k2][n3][k1]
-//   stage 3  8 R1 radix-8 transforms over n3: lane t takes c = t + 64 q = k1 + R1 k2, q < NB, where c < 8 R1
-// and on exit   o[q][k3] = X[(t + 64 q) + 8 R1 k3]   (valid iff t + 64 q < 8 R1).
-// That is t + 64 e only when 8 divides R1: a caller that transforms again regroups through LDS (fft3g_regroup).
+//   stage 2  R1 R3 radix-R2 transforms over n2: lane (g = t / R3, n3) takes k1 = g + R2 i, i < NB2 =
+//            ceil(R1 / R2), where k1 < R1; twiddle W_L^(n3 k2);   exchange E2[k2][n3][k1]
+//   stage 3  R1 R2 radix-R3 transforms over n3 on all 64 lanes: lane t takes c = t + 64 q = k1 + R1 k2,
+//            q < NB3 = ceil(R1 R2 / 64), where c < R1 R2
+// and on exit   o[q][k3] = X[(t + 64 q) + R1 R2 k3]   (valid iff t + 64 q < R1 R2).
+// A caller that transforms again regroups through LDS (fft3g_regroup).
 // ---------------------------------------------------------------------------
-template <int N> struct Fft3gShape {
-    static constexpr int R1 = N / 64, NB = (R1 + 7) / 8, S1 = 72, S2 = R1 | 1;
-    static_assert(N % 64 == 0 && R1 >= 8 && R1 <= 16, "N = R1 * 64, R1 = 8 ... 16");
-};
-template <int N> constexpr int fft3g_lds_doubles() {
-    using S = Fft3gShape<N>;
-    constexpr int a = S::R1 * S::S1, b = 64 * S::S2, c = a > b ? a : b;
-    return c > N ? c : N;                                   // (the regroup needs N)
+struct Fft3gPick { int r2, r3; };
+// The shape of a side, {0, 0} = none (its columns stay on the two-stage engine).  Empirical: every candidate
+// factorisation was timed against the two-stage kernel on an MI355X (tools/cols3g_shapes.hip;
+// profiles/r3_cols3g_shapes.txt).  What wins: R2 = 4 (stage 2 is then NB2 = R1 / 4 cheap radix-4 passes and stage 3
+// one radix-R3 pass, R3 <= 15: the widest stage holds max(R1, R3) complex registers) or 8 x 8 on all 64 lanes;
+// R3 = 16 and the 5 x 10 / 10 x 5 splits of 50 lanes (650, 700, 800) lose to the two-stage kernel, as does
+// every side whose two-stage shape has T <= 21 lanes per transform (the small sides).
+constexpr Fft3gPick fft3g_pick(int n) {
+    switch (n) {
+        case 264: case 308: case 352: case 484: return {4, 11};
+        case 384: case 528: case 576: return {4, 12};
+        case 312: case 364: case 416: case 520: case 572: case 624: case 676: case 780: return {4, 13};
+        case 392: case 504: case 560: case 616: case 672: case 728: case 784: case 840: case 896: return {4, 14};
+        case 480: case 900: return {4, 15};
+        case 448: return {4, 16};
+        case 440: return {5, 11};
+        case 500: return {5, 10};
+        case 600: case 660: case 720: return {5, 12};
+        case 512: case 640: case 704: case 768: case 832: case 960: case 1024: return {8, 8};
+        default: return {0, 0};
+    }
 }
-template <int N> __device__ __forceinline__ bool fft3g_valid(int t, int q) { return t + 64 * q < 8 * Fft3gShape<N>::R1; }
-template <int N> __device__ __forceinline__ int fft3g_index(int t, int q, int k3) {
-    return t + 64 * q + 8 * Fft3gShape<N>::R1 * k3;
+template <int N, int R2_ = fft3g_pick(N).r2, int R3_ = fft3g_pick(N).r3> struct Fft3gShape {
+    static constexpr bool kBuilt = R2_ > 0;
+    static constexpr int R2 = kBuilt ? R2_ : 1, R3 = kBuilt ? R3_ : 1, L = R2 * R3, R1 = kBuilt ? N / L : 1;
+    static_assert(!kBuilt || (R1 * L == N && L <= 64 && R1 <= 16 && R1 >= 4), "N = R1 R2 R3");
+    static constexpr int NB2 = (R1 + R2 - 1) / R2, NB3 = (R1 * R2 + 63) / 64;
+    static constexpr int S1 = 64 + R3;                      // >= 64 and = R3 (mod 32): stage 2's reads are conflict-free
+    static constexpr int S2 = R1 | 1;
+};
+template <class S> constexpr int fft3g_lds_doubles() {
+    constexpr int a = S::R1 * S::S1, b = S::L * S::S2, c = a > b ? a : b, n = S::R1 * S::L;
+    return c > n ? c : n;                                   // (the regroup needs N)
+}
+template <class S> __device__ __forceinline__ bool fft3g_valid(int t, int q) { return t + 64 * q < S::R1 * S::R2; }
+template <class S> __device__ __forceinline__ int fft3g_index(int t, int q, int k3) {
+    return t + 64 * q + S::R1 * S::R2 * k3;
 }
 
-// `w1_lds`: the workgroup's stage-1 twiddle table [k1][t] = W_N^(t k1) in LDS; w2[k2] = W_N^(R1 n3 k2)
-template <int N, int SIGN>
-__device__ __forceinline__ void fft_wave3g(cd (&v)[Fft3gShape<N>::R1], cd (&o)[Fft3gShape<N>::NB][8], const cd (&w2)[8],
-                                           int t, double* __restrict__ lds, const cd* __restrict__ w1_lds) {
-    using S = Fft3gShape<N>;
-    constexpr int R1 = S::R1, NB = S::NB, S1 = S::S1, S2 = S::S2;
-    const int n3 = t & 7, g = t >> 3;
+// `w1_lds`: the workgroup's stage-1 twiddle table [k1][t] = W_N^(t k1) in LDS (row stride 64);
+// w2[k2] = W_N^(R1 n3 k2).  Lanes t >= L carry no input; they work in stage 3 only.
+template <class S, int SIGN>
+__device__ __forceinline__ void fft_wave3g(cd (&v)[S::R1], cd (&o)[S::NB3][S::R3], const cd (&w2)[S::R2], int t,
+                                           double* __restrict__ lds, const cd* __restrict__ w1_lds) {
+    constexpr int R1 = S::R1, R2 = S::R2, R3 = S::R3, L = S::L, NB2 = S::NB2, NB3 = S::NB3, S1 = S::S1, S2 = S::S2;
+    const bool lane_in = L == 64 || t < L;
+    const int tl = lane_in ? t : 0;
+    const int n3 = tl % R3, g = tl / R3;
     Dft<R1, SIGN>::run(v);
 #pragma unroll
     for (int k = 1; k < R1; ++k) {
         const cd wk = w1_lds[k * 64 + t];
         v[k] = cmul(v[k], SIGN < 0 ? wk : cconj(wk));
     }
-    cd z[NB][8];
-    int k1s[NB];
-    bool ok2[NB];
+    cd z[NB2][R2];
+    int k1s[NB2];
+    bool ok2[NB2];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        ok2[i] = g + 8 * i < R1;
-        k1s[i] = ok2[i] ? g + 8 * i : 0;                       // an idle slot works on a valid row and is never stored
+    for (int i = 0; i < NB2; ++i) {
+        ok2[i] = lane_in && g + R2 * i < R1;
+        k1s[i] = ok2[i] ? g + R2 * i : 0;                      // an idle slot works on a valid row and is never stored
     }
 #pragma unroll
-    for (int k = 0; k < R1; ++k) lds[k * S1 + t] = v[k].x;
+    for (int k = 0; k < R1; ++k) lds[k * S1 + t] = v[k].x;     // S1 >= 64: lanes t >= L write columns nobody reads
     wave_lds_sync();
 #pragma unroll
-    for (int i = 0; i < NB; ++i)
+    for (int i = 0; i < NB2; ++i)
 #pragma unroll
-        for (int n2 = 0; n2 < 8; ++n2) z[i][n2].x = lds[k1s[i] * S1 + n2 * 8 + n3];
+        for (int n2 = 0; n2 < R2; ++n2) z[i][n2].x = lds[k1s[i] * S1 + n2 * R3 + n3];
     wave_lds_sync();
 #pragma unroll
     for (int k = 0; k < R1; ++k) lds[k * S1 + t] = v[k].y;
     wave_lds_sync();
 #pragma unroll
-    for (int i = 0; i < NB; ++i)
+    for (int i = 0; i < NB2; ++i)
 #pragma unroll
-        for (int n2 = 0; n2 < 8; ++n2) z[i][n2].y = lds[k1s[i] * S1 + n2 * 8 + n3];
+        for (int n2 = 0; n2 < R2; ++n2) z[i][n2].y = lds[k1s[i] * S1 + n2 * R3 + n3];
     wave_lds_sync();
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        Dft<8, SIGN>::run(z[i]);
+    for (int i = 0; i < NB2; ++i) {
+        Dft<R2, SIGN>::run(z[i]);
 #pragma unroll
-        for (int k2 = 1; k2 < 8; ++k2) z[i][k2] = cmul(z[i][k2], SIGN < 0 ? w2[k2] : cconj(w2[k2]));
+        for (int k2 = 1; k2 < R2; ++k2) z[i][k2] = cmul(z[i][k2], SIGN < 0 ? w2[k2] : cconj(w2[k2]));
     }
-    int k1o[NB], k2o[NB];
+    int k1o[NB3], k2o[NB3];
 #pragma unroll
-    for (int q = 0; q < NB; ++q) {
-        const int c = fft3g_valid<N>(t, q) ? t + 64 * q : 0;
+    for (int q = 0; q < NB3; ++q) {
+        const int c = fft3g_valid<S>(t, q) ? t + 64 * q : 0;
         k1o[q] = c % R1;
         k2o[q] = c / R1;
     }
 #pragma unroll
-    for (int i = 0; i < NB; ++i)
+    for (int i = 0; i < NB2; ++i)
         if (ok2[i]) {
 #pragma unroll
-            for (int k2 = 0; k2 < 8; ++k2) lds[(k2 * 8 + n3) * S2 + k1s[i]] = z[i][k2].x;
+            for (int k2 = 0; k2 < R2; ++k2) lds[(k2 * R3 + n3) * S2 + k1s[i]] = z[i][k2].x;
         }
     wave_lds_sync();
 #pragma unroll
-    for (int q = 0; q < NB; ++q)
+    for (int q = 0; q < NB3; ++q)
 #pragma unroll
-        for (int m = 0; m < 8; ++m) o[q][m].x = lds[(k2o[q] * 8 + m) * S2 + k1o[q]];
+        for (int m = 0; m < R3; ++m) o[q][m].x = lds[(k2o[q] * R3 + m) * S2 + k1o[q]];
     wave_lds_sync();
 #pragma unroll
-    for (int i = 0; i < NB; ++i)
+    for (int i = 0; i < NB2; ++i)
         if (ok2[i]) {
 #pragma unroll
-            for (int k2 = 0; k2 < 8; ++k2) lds[(k2 * 8 + n3) * S2 + k1s[i]] = z[i][k2].y;
+            for (int k2 = 0; k2 < R2; ++k2) lds[(k2 * R3 + n3) * S2 + k1s[i]] = z[i][k2].y;
         }
     wave_lds_sync();
 #pragma unroll
-    for (int q = 0; q < NB; ++q)
+    for (int q = 0; q < NB3; ++q)
 #pragma unroll
-        for (int m = 0; m < 8; ++m) o[q][m].y = lds[(k2o[q] * 8 + m) * S2 + k1o[q]];
+        for (int m = 0; m < R3; ++m) o[q][m].y = lds[(k2o[q] * R3 + m) * S2 + k1o[q]];
     wave_lds_sync();
 #pragma unroll
-    for (int q = 0; q < NB; ++q) Dft<8, SIGN>::run(o[q]);
+    for (int q = 0; q < NB3; ++q) Dft<R3, SIGN>::run(o[q]);
 }
 
-// output order of fft_wave3g -> its input order (v[a] = X[64 a + t]), through the wave's LDS region, one
+// The inverse of fft_wave3g as its mirror image (decimation in time against the forward transform's decimation
+// in frequency): it takes the forward transform's OUTPUT layout o[q][k3] = Y[(t + 64 q) + R1 R2 k3] and leaves
+// v[a] = y[L a + t], the forward transform's INPUT layout -- a convolution needs no regrouping between the two
+// (an LDS round trip of the whole column and four barriers, 15 % of the column kernel's time at 512 and 1024).
+//   stage A  radix-R3 over k3 in place, twiddle conj W_N^(n3 c), c = t + 64 q = k1 + R1 k2   (table wB[n3][c])
+//   exchange E2 backwards;  stage B  radix-R2 over k2, twiddle conj W_N^(R3 n2 k1) = conj w1[k1][R3 n2]
+//   exchange E1 backwards;  stage C  radix-R1 over k1.          Unnormalised, like the forward transform.
+template <class S>
+__device__ __forceinline__ void fft_wave3g_inv(cd (&o)[S::NB3][S::R3], cd (&v)[S::R1], int t, double* __restrict__ lds,
+                                               const cd* __restrict__ w1_lds, const cd* __restrict__ wB_lds) {
+    constexpr int R1 = S::R1, R2 = S::R2, R3 = S::R3, L = S::L, NB2 = S::NB2, NB3 = S::NB3, S1 = S::S1, S2 = S::S2;
+    constexpr int M = R1 * R2;
+    const bool lane_in = L == 64 || t < L;
+    const int tl = lane_in ? t : 0;
+    const int n3 = tl % R3, g = tl / R3;
+    int k1o[NB3], k2o[NB3];
+    bool ok3[NB3];
+#pragma unroll
+    for (int q = 0; q < NB3; ++q) {
+        ok3[q] = fft3g_valid<S>(t, q);
+        const int c = ok3[q] ? t + 64 * q : 0;
+        k1o[q] = c % R1;
+        k2o[q] = c / R1;
+        Dft<R3, +1>::run(o[q]);
+#pragma unroll
+        for (int m = 1; m < R3; ++m) o[q][m] = cmul(o[q][m], cconj(wB_lds[m * M + c]));
+    }
+    cd z[NB2][R2];
+    int k1s[NB2];
+    bool ok2[NB2];
+#pragma unroll
+    for (int i = 0; i < NB2; ++i) {
+        ok2[i] = lane_in && g + R2 * i < R1;
+        k1s[i] = ok2[i] ? g + R2 * i : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < NB3; ++q)
+        if (ok3[q]) {
+#pragma unroll
+            for (int m = 0; m < R3; ++m) lds[(k2o[q] * R3 + m) * S2 + k1o[q]] = o[q][m].x;
+        }
+    wave_lds_sync();
+#pragma unroll
+    for (int i = 0; i < NB2; ++i)
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) z[i][k2].x = lds[(k2 * R3 + n3) * S2 + k1s[i]];
+    wave_lds_sync();
+#pragma unroll
+    for (int q = 0; q < NB3; ++q)
+        if (ok3[q]) {
+#pragma unroll
+            for (int m = 0; m < R3; ++m) lds[(k2o[q] * R3 + m) * S2 + k1o[q]] = o[q][m].y;
+        }
+    wave_lds_sync();
+#pragma unroll
+    for (int i = 0; i < NB2; ++i)
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) z[i][k2].y = lds[(k2 * R3 + n3) * S2 + k1s[i]];
+    wave_lds_sync();
+#pragma unroll
+    for (int i = 0; i < NB2; ++i) {
+        Dft<R2, +1>::run(z[i]);
+#pragma unroll
+        for (int n2 = 1; n2 < R2; ++n2) z[i][n2] = cmul(z[i][n2], cconj(w1_lds[k1s[i] * 64 + R3 * n2]));
+    }
+#pragma unroll
+    for (int i = 0; i < NB2; ++i)
+        if (ok2[i]) {
+#pragma unroll
+            for (int n2 = 0; n2 < R2; ++n2) lds[k1s[i] * S1 + n2 * R3 + n3] = z[i][n2].x;
+        }
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < R1; ++k) v[k].x = lds[k * S1 + tl];
+    wave_lds_sync();
+#pragma unroll
+    for (int i = 0; i < NB2; ++i)
+        if (ok2[i]) {
+#pragma unroll
+            for (int n2 = 0; n2 < R2; ++n2) lds[k1s[i] * S1 + n2 * R3 + n3] = z[i][n2].y;
+        }
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < R1; ++k) v[k].y = lds[k * S1 + tl];
+    wave_lds_sync();
+    Dft<R1, +1>::run(v);
+}
+
+// output order of fft_wave3g -> its input order (v[a] = X[L a + t]), through the wave's LDS region, one
 // component at a time
-template <int N>
-__device__ __forceinline__ void fft3g_regroup(const cd (&o)[Fft3gShape<N>::NB][8], cd (&v)[Fft3gShape<N>::R1], int t,
+template <class S>
+__device__ __forceinline__ void fft3g_regroup(const cd (&o)[S::NB3][S::R3], cd (&v)[S::R1], int t,
                                               double* __restrict__ lds) {
-    using S = Fft3gShape<N>;
+    const int tl = (S::L == 64 || t < S::L) ? t : 0;
 #pragma unroll
-    for (int q = 0; q < S::NB; ++q)
-        if (fft3g_valid<N>(t, q)) {
+    for (int q = 0; q < S::NB3; ++q)
+        if (fft3g_valid<S>(t, q)) {
 #pragma unroll
-            for (int k3 = 0; k3 < 8; ++k3) lds[fft3g_index<N>(t, q, k3)] = o[q][k3].x;
+            for (int k3 = 0; k3 < S::R3; ++k3) lds[fft3g_index<S>(t, q, k3)] = o[q][k3].x;
         }
     wave_lds_sync();
 #pragma unroll
-    for (int a = 0; a < S::R1; ++a) v[a].x = lds[64 * a + t];
+    for (int a = 0; a < S::R1; ++a) v[a].x = lds[S::L * a + tl];
     wave_lds_sync();
 #pragma unroll
-    for (int q = 0; q < S::NB; ++q)
-        if (fft3g_valid<N>(t, q)) {
+    for (int q = 0; q < S::NB3; ++q)
+        if (fft3g_valid<S>(t, q)) {
 #pragma unroll
-            for (int k3 = 0; k3 < 8; ++k3) lds[fft3g_index<N>(t, q, k3)] = o[q][k3].y;
+            for (int k3 = 0; k3 < S::R3; ++k3) lds[fft3g_index<S>(t, q, k3)] = o[q][k3].y;
         }
     wave_lds_sync();
 #pragma unroll
-    for (int a = 0; a < S::R1; ++a) v[a].y = lds[64 * a + t];
+    for (int a = 0; a < S::R1; ++a) v[a].y = lds[S::L * a + tl];
     wave_lds_sync();
 }
 

@@ -33,6 +33,10 @@
 #include "psfmc_device.h"
 #include "psfmc_fft.h"
 
+#ifndef PSFMC_COLS3G_MIN
+#define PSFMC_COLS3G_MIN 0        /* sides above this that psfmc_fft.h fft3g_pick lists run their columns on the general three-stage engine */
+#endif
+
 namespace psfmc {
 
 // Autonomous waves per row-kernel workgroup (they take consecutive row groups).  One is
@@ -589,38 +593,48 @@ k_cols3(TS* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restri
 }
 
 // ---------------------------------------------------------------------------
-// cols3g: the column kernel of ny = 576 ... 960 in steps of 64 (R1 = ny / 64 = 9 ... 15) on the general
-// wave-wide three-stage engine (psfmc_fft.h fft_wave3g): one wave per column, 4 waves per workgroup,
-// persistent.  (Round 2 ran these on the two-stage engine: 24 ... 32 complex registers per lane, one wave per
-// SIMD, 1.7 ... 2.9 TB/s.)  The forward transform leaves X[(t + 64 q) + 8 R1 k3] in register (q, k3): the
-// kernel spectrum is indexed by that k, the regroup in front of the inverse transform goes through LDS, and
-// the inverse transform's output lands at row (t + 64 q) + 8 R1 k3 -- consecutive lanes, consecutive rows.
+// cols3g: the column kernel of the sides above 512 on the general wave-wide three-stage engine (psfmc_fft.h
+// fft_wave3g; ny = R1 L with L = R2 R3 <= 64 lanes, R1 <= 16): one wave per column, 4 waves per workgroup,
+// persistent.  (Round 2 ran these on the two-stage engine: 20 ... 32 complex registers per lane, one wave per
+// SIMD, 1.7 ... 2.9 TB/s.)  The forward transform leaves X[(t + 64 q) + R1 R2 k3] in register (q, k3): the
+// kernel spectrum is indexed by that k, and the inverse transform is the forward one's mirror image
+// (fft_wave3g_inv), which takes exactly that layout and returns the column in the layout it was loaded in.
 // ---------------------------------------------------------------------------
-template <int NY> constexpr size_t fused_col3g_lds_bytes() {
-    return ((size_t)(kColThreads / 64) * fft3g_lds_doubles<NY>() + (size_t)Fft3gShape<NY>::R1 * 64 * 2) * sizeof(double);
+template <class S> constexpr size_t fused_col3g_lds_bytes() {
+    return ((size_t)(kColThreads / 64) * fft3g_lds_doubles<S>() + (size_t)S::R1 * 64 * 2 + (size_t)S::R1 * S::L * 2) *
+           sizeof(double);
 }
-template <int NY> constexpr bool cols3g_side() { return NY % 64 == 0 && NY > 512 && NY < 1024; }
+// the row-group size the kernel's affine addressing allows for a side (see in_off)
+template <class S> constexpr bool cols3g_layout_ok(int rg_log2) { return S::L % 4 != 0 || S::L % (1 << rg_log2) == 0; }
+template <int NY> constexpr bool cols3g_side() { return Fft3gShape<NY>::kBuilt && NY > PSFMC_COLS3G_MIN; }
 
-template <int NY, bool CONVOLVE>
+template <int NY, bool CONVOLVE, class S = Fft3gShape<NY>>
 __global__ void __launch_bounds__(kColThreads, 2)
 k_cols3g(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restrict__ prep,
          const uint8_t* __restrict__ skip, const cd* __restrict__ twy, int plen, int nxh, int n_w, int rg_log2) {
-    using S = Fft3gShape<NY>;
-    constexpr int R1 = S::R1, NB = S::NB, WPB = kColThreads / 64;
+    constexpr int R1 = S::R1, R2 = S::R2, R3 = S::R3, L = S::L, NB3 = S::NB3, WPB = kColThreads / 64;
     extern __shared__ __align__(16) double smem[];
 #if PSFMC_COLS_PRIO
     __builtin_amdgcn_s_setprio(PSFMC_COLS_PRIO);
 #endif
     const int t = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double* lds = smem + (size_t)wave * fft3g_lds_doubles<NY>();
-    cd* tab = reinterpret_cast<cd*>(smem + (size_t)WPB * fft3g_lds_doubles<NY>());
-    for (int i = threadIdx.x; i < R1 * 64; i += kColThreads) tab[i] = twy[(i & 63) * (i >> 6)];
+    const bool lane_in = L == 64 || t < L;
+    const int tl = lane_in ? t : 0;
+    double* lds = smem + (size_t)wave * fft3g_lds_doubles<S>();
+    cd* tab = reinterpret_cast<cd*>(smem + (size_t)WPB * fft3g_lds_doubles<S>());
+    cd* tab_b = tab + R1 * 64;                         // the inverse transform's first twiddles [n3][c] = W_N^(n3 c)
+    for (int i = threadIdx.x; i < R1 * 64; i += kColThreads)
+        tab[i] = (i & 63) < L ? twy[(i & 63) * (i >> 6)] : cd{0.0, 0.0};
+    if constexpr (CONVOLVE)
+        for (int i = threadIdx.x; i < NY; i += kColThreads) tab_b[i] = twy[(i / (R1 * R2)) * (i % (R1 * R2))];
     __syncthreads();                                   // once, before any wave can leave
-    cd w2[8];
+    cd w2[R2];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) w2[k] = twy[R1 * (t & 7) * k];
+    for (int k = 0; k < R2; ++k) w2[k] = twy[R1 * (tl % R3) * k];
     const int rg_mask = (1 << rg_log2) - 1;
     auto row_off = [&](int y) -> int { return 2 * y - (y & rg_mask); };      // element offset of row y in a column
+    constexpr bool kAffine = L % 4 == 0;               // (row groups of 4 or, with 8 | L, 8 rows)
+    const int off_t = row_off(tl);
     const int n_cols = n_w * 2 * nxh;
     const int nyp = t_col_len(NY, rg_log2);
     const GroupRange gr = xcd_group_range((n_cols + WPB - 1) / WPB);
@@ -631,33 +645,39 @@ k_cols3g(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restr
         const int kx = pr / n_w, w = pr - kx * n_w;
         const bool skipped = skip && skip[w];            // wave-uniform; tested once the column's loads are issued
         cd* base = Tbuf + ((size_t)w * nxh + kx) * 2 * nyp + (c << rg_log2);
+        // L a + t: with L a multiple of the row group (host-checked, cols3g_layout_ok) the offset is affine in a
+        auto in_off = [&](int a) -> int { return kAffine ? off_t + 2 * L * a : row_off(L * a + tl); };
         cd v[R1];
 #pragma unroll
-        for (int a = 0; a < R1; ++a) v[a] = load_stream(base + row_off(64 * a + t));
+        for (int a = 0; a < R1; ++a) v[a] = load_stream(base + in_off(a));
         if (skipped) continue;
-        cd o[NB][8];
-        fft_wave3g<NY, -1>(v, o, w2, t, lds, tab);
+        cd o[NB3][R3];
+        fft_wave3g<S, -1>(v, o, w2, t, lds, tab);
         if constexpr (CONVOLVE) {
             __builtin_amdgcn_sched_barrier(0);
             const int psf = (int)prep[(size_t)w * plen + kPrepPsfIdx];
             const cd* k = Kt + (((size_t)psf * nxh + kx) * 2 + c) * NY;
 #pragma unroll
-            for (int q = 0; q < NB; ++q) {
-                const bool ok = fft3g_valid<NY>(t, q);
+            for (int q = 0; q < NB3; ++q) {
+                const bool ok = fft3g_valid<S>(t, q);
 #pragma unroll
-                for (int k3 = 0; k3 < 8; ++k3) o[q][k3] = cmul(o[q][k3], k[ok ? fft3g_index<NY>(t, q, k3) : 0]);
+                for (int k3 = 0; k3 < R3; ++k3) o[q][k3] = cmul(o[q][k3], k[ok ? fft3g_index<S>(t, q, k3) : 0]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            fft3g_regroup<NY>(o, v, t, lds);
-            fft_wave3g<NY, +1>(v, o, w2, t, lds, tab);
+            fft_wave3g_inv<S>(o, v, t, lds, tab, tab_b);
             __builtin_amdgcn_sched_barrier(0);
+            if (lane_in) {
+#pragma unroll
+                for (int a = 0; a < R1; ++a) base[in_off(a)] = v[a];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NB3; ++q)
+                if (fft3g_valid<S>(t, q)) {
+#pragma unroll
+                    for (int k3 = 0; k3 < R3; ++k3) base[row_off(fft3g_index<S>(t, q, k3))] = o[q][k3];
+                }
         }
-#pragma unroll
-        for (int q = 0; q < NB; ++q)
-            if (fft3g_valid<NY>(t, q)) {
-#pragma unroll
-                for (int k3 = 0; k3 < 8; ++k3) base[row_off(fft3g_index<NY>(t, q, k3))] = o[q][k3];
-            }
     }
 }
 

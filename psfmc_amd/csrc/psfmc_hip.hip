@@ -1,6 +1,7 @@
 // psfmc_hip.hip -- C ABI of libpsfmc_hip.so (see include/psfmc_hip.h).
 // gfx950 only.  Build: psfmc_amd/csrc/Makefile (hipcc --offload-arch=gfx950).
 #include "../../include/psfmc_hip.h"
+#include "psfmc_side_costs.h"
 
 // The file compiles either as one translation unit (PSFMC_NPARTS undefined: everything) or as
 // PSFMC_NPARTS = 4 of them built in parallel (csrc/Makefile): every part instantiates the per-side
@@ -334,7 +335,7 @@ struct psfmc_ctx {
     bool t_f32 = false;       // T stored as complex64 (set_option "storage_f32"); arithmetic stays fp64
     bool plain_shape = false; // both sides power-of-two shapes (what storage_f32 is built for)
     bool row_fast = false;    // nx a power-of-two shape and ny a whole number of its row workgroups
-    bool cols3 = true;        // ny >= 512: column kernel on the wave-wide three-stage engine
+    int cols3 = 1;            // column kernel on the wave-wide three-stage engines: 0 never, 1 k_cols3 at 512 / 1024 and k_cols3g at the sides of fft3g_pick, 2 k_cols3g at 512 / 1024 as well
     bool use_graph = false;   // psfmc_stretch_run replays a captured iteration (set_option "graph"; measured: no gain,
                               // the iteration is kernel-time- not launch-bound)
     long long graph_launches = 0;
@@ -475,7 +476,7 @@ static int launch_cols(psfmc_ctx* c, void* Tvoid, int n_w, const double* prep, c
     TS* Tbuf = static_cast<TS*>(Tvoid);
     const int n_cols = n_w * 2 * c->nxh;
     if constexpr (NY == 512 || NY == 1024) {          // long power-of-two columns: wave-wide three-stage engine
-        if (c->cols3) {
+        if (c->cols3 == 1 || (c->cols3 && sizeof(TS) != sizeof(cd))) {
             constexpr size_t lds3 = fused_col3_lds_bytes<NY>();
             const int per_block = kColThreads / 64;
             const int blocks = (n_cols + per_block - 1) / per_block;
@@ -485,9 +486,9 @@ static int launch_cols(psfmc_ctx* c, void* Tvoid, int n_w, const double* prep, c
             return PSFMC_OK;
         }
     }
-    if constexpr (cols3g_side<NY>() && sizeof(TS) == sizeof(cd)) {   // multiples of 64 between 512 and 1024: general three-stage engine
-        if (c->cols3) {
-            constexpr size_t lds3 = fused_col3g_lds_bytes<NY>();
+    if constexpr (cols3g_side<NY>() && sizeof(TS) == sizeof(cd)) {   // the sides of psfmc_fft.h fft3g_pick: general three-stage engine
+        if (c->cols3 && cols3g_layout_ok<Fft3gShape<NY>>(c->rg_log2)) {
+            constexpr size_t lds3 = fused_col3g_lds_bytes<Fft3gShape<NY>>();
             static thread_local int attr3_device = -1;
             if (attr3_device != c->device) {
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cols3g<NY, CONVOLVE>),
@@ -987,15 +988,48 @@ static const int kFusedSides[] = {64,84,88,96,98,100,104,110,112,120,126,128,130
 // the filled transform pixels (psfmc_device.h WrapDesc).  The kernel's origin inside the centre-padded
 // PSF, c = m/2 - (m - pk)/2 (utils.py:9-22 + the ifftshift of :32), is the same for every even m, so
 // outputs [a, a + l) of the length-m circular convolution are those of the length-l one when a = pk - 1 - c.
-static bool embed_axis(int l, int pk, int* m, int* a, int* e) {
-    const int need = l + pk - 1;
-    for (int v : kFusedSides)
-        if (v >= need) {
-            const int c = v / 2 - (v - pk) / 2;
-            *m = v; *a = pk - 1 - c; *e = need;
-            return true;
+static void embed_axis_at(int l, int pk, int m, int* a, int* e) {
+    const int c = m / 2 - (m - pk) / 2;
+    *a = pk - 1 - c;
+    *e = l + pk - 1;
+}
+
+// The transform shape of an image with unbuilt sides.  Every built side >= l + pk - 1 would do; the kernels of
+// the built sides differ by up to 2x per pixel (radix mix, lanes per transform, registers), so the smallest
+// is often not the cheapest: the pair (my, mx) with the least ny nx (rows(nx) + cols(ny)) of the measured table
+// psfmc_side_costs.h wins, if it beats the smallest pair by 4 % (the table's noise).  A built axis stays as it is.
+static bool choose_embedding(int ly, int lx, int pky, int pkx, int* my, int* mx) {
+    auto cost_of = [](int side) -> const SideCost* {
+        for (const SideCost& sc : kSideCosts)
+            if (sc.side == side) return &sc;
+        return nullptr;
+    };
+    const bool fix_y = fused_side(ly), fix_x = fused_side(lx);
+    const int need_y = fix_y ? ly : ly + pky - 1, need_x = fix_x ? lx : lx + pkx - 1;
+    int small_y = 0, small_x = 0;
+    for (int v : kFusedSides) {
+        if (!small_y && v >= need_y) small_y = v;
+        if (!small_x && v >= need_x) small_x = v;
+    }
+    if (!small_y || !small_x) return false;
+    *my = small_y; *mx = small_x;
+    const SideCost *sy0 = cost_of(small_y), *sx0 = cost_of(small_x);
+    if (!sy0 || !sx0) return true;
+    const double base = (double)small_y * small_x * (sx0->rows_ps + sy0->cols_ps);
+    double best = base * 0.96;
+    for (int vy : kFusedSides) {
+        if (fix_y ? vy != ly : vy < need_y) continue;
+        const SideCost* sy = cost_of(vy);
+        if (!sy) continue;
+        for (int vx : kFusedSides) {
+            if (fix_x ? vx != lx : vx < need_x) continue;
+            const SideCost* sx = cost_of(vx);
+            if (!sx) continue;
+            const double cst = (double)vy * vx * (sx->rows_ps + sy->cols_ps);
+            if (cst < best) { best = cst; *my = vy; *mx = vx; }
         }
-    return false;
+    }
+    return true;
 }
 
 static int ctx_create_impl(psfmc_ctx** out, int device, int ny, int nx, int n_fields, const double* sci,
@@ -1030,12 +1064,11 @@ static int ctx_create_impl(psfmc_ctx** out, int device, int ny, int nx, int n_fi
             // embed the axes the transforms are not built for (a built axis stays as it is: a = 0, e = l = m)
             embed = true;
             wrap = WrapDesc{lx, 0, lx, ly, 0, ly};
-            if (!fused_side(nx) && !embed_axis(lx, psf_nx, &nx, &wrap.ax, &wrap.ex))
-                return fail(PSFMC_EINVAL, "fused backend: image width %d + PSF width %d - 1 exceeds the largest "
-                            "built side (1024)", lx, psf_nx);
-            if (!fused_side(ny) && !embed_axis(ly, psf_ny, &ny, &wrap.ay, &wrap.ey))
-                return fail(PSFMC_EINVAL, "fused backend: image height %d + PSF height %d - 1 exceeds the largest "
-                            "built side (1024)", ly, psf_ny);
+            if (!choose_embedding(ly, lx, psf_ny, psf_nx, &ny, &nx))
+                return fail(PSFMC_EINVAL, "fused backend: image %d x %d + PSF %d x %d - 1 exceeds the largest built "
+                            "side (1024)", ly, lx, psf_ny, psf_nx);
+            if (nx != lx) embed_axis_at(lx, psf_nx, nx, &wrap.ax, &wrap.ex);
+            if (ny != ly) embed_axis_at(ly, psf_ny, ny, &wrap.ay, &wrap.ey);
             // the field arrays in transform coordinates: the image at (ay, ax), every other pixel excluded
             const size_t S_t = (size_t)ny * nx, S_l = (size_t)ly * lx;
             pad_sci.assign((size_t)n_fields * S_t, 0.0);
@@ -1218,7 +1251,7 @@ extern "C" int psfmc_set_option(psfmc_ctx* c, const char* key, double value) {
         return PSFMC_OK;
     }
     if (!strcmp(key, "cols3")) {
-        c->cols3 = value != 0;
+        c->cols3 = (int)value;
         return PSFMC_OK;
     }
     if (!strcmp(key, "graph")) {
@@ -1259,6 +1292,8 @@ extern "C" double psfmc_get_option(const psfmc_ctx* cc, const char* key) {
         if (!strcmp(key, name)) { prof_collect(c); return (double)c->prof_n[i]; }
     }
     if (!strcmp(key, "row_group")) return 1 << c->rg_log2;
+    if (!strcmp(key, "transform_ny")) return c->ny;        // the transform shape (the image's own, or the one it is embedded in)
+    if (!strcmp(key, "transform_nx")) return c->nx;
     if (!strcmp(key, "partials_per_walker")) return c->nblk;
     if (!strcmp(key, "storage_f32")) return c->t_f32 ? 1.0 : 0.0;
     if (!strcmp(key, "graph_launches")) return (double)c->graph_launches;

@@ -31,11 +31,38 @@ def nearest_fused_sides(n):
     return (below[-1] if below else None), (above[0] if above else None)
 
 
+# psfmc_fft.h fft3g_pick: the sides whose columns run on the general wave-wide three-stage engine, with
+# their (R2, R3) split of the wave's lanes
+_COLS3G_SHAPES = {}
+for _sides, _shape in (((264, 308, 352, 484), (4, 11)), ((384, 528, 576), (4, 12)),
+                       ((312, 364, 416, 520, 572, 624, 676, 780), (4, 13)),
+                       ((392, 504, 560, 616, 672, 728, 784, 840, 896), (4, 14)), ((480, 900), (4, 15)),
+                       ((448,), (4, 16)), ((440,), (5, 11)), ((500,), (5, 10)), ((600, 660, 720), (5, 12)),
+                       ((640, 704, 768, 832, 960), (8, 8))):
+    for _n in _sides:
+        _COLS3G_SHAPES[_n] = _shape
+
+
+def column_engine(ny):
+    """Which column kernel the fused back end launches for transform side `ny` (psfmc_hip.hip
+    launch_cols): 'k_cols3' (512, 1024: the power-of-two wave-wide three-stage engine), 'k_cols3g' (the
+    sides psfmc_fft.h fft3g_pick lists: ny = R1 * R2 * R3 on R2 * R3 <= 64 lanes) or 'k_cols' (the
+    two-stage engine).  Returns (kernel name, (R1, R2, R3) or None)."""
+    if ny in (512, 1024):
+        return 'k_cols3', None
+    if ny in _COLS3G_SHAPES:
+        r2, r3 = _COLS3G_SHAPES[ny]
+        return 'k_cols3g', (ny // (r2 * r3), r2, r3)
+    return 'k_cols', None
+
+
 def embedding_side(side, psf_side):
-    """The transform side an image side the kernels are not built for is EMBEDDED in: the smallest
-    built side >= side + psf_side - 1 (the image, a wrap-around margin of psf_side - 1 pixels, zeros:
-    the circular convolution of that length equals the image's own on the image's pixels --
-    csrc/psfmc_device.h WrapDesc), or None when there is none (side + psf_side - 1 > 1024)."""
+    """The smallest transform side an image side the kernels are not built for can be EMBEDDED in: the
+    smallest built side >= side + psf_side - 1 (the image, a wrap-around margin of psf_side - 1 pixels,
+    zeros: the circular convolution of that length equals the image's own on the image's pixels --
+    csrc/psfmc_device.h WrapDesc), or None when there is none (side + psf_side - 1 > 1024).  The library
+    may pick a LARGER built side whose kernels are cheaper per walker (psfmc_hip.hip choose_embedding,
+    measured table csrc/psfmc_side_costs.h); `Context.get_option('transform_ny' / 'transform_nx')` tells."""
     need = side + psf_side - 1
     fits = [v for v in FUSED_SIDES if v >= need]
     return fits[0] if fits else None

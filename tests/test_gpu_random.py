@@ -240,7 +240,8 @@ def test_general_sides_with_distinct_walkers(n_side):
 # even sides the transforms are NOT built for (prime factors above 13, or no P x T split with P, T <= 32):
 # embedded in the next built side >= side + PSF side - 1 (psfmc_device.h WrapDesc), each axis on its own
 EMBEDDED_SHAPES = [(170, 170), (256, 90), (490, 64), (64, 490), (74, 74), (134, 256), (200, 134), (166, 226),
-                   (238, 340), (68, 1000), (958, 70), (290, 292), (990, 82), (94, 102), (502, 514), (686, 98)]
+                   (238, 340), (68, 1000), (958, 70), (290, 292), (990, 82), (94, 102), (502, 514), (686, 98),
+                   (642, 70), (70, 642)]        # (642: the smallest sides that fit -- 650, 660, 676 -- have slow kernels)
 
 
 @pytest.mark.parametrize('shape', EMBEDDED_SHAPES, ids=lambda s: '%dx%d' % s)
@@ -264,6 +265,12 @@ def test_embedded_sides_match_oracle(shape):
     assert model._backend == 'fused'
     got = model.log_likelihood_batch(theta)
     assert got[0] == got[1] == got[2]
+    # the transform shape: built sides with room for the image and the wrap-around margin -- the smallest
+    # such side or a larger one whose kernels are cheaper (psfmc_hip.hip choose_embedding)
+    for axis, key in ((0, 'transform_ny'), (1, 'transform_nx')):
+        side = int(model.engine.get_option(key))
+        assert side in engine.FUSED_SIDES
+        assert side == shape[axis] or side >= engine.embedding_side(shape[axis], psf_shape[axis])
     ref = build(case, 'hipfft')
     if np.isfinite(want):
         assert abs(got[0] - want) <= 2e-10 * abs(want), (shape, got[0], want)
