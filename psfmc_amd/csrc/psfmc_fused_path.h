@@ -105,6 +105,9 @@ template <int NY> constexpr size_t fused_col_lds_bytes() {
 #define PSFMC_GEN_R_2WAVES 16     /* general shapes with up to this many registers are compiled for 2 waves per SIMD
                                      (20 spills: k_cols<300> 102 us instead of 77, k_cols<320> 88 instead of 53) */
 #endif
+#ifndef PSFMC_GEN_STAGED
+#define PSFMC_GEN_STAGED 1
+#endif
 #ifndef PSFMC_PLAIN_COL_WAVES
 #define PSFMC_PLAIN_COL_WAVES 2
 #endif
@@ -407,6 +410,16 @@ k_cols(TS* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restric
         int w, kx, c;
         bool active;
     };
+    // General shapes: row y = t + c with c a compile-time constant per register (T a on entry, T h + P d on
+    // exit), and y & rg_mask depends on c only through c & 7 (row groups hold at most 8 rows): eight per-lane
+    // byte offsets, formed once, and an immediate per register replace a 64-bit address computation per
+    // element (k_cols<200>: 300 of 3900 vector instructions per pair of columns).
+    unsigned boff[8];
+    if constexpr (!S::kPlain) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) boff[j] = (unsigned)(2 * t - ((t + j) & rg_mask)) * (unsigned)sizeof(TS);
+    }
+    auto gen_off = [&](int c) -> unsigned { return boff[c & 7] + (unsigned)(2 * c) * (unsigned)sizeof(TS); };
     auto load_group = [&](int grp, cd (&dst)[R], Slot& sl) {
         sl.base = locate(grp, sl.w, sl.kx, sl.c, sl.active);
         if constexpr (S::kPlain) {
@@ -415,7 +428,7 @@ k_cols(TS* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restric
             for (int a = 0; a < P; ++a) dst[a] = load_stream(b0 + 2 * T * a);
         } else {
 #pragma unroll
-            for (int a = 0; a < P; ++a) dst[a] = load_stream(sl.base + row_off(T * a + t));
+            for (int a = 0; a < P; ++a) dst[a] = load_stream(at_bytes(sl.base, gen_off(T * a)));
 #pragma unroll
             for (int a = P; a < R; ++a) dst[a] = cd{0.0, 0.0};
         }
@@ -454,7 +467,7 @@ k_cols(TS* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restric
             } else {
 #pragma unroll
                 for (int e = 0; e < R; ++e)
-                    if (fft_slot_valid<NY>(t, e)) sl.base[row_off(fft_k_of<NY>(t, e))] = v[e];
+                    if (fft_slot_valid<NY>(t, e)) *at_bytes(sl.base, gen_off(fft_k_of<NY>(0, e))) = v[e];
             }
         }
     };
@@ -480,6 +493,25 @@ k_cols(TS* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restric
             transform(v, cur, [&] {
                 __builtin_amdgcn_sched_barrier(0);
                 if (grp + gr.step < gr.end) load_raw(grp + gr.step, nxt);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+    } else if constexpr (PF && !S::kPlain && PSFMC_GEN_STAGED) {
+        // general shapes (compiled for one wave per SIMD): ONE working set; the next group waits in a staging
+        // set that is only ever a load's destination and a copy's source, which the register allocator can
+        // keep in accumulation registers at one move per value.  (Two working sets taking turns, as below,
+        // had it shuffle 390 values per column between the two register files at 200: a fifth of the
+        // kernel's vector instructions.)
+        cd v[R], nxt[R];
+        Slot cur{Tbuf, 0, 0, 0, false}, nx{Tbuf, 0, 0, 0, false};
+        if (gr.first < gr.end) load_group(gr.first, nxt, nx);
+        for (int grp = gr.first; grp < gr.end; grp += gr.step) {
+            cur = nx;
+#pragma unroll
+            for (int a = 0; a < R; ++a) v[a] = nxt[a];
+            transform(v, cur, [&] {
+                __builtin_amdgcn_sched_barrier(0);
+                if (grp + gr.step < gr.end) load_group(grp + gr.step, nxt, nx);
                 __builtin_amdgcn_sched_barrier(0);
             });
         }

@@ -24,13 +24,16 @@ for N in $CONFIGS; do
     1024) ARGS="--size 1024 --sersic 4 --walkers 256"; CH=5.9535 ;;       # 256 / 43
     200)  ARGS="--size 200 --sersic 1 --walkers 4096"; CH=178.0870 ;;     # 4096 / 23
     300)  ARGS="--size 300 --sersic 1 --walkers 2048"; CH=78.7692 ;;      # 2048 / 26
-    *) echo "unknown config $N"; exit 1 ;;
+    *)    ARGS="--size $N --sersic 1 --walkers 1024"; CH=0 ;;              # any other side: CH from the bench's own kernel pass (below)
   esac
   COMMON="$ARGS --no-cpu --no-example --no-extras"
   cd /tmp
   # (1) kernel trace of the bench command as it runs by default (two passes in flight)
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats_$N -- python3 $R/bench.py $COMMON --steps 5 --warmup 2 > $OUT/${TAG}_bench_${N}_under_rocprof.json 2>/dev/null
   cp $R/gpurun_out/${TAG}_stats_$N/*/*kernel_stats.csv $OUT/${TAG}_kernel_stats_$N.csv
+  if [ "$CH" = "0" ]; then
+    CH=$(python3 -c "import json,sys; d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(d['kernels'][0]['walkers_per_launch'])" $OUT/${TAG}_bench_${N}_under_rocprof.json)
+  fi
   # (2) the same with one pass in flight: every kernel runs alone, which is what the
   #     bench's in-library HIP-event pass (roofline object) measures
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats_${N}_s1 -- python3 $R/bench.py $COMMON --steps 5 --warmup 2 --opt streams=1 > /dev/null 2>&1
@@ -52,9 +55,14 @@ for N in $CONFIGS; do
     1024) python3 bench.py --size 1024 --sersic 4 --walkers 256 --no-example --cpu-seconds 6 --cpu-procs 0 > $OUT/${TAG}_bench_1024.json 2>$OUT/${TAG}_bench_1024.err ;;
     200)  python3 bench.py --size 200 --sersic 1 --walkers 4096 --no-example --cpu-seconds 6 --cpu-procs 0 > $OUT/${TAG}_bench_200.json 2>$OUT/${TAG}_bench_200.err ;;
     300)  python3 bench.py --size 300 --sersic 1 --walkers 2048 --no-example --cpu-seconds 6 --cpu-procs 0 > $OUT/${TAG}_bench_300.json 2>$OUT/${TAG}_bench_300.err ;;
+    *)    python3 bench.py --size $N --sersic 1 --walkers 1024 --no-example --cpu-seconds 6 --cpu-procs 0 > $OUT/${TAG}_bench_$N.json 2>$OUT/${TAG}_bench_$N.err ;;
   esac
 done
 tail -c 600 $OUT/${TAG}_bench*.json
+if [ -n "$PSFMC_PROFILES_SIZES_ONLY" ]; then
+  rm -rf $R/gpurun_out/${TAG}_stats_* $R/gpurun_out/${TAG}_pmc_*
+  exit 0
+fi
 # BASELINE config 5's per-GPU share (8 independent 256^2 fields x 256 walkers each: in one shared
 # context, and with a context per field), the
 # small-ensemble timeline and the device-resident sampler's trace
