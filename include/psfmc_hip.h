@@ -326,7 +326,17 @@ int psfmc_get_spectra(psfmc_ctx* ctx, double* psf_spec, double* var_spec);
  * "storage_f32" (0 / 1, default 0): keep the fused path's intermediate half-spectra as
  * complex64 while every operation stays fp64 -- half the memory traffic; the log-posterior is
  * then good to ~1e-7 relative, the class of the reference's own float32 raw-model accumulator
- * (psfMC/models.py:249), not an fp64 result.  Power-of-two sides, fused back end only. */
+ * (psfMC/models.py:249), not an fp64 result.  Power-of-two sides, fused back end only.
+ * "cols3" (0 / 1 / 2, default 1): which column kernel runs -- 0 the two-stage engine everywhere, 1 the wave-wide
+ * three-stage engines where they measured faster (k_cols3 at 512 / 1024, k_cols3g at the sides of
+ * psfmc_fft.h fft3g_pick), 2 k_cols3g at 512 / 1024 as well; results agree to rounding.
+ * "speculate" (device sampler, psfmc_stretch_run): ensembles of up to 2 n walkers run ONE pipeline pass per
+ * iteration -- the first half's proposals and both candidate proposals of every second-half walker (partner
+ * moved / partner stayed) -- instead of two half-steps; the chain is the same bit for bit.  0 never, n > 0 that
+ * bound, -1 (default) n = 3e6 / transform pixels, the measured break-even; needs max_walkers >= 1.5 W.
+ * get_option only: "transform_ny" / "transform_nx" (the transform shape: the image's own, or the built sides an
+ * image of unbuilt sides is embedded in), "speculated_runs", "graph_launches", "row_group",
+ * "partials_per_walker". */
 int psfmc_set_option(psfmc_ctx* ctx, const char* key, double value);
 double psfmc_get_option(const psfmc_ctx* ctx, const char* key);
 

@@ -335,6 +335,8 @@ struct psfmc_ctx {
     bool t_f32 = false;       // T stored as complex64 (set_option "storage_f32"); arithmetic stays fp64
     bool plain_shape = false; // both sides power-of-two shapes (what storage_f32 is built for)
     bool row_fast = false;    // nx a power-of-two shape and ny a whole number of its row workgroups
+    long long speculated_runs = 0;   // psfmc_stretch_run calls that took the whole-iteration route
+    int speculate = -1;       // device sampler: ensembles of up to 2 x this many walkers run ONE pipeline pass per iteration (0 = never, -1 = the default rule)
     int cols3 = 1;            // column kernel on the wave-wide three-stage engines: 0 never, 1 k_cols3 at 512 / 1024 and k_cols3g at the sides of fft3g_pick, 2 k_cols3g at 512 / 1024 as well
     bool use_graph = false;   // psfmc_stretch_run replays a captured iteration (set_option "graph"; measured: no gain,
                               // the iteration is kernel-time- not launch-bound)
@@ -383,6 +385,9 @@ struct psfmc_ctx {
         double *chain = nullptr, *lnchain = nullptr;
         int *partner = nullptr, *iter = nullptr;
         long long* nacc = nullptr;
+        uint8_t* accflag = nullptr;        // whole-iteration launches: which first-half proposals were accepted
+        size_t cap_acc = 0;
+        bool spec = false;                 // this run proposes whole iterations (stretch_run_impl)
         size_t cap_pos = 0, cap_lnp = 0, cap_q = 0, cap_new = 0, cap_rand = 0, cap_chain = 0, cap_lnchain = 0,
                cap_partner = 0, cap_iter = 0, cap_nacc = 0;
         int W = 0, n_iter = 0;
@@ -1181,7 +1186,7 @@ extern "C" int psfmc_ctx_destroy(psfmc_ctx* c) {
                     c->d_layout_blob, c->d_theta, c->d_extra, c->d_lnprior, c->d_rawstage, c->d_field_layouts,
                     c->d_Ts[2], c->d_Ts[3], c->stretch.pos, c->stretch.lnp, c->stretch.q, c->stretch.newlnp,
                     c->stretch.rand, c->stretch.chain, c->stretch.lnchain, c->stretch.partner, c->stretch.iter,
-                    c->stretch.nacc};
+                    c->stretch.nacc, c->stretch.accflag};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1254,6 +1259,10 @@ extern "C" int psfmc_set_option(psfmc_ctx* c, const char* key, double value) {
         c->cols3 = (int)value;
         return PSFMC_OK;
     }
+    if (!strcmp(key, "speculate")) {
+        c->speculate = (int)value;          // 0 never, n > 0 up to n walkers per half, -1 the default rule
+        return PSFMC_OK;
+    }
     if (!strcmp(key, "graph")) {
         c->use_graph = value != 0;
         return PSFMC_OK;
@@ -1292,6 +1301,8 @@ extern "C" double psfmc_get_option(const psfmc_ctx* cc, const char* key) {
         if (!strcmp(key, name)) { prof_collect(c); return (double)c->prof_n[i]; }
     }
     if (!strcmp(key, "row_group")) return 1 << c->rg_log2;
+    if (!strcmp(key, "speculate")) return c->speculate;
+    if (!strcmp(key, "speculated_runs")) return (double)c->speculated_runs;
     if (!strcmp(key, "transform_ny")) return c->ny;        // the transform shape (the image's own, or the one it is embedded in)
     if (!strcmp(key, "transform_nx")) return c->nx;
     if (!strcmp(key, "partials_per_walker")) return c->nblk;
@@ -2145,7 +2156,8 @@ static int stretch_upload(psfmc_ctx* c, int W, int n_iter, const double* pos, co
     const size_t WF = (size_t)W * F;
     RC_TRY(grow(&S.pos, &S.cap_pos, WF * P));
     RC_TRY(grow(&S.lnp, &S.cap_lnp, WF));
-    RC_TRY(grow(&S.q, &S.cap_q, (size_t)half * F * P));
+    RC_TRY(grow(&S.q, &S.cap_q, (size_t)half * F * P * (F == 1 ? 3 : 1)));       // (three proposal sets: whole-iteration launches)
+    RC_TRY(grow(&S.accflag, &S.cap_acc, (size_t)half));
     RC_TRY(grow(&S.newlnp, &S.cap_new, (size_t)half * F));
     RC_TRY(grow(&S.nacc, &S.cap_nacc, WF));
     RC_TRY(grow(&S.rand, &S.cap_rand, 3 * n_rand));
@@ -2206,10 +2218,23 @@ static void stretch_accept(psfmc_ctx* c, int it, int h, const double* d_newlnp, 
     const int half = S.W / 2;
     const size_t per_field = (size_t)S.n_iter * S.W;
     const size_t n_rand = per_field * S.F;
+    // whole-iteration launches: the first half records its outcomes, the second half selects its rows by them
+    uint8_t* acc_out = S.spec && h == 0 ? S.accflag : nullptr;
+    const uint8_t* acc_in = S.spec && h == 1 ? S.accflag : nullptr;
     hipLaunchKernelGGL(k_stretch_finish, dim3(finish_blocks(half), S.F), dim3(kFinishThreads), 0, st, c->d_partial,
                        c->d_skip, c->d_lnprior, c->nblk, d_newlnp, S.pos, S.lnp, S.q, S.rand + n_rand,
                        S.rand + 2 * n_rand, S.nacc, S.store ? S.chain : nullptr, S.store ? S.lnchain : nullptr,
-                       graph_iter ? S.iter : nullptr, it, S.n_iter, half, h, c->layout.n_params, per_field);
+                       graph_iter ? S.iter : nullptr, it, S.n_iter, half, h, c->layout.n_params, per_field,
+                       acc_out, acc_in, S.partner);
+}
+
+// a whole iteration's proposals in one launch (StretchIn::spec): 3 half walkers
+static void stretch_propose_iteration(psfmc_ctx* c, int it, bool graph_iter, hipStream_t st) {
+    psfmc_ctx::Stretch& S = c->stretch;
+    const int half = S.W / 2, P = c->layout.n_params;
+    StretchIn sp{S.pos, S.q, S.rand, S.partner, graph_iter ? S.iter : nullptr, it, half, 0,
+                 (size_t)S.W * P, (size_t)half * P, (size_t)S.n_iter * S.W, 1};
+    launch_theta_prep(c, 3 * half, nullptr, nullptr, nullptr, st, sp);
 }
 
 static int stretch_prepare_accumulation(psfmc_ctx* c) {
@@ -2255,8 +2280,25 @@ static int stretch_run_impl(psfmc_ctx* c, int F, int W, int n_iter, double* pos,
     // a hipGraph.
     const bool use_d_iter = n_iter > 2 && c->use_graph && !c->profile && c->backend == PSFMC_BACKEND_FUSED && F == 1;
     int it_host = 0;
+    // Small ensembles (the reference's default 2 P + 2 walkers, fitting.py:52-53) are latency-bound: a half-step of
+    // 11 walkers takes as long as one of 33.  They run ONE pipeline pass per iteration over the first half's
+    // proposals and BOTH candidate proposals of every second-half walker (partner moved / partner stayed), and the
+    // second accept step picks by the first one's outcomes: the same chain bit for bit (per-walker results do not
+    // depend on the batch), 6 launches per iteration instead of 10.
+    // default rule, measured (tools/time_small_sampler.py; profiles/r3_small_sampler.txt): the single pass wins while
+    // half an ensemble is at most ~3 M transform pixels -- 183 walkers at 128^2 (x1.55 at 22 walkers ... x1.10 at
+    // 256), 45 at 256^2 (x1.31 at 22, x1.09 at 64), 11 at 512^2 (x1.07); beyond it the extra half-ensemble of
+    // evaluations costs more than the launches it saves
+    const int spec_bound = c->speculate >= 0 ? c->speculate : (int)(3.0e6 / ((double)c->ny * c->nx));
+    S.spec = F == 1 && half <= spec_bound && 3 * half <= c->max_walkers && c->backend == PSFMC_BACKEND_FUSED;
+    if (S.spec) ++c->speculated_runs;
     auto iteration = [&]() -> int {
-        for (int h = 0; h < 2; ++h) {
+        if (S.spec) {
+            stretch_propose_iteration(c, it_host, use_d_iter, st);
+            RC_TRY(run_pipeline(c, 3 * half, c->d_skip, st));
+            stretch_accept(c, it_host, 0, nullptr, use_d_iter, st);
+            stretch_accept(c, it_host, 1, nullptr, use_d_iter, st);
+        } else for (int h = 0; h < 2; ++h) {
             stretch_propose(c, it_host, h, use_d_iter, st);
             RC_TRY(run_pipeline(c, half * F, c->d_skip, st));
             stretch_accept(c, it_host, h, nullptr, use_d_iter, st);
@@ -2314,6 +2356,7 @@ static int stretch_run_impl(psfmc_ctx* c, int F, int W, int n_iter, double* pos,
     (void)hipStreamSynchronize(st);
     if (rc == PSFMC_OK && hipGetLastError() != hipSuccess) rc = fail(PSFMC_EHIP, "kernel launch failed");
     S.open = false;
+    S.spec = false;
     return rc;
 }
 

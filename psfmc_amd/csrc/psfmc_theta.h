@@ -241,6 +241,14 @@ struct StretchIn {
     // field is its own ensemble of 2 half walkers with its own random numbers.  Element strides
     // between consecutive fields of pos / q / z (and partner); 0 in a one-field launch.
     size_t pos_stride, q_stride, rand_stride;
+    // spec = 1 (small ensembles, one field): ONE launch proposes a whole iteration -- 3 half walkers:
+    //   [0, half)        the first half's proposals (as h = 0),
+    //   [half, 2 half)   the second half's proposals IF the partner's proposal is accepted (the partner's
+    //                    position is then its proposal, formed here again with the same three roundings),
+    //   [2 half, 3 half) the second half's proposals if it is rejected (the partner stays where it is).
+    // The accept step of the second half picks the row its partner's outcome selects (k_stretch_finish), so the
+    // chain is the one of two half-steps run after each other, bit for bit, at one pipeline pass per iteration.
+    int spec;
 };
 
 // the fields of one k_theta_prep launch (gridDim.y > 1): field f takes layouts[f], walkers
@@ -327,7 +335,24 @@ k_theta_prep(ThetaLayout G, const double* __restrict__ theta,
     if (tid < n_dbl) first_d = G.slot_const[tid];
     size_t soff = 0;
     double s_own = 0.0, c_other = 0.0, zz = 0.0;
-    if (sp.pos) {                                                   // propose into the tile
+    // element i = lw P + d of the tile in a whole-iteration launch (sp.spec)
+    auto propose_spec = [&](int i, size_t off0) -> double {
+        const int lw = i / P, d = i - lw * P, w3 = w0 + lw;
+        const int seg = w3 / sp.half, w = w3 - seg * sp.half;
+        const size_t off1 = off0 + sp.half;
+        if (seg == 0)
+            return stretch_point(sp.pos[(size_t)w * P + d],
+                                 sp.pos[(size_t)(sp.half + sp.partner[off0 + w]) * P + d], sp.z[off0 + w]);
+        const int j = sp.partner[off1 + w];                          // a walker of the first half
+        double cj = sp.pos[(size_t)j * P + d];
+        if (seg == 1)
+            cj = stretch_point(cj, sp.pos[(size_t)(sp.half + sp.partner[off0 + j]) * P + d], sp.z[off0 + j]);
+        return stretch_point(sp.pos[(size_t)(sp.half + w) * P + d], cj, sp.z[off1 + w]);
+    };
+    if (sp.pos && sp.spec) {
+        const int it = sp.d_iter ? *sp.d_iter : sp.it;
+        soff = (size_t)it * 2 * sp.half;
+    } else if (sp.pos) {                                            // propose into the tile
         const int it = sp.d_iter ? *sp.d_iter : sp.it;
         soff = ((size_t)it * 2 + sp.h) * sp.half;
         if (tid < n_tile) {
@@ -343,7 +368,13 @@ k_theta_prep(ThetaLayout G, const double* __restrict__ theta,
     if (tid < n_dbl) ld[tid] = first_d;
     for (int i = tid + nthr; i < n_tab_i; i += nthr) li[i] = G.slot_col[i];
     for (int i = tid + nthr; i < n_dbl; i += nthr) ld[i] = G.slot_const[i];
-    if (sp.pos) {
+    if (sp.pos && sp.spec) {
+        for (int i = tid; i < n_tile; i += nthr) {
+            const double q = propose_spec(i, soff);
+            th_tile[i] = q;
+            sp.q[(size_t)w0 * P + i] = q;
+        }
+    } else if (sp.pos) {
         if (tid < n_tile) {
             const double q = stretch_point(s_own, c_other, zz);
             th_tile[tid] = q;
@@ -479,7 +510,8 @@ __global__ void k_stretch_finish(const double* __restrict__ partial, const uint8
                                  const double* __restrict__ log_u, long long* __restrict__ nacc,
                                  double* __restrict__ chain, double* __restrict__ lnchain,
                                  const int* __restrict__ d_iter, int it_val, int n_iter, int half, int h,
-                                 int P, size_t rand_stride) {
+                                 int P, size_t rand_stride, uint8_t* __restrict__ acc_out,
+                                 const uint8_t* __restrict__ acc_in, const int* __restrict__ partner) {
 #pragma clang fp contract(off)
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * (kFinishThreads / 64) + (threadIdx.x >> 6);
@@ -502,8 +534,12 @@ __global__ void k_stretch_finish(const double* __restrict__ partial, const uint8
         }
     }
     const int it = d_iter ? *d_iter : it_val;
-    const double newlnp = newlnp_in ? newlnp_in[w] : walker_lnprob(partial, skip, lnprior, nblk, w, lane);
     const size_t off = ((size_t)it * 2 + h) * half;
+    // whole-iteration launches (StretchIn::spec): the second half's walker takes the proposal row its
+    // partner's outcome selects -- half + w if the partner moved, 2 half + w if it stayed
+    int row = w;
+    if (acc_in) row = w + (acc_in[partner[off + w]] ? half : 2 * half);
+    const double newlnp = newlnp_in ? newlnp_in[w] : walker_lnprob(partial, skip, lnprior, nblk, row, lane);
     const int g = h * half + w;
     double lp = lnprob[g];
     const double diff = (lz[off + w] + newlnp) - lp;
@@ -512,7 +548,7 @@ __global__ void k_stretch_finish(const double* __restrict__ partial, const uint8
     for (int d = lane; d < P; d += 64) {                     // lane d moves coordinate d
         double v;
         if (accept) {
-            v = q[(size_t)w * P + d];
+            v = q[(size_t)row * P + d];
             pos[(size_t)g * P + d] = v;
         } else {
             v = pos[(size_t)g * P + d];
@@ -520,6 +556,7 @@ __global__ void k_stretch_finish(const double* __restrict__ partial, const uint8
         if (chain) chain[((size_t)g * n_iter + it) * P + d] = v;
     }
     if (lane == 0) {
+        if (acc_out) acc_out[w] = accept ? 1 : 0;
         if (accept) {
             lnprob[g] = lp;
             nacc[g] += 1;

@@ -128,8 +128,10 @@ class MultiComponentModel(object):
                 self.config.obs_data, self.config.obs_var, self.config.bad_px,
                 np.stack(sel.psf_data), np.stack(sel.psf_var),
                 n_ps=len(self._ps), n_sersic=len(self._sersic),
-                max_walkers=self._max_walkers, device=self._device,
-                backend=self._backend)
+                # small ensembles: room for the device sampler's whole-iteration launches (3 proposal sets of
+                # half an ensemble each, psfmc_hip.hip stretch_run_impl)
+                max_walkers=self._max_walkers + (self._max_walkers // 2 + 1 if self._max_walkers <= 512 else 0),
+                device=self._device, backend=self._backend)
             if self._storage == 'f32':
                 self._engine.set_option('storage_f32', 1)
             self._register_layout(self._engine)

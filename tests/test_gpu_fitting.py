@@ -130,6 +130,19 @@ def test_device_sampler_reproduces_host_sampler(tmp_path):
     assert helpers.rel_err(dev.lnprobability, host.lnprobability) <= 1e-13
     assert np.array_equal(out_d[-1][0], out_h[-1][0]) and len(out_d) == 25
     assert 0.05 < dev.acceptance_fraction.mean() < 0.9
+    # half an ensemble of 20 walkers is below the library's `speculate` bound: the run above took ONE pipeline
+    # pass per iteration (both candidate proposals of every second-half walker, psfmc_hip.hip stretch_run_impl);
+    # two half-steps after each other give the same chain
+    assert model.engine.get_option('speculated_runs') > 0
+    before = model.engine.get_option('speculated_runs')
+    model.engine.set_option('speculate', 0)
+    plain = DeviceEnsembleSampler(40, model, block=7)
+    plain.random_state = np.random.RandomState(11).get_state()
+    list(plain.sample(p0, iterations=25))
+    assert model.engine.get_option('speculated_runs') == before
+    assert np.array_equal(plain.chain, dev.chain) and np.array_equal(plain.lnprobability, dev.lnprobability)
+    assert np.array_equal(plain.naccepted, dev.naccepted)
+    model.engine.set_option('speculate', -1)
     # continuing a run (lnprob0 given) and thinning
     more_h = list(host.sample(out_h[-1][0], lnprob0=out_h[-1][1], iterations=6, thin=2))
     more_d = list(dev.sample(out_d[-1][0], lnprob0=out_d[-1][1], iterations=6, thin=2))
