@@ -216,3 +216,40 @@ def test_nearest_fused_sides():
     assert engine.fused_supports(140, 256) and not engine.fused_supports(134, 256)
     assert engine.fused_supports(134, 256, (64, 64)) and engine.embedding_side(134, 64) == 200
     assert engine.embedding_side(1000, 64) is None and engine.embedding_side(170, 33) == 208
+
+
+def test_side_tables_agree_between_python_and_the_kernels():
+    """The per-side tables exist in several places: the list of built sides (engine.FUSED_SIDES, two copies in
+    psfmc_hip.hip), the sides whose columns run on the general three-stage engine with their (R2, R3) split
+    (psfmc_fft.h fft3g_pick, mirrored by engine.column_engine), and the measured cost table the embedding ranks
+    candidate sides with (psfmc_side_costs.h).  They are parsed from the sources here and compared."""
+    import re
+    from psfmc_amd import engine
+    csrc = os.path.join(os.path.dirname(os.path.abspath(engine.__file__)), 'csrc')
+    hip = open(os.path.join(csrc, 'psfmc_hip.hip')).read()
+    lists = re.findall(r'static const int (?:sides|kFusedSides)\[\] = \{([0-9, ]+)\}', hip)
+    assert len(lists) == 2
+    for text in lists:
+        assert tuple(int(v) for v in text.split(',')) == tuple(engine.FUSED_SIDES)
+    fft = open(os.path.join(csrc, 'psfmc_fft.h')).read()
+    body = fft[fft.index('constexpr Fft3gPick fft3g_pick(int n)'):]
+    body = body[:body.index('default:')]
+    picks = {}
+    for cases, r2, r3 in re.findall(r'((?:case \d+:\s*)+)return \{(\d+), (\d+)\};', body):
+        for n in re.findall(r'case (\d+):', cases):
+            picks[int(n)] = (int(r2), int(r3))
+    assert picks and set(picks) <= set(engine.FUSED_SIDES)
+    for n in engine.FUSED_SIDES:
+        name, shape = engine.column_engine(n)
+        if n in (512, 1024):
+            assert name == 'k_cols3' and picks[n] == (8, 8)
+        elif n in picks:
+            r2, r3 = picks[n]
+            assert name == 'k_cols3g' and shape == (n // (r2 * r3), r2, r3), n
+            assert n % (r2 * r3) == 0 and r2 * r3 <= 64 and 4 <= n // (r2 * r3) <= 16
+        else:
+            assert name == 'k_cols' and shape is None, n
+    costs = open(os.path.join(csrc, 'psfmc_side_costs.h')).read()
+    rows = re.findall(r'\{(\d+), ([0-9.]+)f, ([0-9.]+)f\}', costs)
+    assert tuple(int(r[0]) for r in rows) == tuple(engine.FUSED_SIDES)
+    assert all(5.0 < float(r[1]) < 40.0 and 3.0 < float(r[2]) < 30.0 for r in rows)      # picoseconds per pixel per walker
