@@ -268,6 +268,45 @@ def small_ensembles(eng, args, torch, dev, theta_dev, out_dev, stream):
     return res
 
 
+def default_ensemble_sampler(model, theta, n_iter=64):
+    """The reference's default fit: `chains = 2 P + 2` walkers (psfMC/fitting.py:52-53) stepped by the
+    device-resident sampler (psfmc_stretch_run), ms per stretch-move iteration -- as the library runs it (small
+    ensembles: ONE pipeline pass per iteration over the first half's proposals and both candidate proposals
+    of every second-half walker) and as two half-steps (option speculate = 0); same chain bit for bit."""
+    from psfmc_amd.sampler import DeviceEnsembleSampler
+    eng = model.engine
+    n_w = 2 * model.num_params + 2
+    p0 = np.ascontiguousarray(theta[:n_w])
+    lnp = model.log_posterior_batch(p0)
+    if not np.all(np.isfinite(lnp)):
+        good = theta[np.isfinite(model.log_posterior_batch(theta[:8 * n_w]))]
+        if len(good) < n_w:
+            return None
+        p0 = np.ascontiguousarray(good[:n_w])
+        lnp = model.log_posterior_batch(p0)
+    s = DeviceEnsembleSampler(n_w, model, block=n_iter)
+    s.random_state = np.random.RandomState(5).get_state()
+    draws, _ = s._draw(n_iter)
+    out, chains = {}, {}
+    for key, mode in (('ms_per_iteration', -1), ('ms_per_iteration_two_half_steps', 0)):
+        eng.set_option('speculate', mode)
+        best = None
+        for _ in range(4):
+            t0 = time.perf_counter()
+            res = eng.stretch_run(p0.copy(), lnp.copy(), *draws, np.zeros(n_w, dtype=np.int64), store=True)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        out[key] = best * 1e3 / n_iter
+        chains[key] = res[2]
+    eng.set_option('speculate', -1)
+    out['walkers'] = n_w
+    out['evals_per_s'] = n_w * n_iter / (out['ms_per_iteration'] * 1e-3 * n_iter)
+    out['chains_identical'] = bool(np.array_equal(*chains.values()))
+    out['what'] = ('%d walkers (2 P + 2), %d iterations per psfmc_stretch_run call, upload and chain download '
+                   'included; best of 4' % (n_w, n_iter))
+    return out
+
+
 def example_model_rate(walkers=256, reps=40):
     """BASELINE.json configs[1]: the reference's example field (128^2 HST data, Sky +
     PointSource + 2 Sersic, 18 parameters; data files under tests/golden/example), 256
@@ -790,6 +829,8 @@ def main():
                         'HOST numpy vectors in and HOST log-posteriors out (host-to-device copy, launch, '
                         'device-to-host copy and synchronisation inside every call)'}
             line['small_ensembles'] = small_ensembles(eng, args, torch, dev, theta_dev[0], out[0], stream)
+            if args.backend == 'fused' and not model._host_priors:
+                line['default_ensemble_sampler'] = default_ensemble_sampler(model, theta)
             if args.backend == 'fused':
                 per_pass = eng.pass_size(args.walkers)
                 t_bytes = 2 * (args.size // 2 + 1) * args.size * 16
