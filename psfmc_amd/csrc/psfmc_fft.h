@@ -764,7 +764,7 @@ __device__ __forceinline__ void fft_wave3(cd (&v)[Fft3Shape<N>::R1], const cd (&
 //   stage 3  R1 R2 radix-R3 transforms over n3 on all 64 lanes: lane t takes c = t + 64 q = k1 + R1 k2,
 //            q < NB3 = ceil(R1 R2 / 64), where c < R1 R2
 // and on exit   o[q][k3] = X[(t + 64 q) + R1 R2 k3]   (valid iff t + 64 q < R1 R2).
-// A caller that transforms again regroups through LDS (fft3g_regroup).
+// Its inverse is the mirror image below (fft_wave3g_inv), which takes exactly this output layout.
 // ---------------------------------------------------------------------------
 struct Fft3gPick { int r2, r3; };
 // The shape of a side, {0, 0} = none (its columns stay on the two-stage engine).  Empirical: every candidate
@@ -797,8 +797,8 @@ template <int N, int R2_ = fft3g_pick(N).r2, int R3_ = fft3g_pick(N).r3> struct 
     static constexpr int S2 = R1 | 1;
 };
 template <class S> constexpr int fft3g_lds_doubles() {
-    constexpr int a = S::R1 * S::S1, b = S::L * S::S2, c = a > b ? a : b, n = S::R1 * S::L;
-    return c > n ? c : n;                                   // (the regroup needs N)
+    constexpr int a = S::R1 * S::S1, b = S::L * S::S2;
+    return a > b ? a : b;
 }
 template <class S> __device__ __forceinline__ bool fft3g_valid(int t, int q) { return t + 64 * q < S::R1 * S::R2; }
 template <class S> __device__ __forceinline__ int fft3g_index(int t, int q, int k3) {
@@ -971,34 +971,6 @@ __device__ __forceinline__ void fft_wave3g_inv(cd (&o)[S::NB3][S::R3], cd (&v)[S
     for (int k = 0; k < R1; ++k) v[k].y = lds[k * S1 + tl];
     wave_lds_sync();
     Dft<R1, +1>::run(v);
-}
-
-// output order of fft_wave3g -> its input order (v[a] = X[L a + t]), through the wave's LDS region, one
-// component at a time
-template <class S>
-__device__ __forceinline__ void fft3g_regroup(const cd (&o)[S::NB3][S::R3], cd (&v)[S::R1], int t,
-                                              double* __restrict__ lds) {
-    const int tl = (S::L == 64 || t < S::L) ? t : 0;
-#pragma unroll
-    for (int q = 0; q < S::NB3; ++q)
-        if (fft3g_valid<S>(t, q)) {
-#pragma unroll
-            for (int k3 = 0; k3 < S::R3; ++k3) lds[fft3g_index<S>(t, q, k3)] = o[q][k3].x;
-        }
-    wave_lds_sync();
-#pragma unroll
-    for (int a = 0; a < S::R1; ++a) v[a].x = lds[S::L * a + tl];
-    wave_lds_sync();
-#pragma unroll
-    for (int q = 0; q < S::NB3; ++q)
-        if (fft3g_valid<S>(t, q)) {
-#pragma unroll
-            for (int k3 = 0; k3 < S::R3; ++k3) lds[fft3g_index<S>(t, q, k3)] = o[q][k3].y;
-        }
-    wave_lds_sync();
-#pragma unroll
-    for (int a = 0; a < S::R1; ++a) v[a].y = lds[S::L * a + tl];
-    wave_lds_sync();
 }
 
 }  // namespace psfmc
