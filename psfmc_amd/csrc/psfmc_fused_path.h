@@ -54,6 +54,9 @@ constexpr int kColThreads = 256;     // column kernel: 4 waves, persistent
 #ifndef PSFMC_INV_PRIO
 #define PSFMC_INV_PRIO 0
 #endif
+#ifndef PSFMC_INV_REMAP_MIN
+#define PSFMC_INV_REMAP_MIN 720       /* k_rows_inv of sides from this on: row groups in XCD-sized batches over all walkers */
+#endif
 #ifndef PSFMC_INV_CHUNK
 #define PSFMC_INV_CHUNK 8             /* field pixels per load chunk of k_rows_inv at nx = 512, 1024 */
 #endif
@@ -736,13 +739,30 @@ k_rows_inv(const TS* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
     __builtin_amdgcn_s_setprio(PSFMC_INV_PRIO);
 #endif
 
-    const int w = blockIdx.y;
+    int w = blockIdx.y, bx = blockIdx.x;
+    if constexpr (NX >= PSFMC_INV_REMAP_MIN) {
+        // Which workgroup takes which (row group, walker).  Workgroups are dealt to the 8 XCDs round-robin in
+        // launch order (x fastest), so with walker = blockIdx.y a row group's field pixels (FieldPx: 16 bytes
+        // per pixel, as much as T itself) always come through the same XCD's L2 -- but one walker apart, i.e.
+        // after 1/8 of (T + field) = 4.2 MB of other lines at nx = 1024: gone from a 4-MiB L2, so every walker
+        // of a pass fetched the field again (24.4 MB per walker for a 16.8-MB T: the "1.42x" of rounds 1-2, which
+        // was never about half-lines of T).  Eight consecutive row groups (one per XCD) of ALL walkers now run
+        // back to back: FETCH_SIZE of k_rows_inv<1024> 71.1 -> 60.2 k per launch (1.45x -> 1.23x: the field once
+        // per pass), 33.5 -> 33.1 us, step +1 % (the 1024^2 pass is VALU-bound).  From nx = 720 on: below, a
+        // walker's share of T + field per XCD stays in the L2 anyway (512^2: 1.07x).
+        const int gx = (int)gridDim.x, n_w = (int)gridDim.y;
+        if ((gx & 7) == 0) {
+            const int id = w * gx + bx, r = id >> 3;
+            w = r % n_w;
+            bx = (r / n_w) * 8 + (id & 7);
+        }
+    }
     // (testing the flag only after the loads of T were issued, as k_rows_fwd and k_cols3 do, made
     // this kernel slower at 512 and 1024 -- 31.5 -> 37.7 us, 34.1 -> 41.6 us -- and left 256 unchanged)
     if (skip && skip[w]) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int f = lane / T, t = lane % T;
-    const int yg = blockIdx.x * row_waves<NX, FAST>() + wave;
+    const int yg = bx * row_waves<NX, FAST>() + wave;
     if constexpr (!FAST)
         if (yg * RG >= ny) return;                                    // wave-uniform
     const bool lane_on = S::kFull || f < RG;
