@@ -55,8 +55,14 @@ constexpr int kColThreads = 256;     // column kernel: 4 waves, persistent
 #define PSFMC_INV_PRIO 0
 #endif
 #ifndef PSFMC_INV_REMAP_MIN
-#define PSFMC_INV_REMAP_MIN 720       /* k_rows_inv of sides from this on: row groups in XCD-sized batches over all walkers */
+#define PSFMC_INV_REMAP_MIN 720       /* unguarded k_rows_inv of sides from this on (and every guarded one): row groups in XCD-sized batches over all walkers */
 #endif
+template <int NX, bool FAST> constexpr bool inv_remap() { return !FAST || NX >= PSFMC_INV_REMAP_MIN; }
+// ... for launches of at most this many walkers: with more (the small sides: 80 walkers per pass at 300^2, 172 at
+// 200^2) eight workgroups per walker hop through that many T regions and the kernel gets slower (k_rows_inv<300>
+// 43 -> 49 us, <200> 37 -> 51 us), while a field of that size stays in the L2s anyway; 600^2 (19 walkers): 41.3 ->
+// 38.2 us, step +2.8 %
+constexpr int kInvRemapMaxWalkers = 24;
 #ifndef PSFMC_INV_CHUNK
 #define PSFMC_INV_CHUNK 8             /* field pixels per load chunk of k_rows_inv at nx = 512, 1024 */
 #endif
@@ -740,7 +746,7 @@ k_rows_inv(const TS* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
 #endif
 
     int w = blockIdx.y, bx = blockIdx.x;
-    if constexpr (NX >= PSFMC_INV_REMAP_MIN) {
+    if constexpr (inv_remap<NX, FAST>()) {
         // Which workgroup takes which (row group, walker).  Workgroups are dealt to the 8 XCDs round-robin in
         // launch order (x fastest), so with walker = blockIdx.y a row group's field pixels (FieldPx: 16 bytes
         // per pixel, as much as T itself) always come through the same XCD's L2 -- but one walker apart, i.e.
@@ -748,10 +754,12 @@ k_rows_inv(const TS* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
         // of a pass fetched the field again (24.4 MB per walker for a 16.8-MB T: the "1.42x" of rounds 1-2, which
         // was never about half-lines of T).  Eight consecutive row groups (one per XCD) of ALL walkers now run
         // back to back: FETCH_SIZE of k_rows_inv<1024> 71.1 -> 60.2 k per launch (1.45x -> 1.23x: the field once
-        // per pass), 33.5 -> 33.1 us, step +1 % (the 1024^2 pass is VALU-bound).  From nx = 720 on: below, a
-        // walker's share of T + field per XCD stays in the L2 anyway (512^2: 1.07x).
+        // per pass), 33.5 -> 33.1 us, step +1 % (the 1024^2 pass is VALU-bound).  The general-shape kernels do the
+        // same for launches of up to kInvRemapMaxWalkers walkers (the host pads the grid to a multiple of eight
+        // row-group workgroups; the spare ones leave at the row guard).  The unguarded kernels of 64 ... 512 are
+        // left as they are: a walker's share of T + field per XCD stays in the L2 (512^2: 1.07x).
         const int gx = (int)gridDim.x, n_w = (int)gridDim.y;
-        if ((gx & 7) == 0) {
+        if ((gx & 7) == 0 && n_w <= kInvRemapMaxWalkers) {
             const int id = w * gx + bx, r = id >> 3;
             w = r % n_w;
             bx = (r / n_w) * 8 + (id & 7);
