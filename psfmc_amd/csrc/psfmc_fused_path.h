@@ -58,10 +58,7 @@ constexpr int kColThreads = 256;     // column kernel: 4 waves, persistent
 #define PSFMC_INV_REMAP_MIN 720       /* unguarded k_rows_inv of sides from this on (and every guarded one): row groups in XCD-sized batches over all walkers */
 #endif
 template <int NX, bool FAST> constexpr bool inv_remap() { return !FAST || NX >= PSFMC_INV_REMAP_MIN; }
-// ... for launches of at most this many walkers: with more (the small sides: 80 walkers per pass at 300^2, 172 at
-// 200^2) eight workgroups per walker hop through that many T regions and the kernel gets slower (k_rows_inv<300>
-// 43 -> 49 us, <200> 37 -> 51 us), while a field of that size stays in the L2s anyway; 600^2 (19 walkers): 41.3 ->
-// 38.2 us, step +2.8 %
+// walkers per block of that order: all of a launch up to this many, else 8
 constexpr int kInvRemapMaxWalkers = 24;
 #ifndef PSFMC_INV_CHUNK
 #define PSFMC_INV_CHUNK 8             /* field pixels per load chunk of k_rows_inv at nx = 512, 1024 */
@@ -748,22 +745,35 @@ k_rows_inv(const TS* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
     int w = blockIdx.y, bx = blockIdx.x;
     if constexpr (inv_remap<NX, FAST>()) {
         // Which workgroup takes which (row group, walker).  Workgroups are dealt to the 8 XCDs round-robin in
-        // launch order (x fastest), so with walker = blockIdx.y a row group's field pixels (FieldPx: 16 bytes
-        // per pixel, as much as T itself) always come through the same XCD's L2 -- but one walker apart, i.e.
-        // after 1/8 of (T + field) = 4.2 MB of other lines at nx = 1024: gone from a 4-MiB L2, so every walker
-        // of a pass fetched the field again (24.4 MB per walker for a 16.8-MB T: the "1.42x" of rounds 1-2, which
-        // was never about half-lines of T).  Eight consecutive row groups (one per XCD) of ALL walkers now run
-        // back to back: FETCH_SIZE of k_rows_inv<1024> 71.1 -> 60.2 k per launch (1.45x -> 1.23x: the field once
-        // per pass), 33.5 -> 33.1 us, step +1 % (the 1024^2 pass is VALU-bound).  The general-shape kernels do the
-        // same for launches of up to kInvRemapMaxWalkers walkers (the host pads the grid to a multiple of eight
-        // row-group workgroups; the spare ones leave at the row guard).  The unguarded kernels of 64 ... 512 are
-        // left as they are: a walker's share of T + field per XCD stays in the L2 (512^2: 1.07x).
+        // launch order (x fastest).  With walker = blockIdx.y a row group's field pixels (FieldPx: 16 bytes per
+        // pixel, as much as T itself) came through the same XCD's L2 one walker apart -- after 1/8 of (T + field)
+        // = 4.2 MB of other lines at nx = 1024: gone from a 4-MiB L2, so every walker of a pass fetched the field
+        // again (24.4 MB per walker for a 16.8-MB T: the "1.42x" of rounds 1-2, which was never about half-lines
+        // of T) -- or, where the workgroups per walker are not a multiple of 8 (25 at 300^2), through a different
+        // XCD for every walker.  Now the walkers go in blocks of WB (all of them up to 24, else 8), and inside a
+        // block eight consecutive row groups (one per XCD) of all its walkers run back to back; the gx mod 8 row
+        // groups left over take whatever XCD comes (padding the grid to whole rounds instead loaded one XCD with
+        // 4 workgroups per walker against 3: k_rows_inv<200> 37 -> 50 us).  Measured: FETCH_SIZE of
+        // k_rows_inv<1024> 71.1 -> 60.2 k per launch (1.45x -> 1.23x: the field once per pass), step +1 % (that
+        // pass is VALU-bound); 600^2 +2.6 %, 832^2 +4.3 %.  The unguarded kernels of 64 ... 512 keep the plain
+        // order: a walker's share of T + field per XCD stays in the L2 (512^2: 1.07x).
         const int gx = (int)gridDim.x, n_w = (int)gridDim.y;
-        if ((gx & 7) == 0 && n_w <= kInvRemapMaxWalkers) {
-            const int id = w * gx + bx, r = id >> 3;
-            w = r % n_w;
-            bx = (r / n_w) * 8 + (id & 7);
+        const int id = w * gx + bx;
+        const int WB = n_w <= kInvRemapMaxWalkers ? n_w : 8;
+        const int B = id / (WB * gx), rem = id - B * WB * gx;
+        const int left = n_w - B * WB, wb = left < WB ? left : WB;
+        const int q8 = gx & ~7;                                    // row groups in whole rounds of the XCDs
+        int wi;
+        if (rem < wb * q8) {
+            const int gc = rem / (wb * 8), rr = rem - gc * wb * 8;
+            wi = rr >> 3;
+            bx = gc * 8 + (rr & 7);
+        } else {
+            const int rr = rem - wb * q8, j = rr / wb;
+            wi = rr - j * wb;
+            bx = q8 + j;
         }
+        w = B * WB + wi;
     }
     // (testing the flag only after the loads of T were issued, as k_rows_fwd and k_cols3 do, made
     // this kernel slower at 512 and 1024 -- 31.5 -> 37.7 us, 34.1 -> 41.6 us -- and left 256 unchanged)

@@ -536,9 +536,7 @@ static int launch_rows_inv_kernel(psfmc_ctx* c, int n, const TS* Tbuf, const dou
         }
     }
     constexpr int waves = row_waves<NX, FAST>();
-    int gx = (c->nblk + waves - 1) / waves;
-    if constexpr (inv_remap<NX, FAST>() && !FAST)
-        if (n <= kInvRemapMaxWalkers) gx = (gx + 7) & ~7;                  // (spare workgroups leave at the row guard)
+    const int gx = (c->nblk + waves - 1) / waves;
     hipLaunchKernelGGL((k_rows_inv<NX, TS, FAST, MULTI>), dim3(gx, n),
                        dim3((row_threads<NX, FAST>())), lds, st, Tbuf, skip, c->d_twx, c->d_field, partial, c->ny,
                        prep, c->plen, conv_out, var_out, c->n_fields > 1 ? c->n_psf_field : 0, (unsigned)c->field_len);
