@@ -120,6 +120,28 @@ template <int NY> constexpr size_t fused_col_lds_bytes() {
 template <int N> constexpr int fused_min_waves() {
     return FftShape<N>::kPlain ? (FftShape<N>::R > 16 ? 1 : 2) : (FftShape<N>::R > PSFMC_GEN_R_2WAVES ? 1 : 2);
 }
+// The row kernels' bound for the general shapes.  Left to itself (a bound of one wave per SIMD) the register
+// allocator took 1 ... 50 accumulation registers on top of the 256 vector registers at nine sides, which halves
+// the waves per SIMD for the sake of a handful of values.  Bounded to two waves, 650 / 700 / 720 spill 4 ... 10
+// registers and run 20 ... 24 % faster (whole step, same box: 94 -> 117 k, 88 -> 105 k, 94 -> 113 k evals/s), 676
+// (18 spilled) +9 %, 780 (29) +3 %; 728, 784, 840, 900 (25 ... 51 spilled) measured 2 ... 14 % SLOWER and keep one
+// wave.  (PSFMC_GEN_ROW_R_2WAVES = 32 bounds every general shape to two waves, for the A/B.)
+#ifndef PSFMC_GEN_ROW_R_2WAVES
+#define PSFMC_GEN_ROW_R_2WAVES 16
+#endif
+constexpr bool row_two_waves_side(int n) { return n == 650 || n == 676 || n == 700 || n == 720 || n == 780; }
+// Sides whose row kernels sit 2 ... 8 registers above an occupancy step (130 vector registers: three waves per
+// SIMD instead of four; 172 ... 176: two instead of three), bounded to the next step where that measured faster
+// (same box, kernel time): the forward kernel of 84, 98, 132, 160, 176 (-3 ... -6 %), the inverse kernel of 220, 260,
+// 280, 300 (-9 ... -13 %: k_rows_inv<300> 41.9 -> 38.2 us, step +2.9 %).  The other way round -- the rasteriser's
+// kernel at 220 ... 300, the inverse at the small sides -- the spills cost more than the extra wave hides.
+constexpr int row_fwd_more_waves(int n) { return (n == 84 || n == 98 || n == 132) ? 4 : ((n == 160 || n == 176) ? 3 : 0); }
+constexpr int row_inv_more_waves(int n) { return (n == 220 || n == 260 || n == 280 || n == 300) ? 3 : 0; }
+template <int N, bool INVERSE> constexpr int fused_row_min_waves() {
+    if (FftShape<N>::kPlain) return fused_min_waves<N>();
+    if ((INVERSE ? row_inv_more_waves(N) : row_fwd_more_waves(N)) > 0) return INVERSE ? row_inv_more_waves(N) : row_fwd_more_waves(N);
+    return (FftShape<N>::R > PSFMC_GEN_ROW_R_2WAVES && !row_two_waves_side(N)) ? 1 : 2;
+}
 // the column kernel's own bound (experiments: more waves per SIMD instead of the register
 // double-buffering)
 template <int N> constexpr int fused_col_min_waves() {
@@ -198,7 +220,7 @@ __global__ void k_pack_field(const double* __restrict__ sci, const double* __res
 // WRAP: the image is embedded in a larger transform size (psfmc_device.h WrapDesc); ny, NX are the
 // transform's sides
 template <int NX, bool FROM_IMAGE, typename TS = cd, bool FAST = FftShape<NX>::kPlain, bool WRAP = false>
-__global__ void __launch_bounds__((row_threads<NX, FAST>()), fused_min_waves<NX>())
+__global__ void __launch_bounds__((row_threads<NX, FAST>()), (fused_row_min_waves<NX, false>()))
 k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
            const cd* __restrict__ twx, TS* __restrict__ Tbuf, int n_ps, int n_sersic, int ny,
            int ps_only, const double* __restrict__ img, const double* __restrict__ img_scale,
@@ -728,7 +750,7 @@ k_cols3g(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restr
 // so that the one-field kernel keeps its registers (at nx = 1024 two more kernel arguments pushed the
 // scalar registers over their limit and the kernel to one wave per SIMD: 33.7 -> 39.6 us)
 template <int NX, typename TS = cd, bool FAST = FftShape<NX>::kPlain, bool MULTI = false>
-__global__ void __launch_bounds__((row_threads<NX, FAST>()), fused_min_waves<NX>())
+__global__ void __launch_bounds__((row_threads<NX, FAST>()), (fused_row_min_waves<NX, true>()))
 k_rows_inv(const TS* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const cd* __restrict__ twx,
            const FieldPx* __restrict__ field, double* __restrict__ partial, int ny,
            const double* __restrict__ prep, int plen,
