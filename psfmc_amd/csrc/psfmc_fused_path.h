@@ -137,7 +137,11 @@ constexpr bool row_two_waves_side(int n) { return n == 650 || n == 676 || n == 7
 // kernel at 220 ... 300, the inverse at the small sides -- the spills cost more than the extra wave hides.
 constexpr int row_fwd_more_waves(int n) { return (n == 84 || n == 98 || n == 132) ? 4 : ((n == 160 || n == 176) ? 3 : 0); }
 constexpr int row_inv_more_waves(int n) { return (n == 220 || n == 260 || n == 280 || n == 300) ? 3 : 0; }
+#ifndef PSFMC_FWD512_WAVES
+#define PSFMC_FWD512_WAVES 0          /* k_rows_fwd<512> (184 registers) bounded to 3 waves per SIMD: 12 spilled, 46.3 -> 52.2 us, step -2.5 % */
+#endif
 template <int N, bool INVERSE> constexpr int fused_row_min_waves() {
+    if (PSFMC_FWD512_WAVES && N == 512 && !INVERSE) return PSFMC_FWD512_WAVES;
     if (FftShape<N>::kPlain) return fused_min_waves<N>();
     if ((INVERSE ? row_inv_more_waves(N) : row_fwd_more_waves(N)) > 0) return INVERSE ? row_inv_more_waves(N) : row_fwd_more_waves(N);
     return (FftShape<N>::R > PSFMC_GEN_ROW_R_2WAVES && !row_two_waves_side(N)) ? 1 : 2;
