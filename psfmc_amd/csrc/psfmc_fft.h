@@ -771,8 +771,9 @@ struct Fft3gPick { int r2, r3; };
 // factorisation was timed against the two-stage kernel on an MI355X (tools/cols3g_shapes.hip;
 // profiles/r3_cols3g_shapes.txt).  What wins: R2 = 4 (stage 2 is then NB2 = R1 / 4 cheap radix-4 passes and stage 3
 // one radix-R3 pass, R3 <= 15: the widest stage holds max(R1, R3) complex registers) or 8 x 8 on all 64 lanes;
-// R3 = 16 and the 5 x 10 / 10 x 5 splits of 50 lanes (650, 700, 800) lose to the two-stage kernel, as does
-// every side whose two-stage shape has T <= 21 lanes per transform (the small sides).
+// R3 = 16 and the 5 x 10 / 10 x 5 splits of 50 lanes at R1 >= 13 (650, 700, 800) lose to the two-stage kernel, as
+// does every side whose two-stage shape has T <= 21 lanes per transform (the small sides); 250, 294, 330, whose
+// two-stage kernels hold 21 ... 25 complex registers at one wave per SIMD, win 14 ... 25 % on it.
 constexpr Fft3gPick fft3g_pick(int n) {
     switch (n) {
         case 264: case 308: case 352: case 484: return {4, 11};
@@ -781,8 +782,9 @@ constexpr Fft3gPick fft3g_pick(int n) {
         case 392: case 504: case 560: case 616: case 672: case 728: case 784: case 840: case 896: return {4, 14};
         case 480: case 900: return {4, 15};
         case 448: return {4, 16};
-        case 440: return {5, 11};
-        case 500: return {5, 10};
+        case 330: case 440: return {5, 11};
+        case 250: case 500: return {5, 10};
+        case 294: return {7, 7};
         case 600: case 660: case 720: return {5, 12};
         case 512: case 640: case 704: case 768: case 832: case 960: case 1024: return {8, 8};
         default: return {0, 0};

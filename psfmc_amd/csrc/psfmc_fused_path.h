@@ -111,6 +111,9 @@ template <int NY> constexpr size_t fused_col_lds_bytes() {
 #define PSFMC_GEN_R_2WAVES 16     /* general shapes with up to this many registers are compiled for 2 waves per SIMD
                                      (20 spills: k_cols<300> 102 us instead of 77, k_cols<320> 88 instead of 53) */
 #endif
+#ifndef PSFMC_GEN_PF_MAX_R
+#define PSFMC_GEN_PF_MAX_R 20        /* general shapes with up to this many registers per lane prefetch the next column */
+#endif
 #ifndef PSFMC_GEN_STAGED
 #define PSFMC_GEN_STAGED 1
 #endif
@@ -436,7 +439,7 @@ k_cols(TS* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restric
     // stores (issued before the forward transform they made the multiply wait for them:
     // 56 us instead of 46; here 43 us).  The twiddles live in LDS to make room.
     // (general shapes: only those compiled for one wave per SIMD have the registers for it)
-    constexpr bool PF = PSFMC_COLS_PREFETCH && (S::kPlain ? R <= 16 : (R > PSFMC_GEN_R_2WAVES && R <= 20));
+    constexpr bool PF = PSFMC_COLS_PREFETCH && (S::kPlain ? R <= 16 : (R > PSFMC_GEN_R_2WAVES && R <= PSFMC_GEN_PF_MAX_R));
     struct Slot {
         TS* base;
         int w, kx, c;

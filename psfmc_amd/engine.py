@@ -37,7 +37,8 @@ _COLS3G_SHAPES = {}
 for _sides, _shape in (((264, 308, 352, 484), (4, 11)), ((384, 528, 576), (4, 12)),
                        ((312, 364, 416, 520, 572, 624, 676, 780), (4, 13)),
                        ((392, 504, 560, 616, 672, 728, 784, 840, 896), (4, 14)), ((480, 900), (4, 15)),
-                       ((448,), (4, 16)), ((440,), (5, 11)), ((500,), (5, 10)), ((600, 660, 720), (5, 12)),
+                       ((448,), (4, 16)), ((330, 440), (5, 11)), ((250, 500), (5, 10)), ((294,), (7, 7)),
+                       ((600, 660, 720), (5, 12)),
                        ((640, 704, 768, 832, 960), (8, 8))):
     for _n in _sides:
         _COLS3G_SHAPES[_n] = _shape
