@@ -128,18 +128,25 @@ template <int N> constexpr int fused_min_waves() {
 // the waves per SIMD for the sake of a handful of values.  Bounded to two waves, 650 / 700 / 720 spill 4 ... 10
 // registers and run 20 ... 24 % faster (whole step, same box: 94 -> 117 k, 88 -> 105 k, 94 -> 113 k evals/s), 676
 // (18 spilled) +9 %, 780 (29) +3 %; 728, 784, 840, 900 (25 ... 51 spilled) measured 2 ... 14 % SLOWER and keep one
-// wave.  (PSFMC_GEN_ROW_R_2WAVES = 32 bounds every general shape to two waves, for the A/B.)
+// wave.  630 and 660: only the inverse kernel was over, by 2 registers: 57 -> 41 us and 68 -> 47 us, step +14 % / +13 %.  (PSFMC_GEN_ROW_R_2WAVES = 32 bounds every general shape to two waves, for the A/B.)
 #ifndef PSFMC_GEN_ROW_R_2WAVES
 #define PSFMC_GEN_ROW_R_2WAVES 16
 #endif
-constexpr bool row_two_waves_side(int n) { return n == 650 || n == 676 || n == 700 || n == 720 || n == 780; }
+constexpr bool row_two_waves_side(int n) {
+    return n == 630 || n == 650 || n == 660 || n == 676 || n == 700 || n == 720 || n == 780;
+}
 // Sides whose row kernels sit 2 ... 8 registers above an occupancy step (130 vector registers: three waves per
 // SIMD instead of four; 172 ... 176: two instead of three), bounded to the next step where that measured faster
 // (same box, kernel time): the forward kernel of 84, 98, 132, 160, 176 (-3 ... -6 %), the inverse kernel of 220, 260,
 // 280, 300 (-9 ... -13 %: k_rows_inv<300> 41.9 -> 38.2 us, step +2.9 %).  The other way round -- the rasteriser's
-// kernel at 220 ... 300, the inverse at the small sides -- the spills cost more than the extra wave hides.
+// kernel at 220 ... 300, the inverse at the small sides -- the spills cost more than the extra wave hides; so they
+// do for the inverse kernels of 88, 96, 160, 176, 192 (140 registers -> 128: -0.1 ... -2.4 %) and 294, 320, 336
+// (174 ... 182 -> 168: -1 ... -15 %).
 constexpr int row_fwd_more_waves(int n) { return (n == 84 || n == 98 || n == 132) ? 4 : ((n == 160 || n == 176) ? 3 : 0); }
-constexpr int row_inv_more_waves(int n) { return (n == 220 || n == 260 || n == 280 || n == 300) ? 3 : 0; }
+constexpr int row_inv_more_waves(int n) {
+    if (n == 150 || n == 180) return 4;                 // (132 / 131 registers; +1 %)
+    return (n == 220 || n == 260 || n == 280 || n == 300) ? 3 : 0;
+}
 #ifndef PSFMC_FWD512_WAVES
 #define PSFMC_FWD512_WAVES 0          /* k_rows_fwd<512> (184 registers) bounded to 3 waves per SIMD: 12 spilled, 46.3 -> 52.2 us, step -2.5 % */
 #endif
