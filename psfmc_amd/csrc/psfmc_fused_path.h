@@ -150,7 +150,11 @@ constexpr int row_inv_more_waves(int n) {
 #ifndef PSFMC_FWD512_WAVES
 #define PSFMC_FWD512_WAVES 0          /* k_rows_fwd<512> (184 registers) bounded to 3 waves per SIMD: 12 spilled, 46.3 -> 52.2 us, step -2.5 % */
 #endif
-template <int N, bool INVERSE> constexpr int fused_row_min_waves() {
+// the forward kernel's WRAP variant (embedded images) carries a few registers more: at 768 -- a frequent embedding
+// target -- that took it to 256 + 32 accumulation registers and one wave per SIMD
+constexpr bool row_fwd_wrap_two_waves(int n) { return n == 768; }
+template <int N, bool INVERSE, bool WRAP = false> constexpr int fused_row_min_waves() {
+    if (WRAP && !INVERSE && row_fwd_wrap_two_waves(N)) return 2;
     if (PSFMC_FWD512_WAVES && N == 512 && !INVERSE) return PSFMC_FWD512_WAVES;
     if (FftShape<N>::kPlain) return fused_min_waves<N>();
     if ((INVERSE ? row_inv_more_waves(N) : row_fwd_more_waves(N)) > 0) return INVERSE ? row_inv_more_waves(N) : row_fwd_more_waves(N);
@@ -234,7 +238,7 @@ __global__ void k_pack_field(const double* __restrict__ sci, const double* __res
 // WRAP: the image is embedded in a larger transform size (psfmc_device.h WrapDesc); ny, NX are the
 // transform's sides
 template <int NX, bool FROM_IMAGE, typename TS = cd, bool FAST = FftShape<NX>::kPlain, bool WRAP = false>
-__global__ void __launch_bounds__((row_threads<NX, FAST>()), (fused_row_min_waves<NX, false>()))
+__global__ void __launch_bounds__((row_threads<NX, FAST>()), (fused_row_min_waves<NX, false, WRAP>()))
 k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
            const cd* __restrict__ twx, TS* __restrict__ Tbuf, int n_ps, int n_sersic, int ny,
            int ps_only, const double* __restrict__ img, const double* __restrict__ img_scale,
