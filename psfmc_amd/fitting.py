@@ -65,7 +65,9 @@ def model_galaxy_mcmc(model_file, output_name=None, write_fits=default_filetypes
 
     mc_model = model_file if isinstance(model_file, MultiComponentModel) else None
     if mc_model is None:
-        n_hint = max(chains or 0, 64)
+        # room for batches beyond the ensemble: the posterior images are recomputed from the filtered database in
+        # slices of max_walkers samples (152 k samples in slices of 64 were 2300 calls, a fifth of a default fit)
+        n_hint = max(chains or 0, 1024)
         mc_model = MultiComponentModel(model_file, device=device, backend=backend,
                                        max_walkers=n_hint)
     ranks = _rank_group(group, mc_model._device)
