@@ -10,6 +10,16 @@
 
 namespace psfmc {
 
+// LDS hand-off between lanes of ONE wave.  A wave's DS instructions execute in
+// program order, so a ds_read issued after a ds_write of the same wave observes
+// it; all that is needed is that the compiler keeps that order (the fences) and
+// that the wave is converged here.  No s_barrier: waves never wait for each other.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 constexpr int kRowSky = 1;      // doubles in a caller row (include/psfmc_hip.h)
 constexpr int kRowPs = 4;
 constexpr int kRowSersic = 9;
@@ -27,8 +37,17 @@ constexpr int kPrepSersic = 9;
 __host__ __device__ inline int row_len(int n_ps, int n_sersic) {
     return kRowSky + kRowPs * n_ps + kRowSersic * n_sersic + 1;
 }
-__host__ __device__ inline int prep_len(int n_ps, int n_sersic) {
+// Behind the record proper, per Sersic component: the POWER TABLES of its radial exponent p = 1/(2n)
+// (k_pow_tables; what raster_row reads instead of evaluating log2 + exp2 per pixel):
+//   [0, 256)    PB[j] = 2^(p b_j), b_j = -log2(a_j) of the rasteriser's mantissa table (psfmc_log_table.h)
+//   [256, 512)  PE[i] = 2^(p (i - 128)): the exponent e = i - 128 of rho^2 = 2^e m, clamped to [-128, 127]
+constexpr int kPowTabB = 256, kPowTabE = 256, kPowTabEBias = 128;
+constexpr int kPowTab = kPowTabB + kPowTabE;
+__host__ __device__ inline int prep_rec_len(int n_ps, int n_sersic) {
     return kPrepHead + kPrepPs * n_ps + kPrepSersic * n_sersic;
+}
+__host__ __device__ inline int prep_len(int n_ps, int n_sersic) {
+    return prep_rec_len(n_ps, n_sersic) + kPowTab * n_sersic;
 }
 
 // ---------------------------------------------------------------------------
@@ -273,6 +292,89 @@ __device__ __forceinline__ double fast_log2_tab(double x, const double* __restri
     return __builtin_fma(r, p, (double)e + ab.y);
 }
 
+// ---------------------------------------------------------------------------
+// t = (rho^2)^p without a logarithm or an exponential per pixel (round 3).  With rho^2 = 2^e m, m in
+// [1/2, 1), and the mantissa table's a_j (|m a_j - 1| = |r| <= 2^-9, b_j = -log2 a_j):
+//     (rho^2)^p = 2^(p e) * 2^(p b_j) * (1 + r)^p = PE[e] * PB[j] * (1 + r (q1 + r (q2 + ... + r q5)))
+// q_k = binomial(p, k) (truncation binomial(p, 6) 2^-54: 1e-18 for n >= 1/4, 1e-14 at n = 0.05 where
+// kappa ~ 1e-3 scales it away), and the two tables depend on the walker's p only: k_pow_tables writes
+// them behind the prep record, a row wave copies them into LDS once per component (3 KB for its
+// 1024 ... 2048 pixels).  14 vector instructions where table log2 + multiply + exp2 were 31; the three
+// roundings of PE PB (1 + d) replace the rounding of p log2(rho^2), which grew with |log2 rho^2|.
+// LDS layout of a wave's rasteriser region (kRasterLdsDoubles): [2j] = a_j, [2j + 1] = PB[j] (one
+// 16-byte read per pixel, as the log2 table had), then PE[256].
+// ---------------------------------------------------------------------------
+constexpr int kRasterLdsDoubles = 2 * kPowTabB + kPowTabE;
+// the static half: a_j into the even slots (converged call, once per wave)
+__device__ __forceinline__ void load_a_table(double* __restrict__ lds, int lane) {
+    const double a0 = kLog2Tab[lane][0], a1 = kLog2Tab[lane + 64][0], a2 = kLog2Tab[lane + 128][0],
+                 a3 = kLog2Tab[lane + 192][0];
+    lds[2 * lane] = a0;
+    lds[2 * (lane + 64)] = a1;
+    lds[2 * (lane + 128)] = a2;
+    lds[2 * (lane + 192)] = a3;
+}
+// one component's tables (global, behind the walker's prep record) into the odd slots and the PE part
+__device__ __forceinline__ void load_pow_table(double* __restrict__ lds, const double* __restrict__ g, int lane) {
+    double b[4], e[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        b[i] = g[lane + 64 * i];
+        e[i] = g[kPowTabB + lane + 64 * i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        lds[2 * (lane + 64 * i) + 1] = b[i];
+        lds[2 * kPowTabB + lane + 64 * i] = e[i];
+    }
+}
+// 2^(p x) with the product carried in two pieces (hi + lo exactly p x), OCML exp2 (< 1 ulp)
+__device__ inline double pow2_product(double p, double x) {
+    const double hi = p * x;
+    const double lo = __builtin_fma(p, x, -hi);
+    const double v = exp2(hi);
+    const double c = __builtin_fma(v, lo * 0.69314718055994530942, v);
+    return (v > 0.0 && v < 1e300 && lo == lo) ? c : v;
+}
+// the power tables of one (walker, component): all 64 lanes of a wave, 8 entries each
+__device__ inline void build_pow_table(double p, double* __restrict__ g, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = lane + 64 * i;
+        g[j] = pow2_product(p, kLog2Tab[j][1]);
+        g[kPowTabB + j] = pow2_product(p, (double)(j - kPowTabEBias));
+    }
+}
+struct PowPoly { double q1, q2, q3, q4, q5; };
+__device__ __forceinline__ PowPoly pow_poly(double p) {
+    PowPoly q;
+    q.q1 = p;
+    q.q2 = q.q1 * (p - 1.0) * 0.5;
+    q.q3 = q.q2 * (p - 2.0) * 0.33333333333333333333;
+    q.q4 = q.q3 * (p - 3.0) * 0.25;
+    q.q5 = q.q4 * (p - 4.0) * 0.2;
+    return q;
+}
+// (rho^2)^p from the wave's LDS tables; x >= 0 finite (x = 0: some finite value -- the pixel is NaN
+// through the centroid term's reciprocal, as the reference's 0/0)
+__device__ __forceinline__ double fast_pow_tab(double x, const PowPoly& q, const double* __restrict__ tab) {
+    const int e = __builtin_amdgcn_frexp_exp(x);
+    const double m = __builtin_amdgcn_frexp_mant(x);            // [0.5, 1)
+    const unsigned off = ((unsigned)__double2hiint(m) >> 8) & 0xff0u;   // 16 j
+    const double2 ab = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(tab) + off);
+    const int ei = min(max(e, -kPowTabEBias), kPowTabE - kPowTabEBias - 1);      // v_med3_i32
+    const double pe = tab[2 * kPowTabB + kPowTabEBias + ei];
+    const double r = __builtin_fma(m, ab.x, -1.0);
+    double d = q.q5;
+    d = __builtin_fma(d, r, q.q4);
+    d = __builtin_fma(d, r, q.q3);
+    d = __builtin_fma(d, r, q.q2);
+    d = __builtin_fma(d, r, q.q1);
+    d *= r;
+    const double eb = pe * ab.y;
+    return __builtin_fma(eb, d, eb);
+}
+
 // 2^y for finite |y| (any magnitude: ldexp saturates); no inf handling.
 __device__ __forceinline__ double fast_exp2_poly(double r);
 __device__ __forceinline__ double fast_exp2_noclamp(double y) {
@@ -301,19 +403,14 @@ __device__ __forceinline__ double fast_exp2_floor(double y) {
 
 // 2^r, |r| <= 1/2: degree-11 near-minimax polynomial (Chebyshev interpolant at 50 digits;
 // truncation 3e-18, where the degree-12 Taylor series it replaces had 1.7e-16)
+constexpr double kExp2Deg11[12] = {
+    1.00000000000000000e+00, 6.93147180559945286e-01, 2.40226506959101582e-01, 5.55041086648216248e-02,
+    9.61812910758725638e-03, 1.33335581464064708e-03, 1.54035304637243530e-04, 1.52527338415567733e-05,
+    1.32154325359123753e-06, 1.01780570877339407e-07, 7.07419429728852106e-09, 4.45581790833606449e-10};
 __device__ __forceinline__ double fast_exp2_poly(double r) {
-    double p = 4.45581790833606449e-10;
-    p = __builtin_fma(p, r, 7.07419429728852106e-09);
-    p = __builtin_fma(p, r, 1.01780570877339407e-07);
-    p = __builtin_fma(p, r, 1.32154325359123753e-06);
-    p = __builtin_fma(p, r, 1.52527338415567733e-05);
-    p = __builtin_fma(p, r, 1.54035304637243530e-04);
-    p = __builtin_fma(p, r, 1.33335581464064708e-03);
-    p = __builtin_fma(p, r, 9.61812910758725638e-03);
-    p = __builtin_fma(p, r, 5.55041086648216248e-02);
-    p = __builtin_fma(p, r, 2.40226506959101582e-01);
-    p = __builtin_fma(p, r, 6.93147180559945286e-01);
-    p = __builtin_fma(p, r, 1.00000000000000000e+00);
+    double p = kExp2Deg11[11];
+#pragma unroll
+    for (int i = 10; i >= 0; --i) p = __builtin_fma(p, r, kExp2Deg11[i]);
     return p;
 }
 
@@ -357,9 +454,10 @@ __device__ __forceinline__ int wrap_coord(int p, int a, int l) {
 
 // K0: the lane's pixels are x = T (K0 + k) + t, k < P (a segment of a longer row; 0 for whole rows)
 // WRAP: `iy` and x are transform coordinates of an embedded image (see WrapDesc)
-template <int P, int T, int K0 = 0, bool WRAP = false>
+// G: Sersic pixels per lane that go through the profile's stages together (1: pixel after pixel)
+template <int P, int T, int K0 = 0, bool WRAP = false, int G = 1>
 __device__ __forceinline__ void raster_row(const double* __restrict__ prep, int n_ps, int n_sersic,
-                                           int t, int iy, bool ps_only, const double* __restrict__ log_tab,
+                                           int t, int iy, bool ps_only, double* __restrict__ log_tab,
                                            double (&r)[P], const WrapDesc& wr = WrapDesc{0, 0, 0, 0, 0, 0}) {
     const double sky = ps_only ? 0.0 : prep[0];
 #pragma unroll
@@ -373,6 +471,21 @@ __device__ __forceinline__ void raster_row(const double* __restrict__ prep, int 
         for (int k = 0; k < P; ++k) xm[k] = wrap_coord(T * (K0 + k) + t, wr.ax, wr.lx);
     }
     const double* p = prep + kPrepHead;
+    const double* const sersic0 = p + kPrepPs * n_ps;              // the Sersic blocks, then their power tables
+    const double* const pow_tabs = sersic0 + kPrepSersic * n_sersic;   // (behind the record: prep_len)
+    const int lane_id = (int)(threadIdx.x & 63);
+    struct Block { double par, b[4], e[4]; };
+    auto issue = [&](int c, Block& B) {
+        B.par = sersic0[c * kPrepSersic + (lane_id < kPrepSersic ? lane_id : 0)];
+        const double* g = pow_tabs + (size_t)c * kPowTab;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            B.b[i] = g[lane_id + 64 * i];
+            B.e[i] = g[kPowTabB + lane_id + 64 * i];
+        }
+    };
+    Block cur{}, nxt{};
+    if (!ps_only && n_sersic > 0) issue(0, cur);                  // in flight during the point sources
     for (int c = 0; c < n_ps; ++c, p += kPrepPs) {
         const int ty = iy - (int)p[0];
         const bool row_in = ty >= 0 && ty < (int)p[1];
@@ -401,27 +514,104 @@ __device__ __forceinline__ void raster_row(const double* __restrict__ prep, int 
     }
     constexpr double kLog2e = 1.44269504088896340736;
     const double y = (double)iy;
-    for (int c = 0; c < n_sersic; ++c, p += kPrepSersic) {
-        const double x0 = p[0], y0 = p[1], m00 = p[2], m01 = p[3], m10 = p[4], m11 = p[5];
-        const double kappa = p[6], pw = p[7], sbeff = p[8];
+    // A component's parameters and power tables are PREFETCHED through vector loads while the previous
+    // component's pixels are evaluated (lane i < 9 brings parameter i, every lane eight table entries), and
+    // the parameters are then broadcast into scalar registers with v_readlane.  Read as scalar loads at the head
+    // of each component (round 2), every wave stood still for the round trip of the s_load, then again for the
+    // table's: 40 % of a wave's lifetime in k_rows_fwd<1024> with four components was s_waitcnt
+    // (SQ_WAIT_INST_ANY), and two waves per SIMD do not hide that for each other.
+    auto bcast = [](double v, int src) {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src),
+                                __builtin_amdgcn_readlane(__double2loint(v), src));
+    };
+    for (int c = 0; c < n_sersic; ++c) {
+        if (c + 1 < n_sersic) issue(c + 1, nxt);           // in flight during this component's pixels
+        const double x0 = bcast(cur.par, 0), y0 = bcast(cur.par, 1), m00 = bcast(cur.par, 2), m01 = bcast(cur.par, 3),
+                     m10 = bcast(cur.par, 4), m11 = bcast(cur.par, 5);
+        const double kappa = bcast(cur.par, 6), pw = bcast(cur.par, 7), sbeff = bcast(cur.par, 8);
         const double dy = y - y0;
         const double uy = m01 * dy, vy = m11 * dy, dy2 = dy * dy;
         const double nkl = -kappa * kLog2e;                // sb = 2^(nkl (t - 1))
         // g = gk t / sqrt(rho2); the 1/12 of the centroid term rides on gk
         const double gk = -2.0 * kappa * pw * 0.28867513459481288225;   // sqrt(1/12)
+        const PowPoly q = pow_poly(pw);
+        wave_lds_sync();                                   // the previous component's reads are done
 #pragma unroll
-        for (int k = 0; k < P; ++k) {
-            const double dx = (double)(WRAP ? xm[k] : T * (K0 + k) + t) - x0;   // exact pixel coordinate, one rounding
-            const double u = __builtin_fma(m00, dx, uy);
-            const double v = __builtin_fma(m10, dx, vy);
-            const double rho2 = __builtin_fma(u, u, v * v);
-            const double d2 = __builtin_fma(dx, dx, dy2);
-            const double tt = fast_exp2_noclamp(pw * fast_log2_tab(rho2, log_tab));
-            const double sb = fast_exp2_floor(__builtin_fma(nkl, tt, -nkl));
-            // g^2 q / 12 = (gk t)^2 / rho2 * rho2 / d2: the elliptical radius cancels
-            const double gt = gk * tt;
-            r[k] = __builtin_fma(sbeff * sb, __builtin_fma(gt * gt, fast_rcp1(d2), 1.0), r[k]);
+        for (int i = 0; i < 4; ++i) {
+            log_tab[2 * (lane_id + 64 * i) + 1] = cur.b[i];
+            log_tab[2 * kPowTabB + lane_id + 64 * i] = cur.e[i];
         }
+        wave_lds_sync();
+        // G > 1 (the kernels that run at two waves per SIMD anyway): the pixels go through the profile in GROUPS
+        // of G, stage by stage (every stage for all pixels of the group before the next stage), and the table
+        // reads of the next group are issued before the current group's arithmetic.  Written pixel after pixel
+        // (G = 1) the compiler keeps that order -- one dependent chain of ~45 instructions per pixel behind an LDS
+        // read it waits for at once -- which four waves per SIMD hide and two do not; a wave alone on its SIMD
+        // (the last half round of a 512^2 / 1024^2 launch) ran at the latency of that chain.
+        constexpr int kG = G, NG = (P + kG - 1) / kG;
+        struct Fetched { double m[kG], d2[kG], pe[kG]; double2 ab[kG]; };
+        auto fetch = [&](int g, Fetched& F) {
+#pragma unroll
+            for (int j = 0; j < kG; ++j) {
+                const int k = g * kG + j;
+                if (k < P) {
+                    const double dx = (double)(WRAP ? xm[k] : T * (K0 + k) + t) - x0;   // exact pixel coordinate, one rounding
+                    const double u = __builtin_fma(m00, dx, uy);
+                    const double v = __builtin_fma(m10, dx, vy);
+                    const double rho2 = __builtin_fma(u, u, v * v);
+                    F.d2[j] = __builtin_fma(dx, dx, dy2);
+                    const int e = __builtin_amdgcn_frexp_exp(rho2);
+                    F.m[j] = __builtin_amdgcn_frexp_mant(rho2);                         // [0.5, 1)
+                    const unsigned off = ((unsigned)__double2hiint(F.m[j]) >> 8) & 0xff0u;   // 16 j
+                    F.ab[j] = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(log_tab) + off);
+                    const int ei = min(max(e, -kPowTabEBias), kPowTabE - kPowTabEBias - 1);  // v_med3_i32
+                    F.pe[j] = log_tab[2 * kPowTabB + kPowTabEBias + ei];
+                }
+            }
+        };
+        auto finish = [&](int g, const Fetched& F) {
+            double rr[kG], d[kG], tt[kG], yy[kG], nn[kG], sb[kG], rc[kG];
+            auto each = [&](auto&& fn) {
+#pragma unroll
+                for (int j = 0; j < kG; ++j)
+                    if (g * kG + j < P) fn(j);
+            };
+            // t = rho2^p = PE PB (1 + r (q1 + r (q2 + ...)))      (fast_pow_tab)
+            each([&](int j) { rr[j] = __builtin_fma(F.m[j], F.ab[j].x, -1.0); d[j] = __builtin_fma(q.q5, rr[j], q.q4); });
+            each([&](int j) { d[j] = __builtin_fma(d[j], rr[j], q.q3); });
+            each([&](int j) { d[j] = __builtin_fma(d[j], rr[j], q.q2); });
+            each([&](int j) { d[j] = __builtin_fma(d[j], rr[j], q.q1); });
+            each([&](int j) { d[j] *= rr[j]; tt[j] = F.pe[j] * F.ab[j].y; });
+            each([&](int j) { tt[j] = __builtin_fma(tt[j], d[j], tt[j]); });
+            // sb = 2^(nkl (t - 1))                                 (fast_exp2_floor)
+            each([&](int j) { yy[j] = __builtin_fmax(__builtin_fma(nkl, tt[j], -nkl), -1100.0); nn[j] = __builtin_rint(yy[j]); });
+            each([&](int j) { yy[j] -= nn[j]; sb[j] = __builtin_fma(kExp2Deg11[11], yy[j], kExp2Deg11[10]); });
+#pragma unroll
+            for (int i = 9; i >= 0; --i) each([&](int j) { sb[j] = __builtin_fma(sb[j], yy[j], kExp2Deg11[i]); });
+            each([&](int j) { sb[j] = __builtin_amdgcn_ldexp(sb[j], (int)nn[j]); rc[j] = __builtin_amdgcn_rcp(F.d2[j]); });
+            // 1 / d2 with one Newton step (fast_rcp1); g^2 q / 12 = (gk t)^2 / rho2 * rho2 / d2: the elliptical
+            // radius cancels
+            each([&](int j) { rc[j] = __builtin_fma(rc[j], __builtin_fma(-F.d2[j], rc[j], 1.0), rc[j]); tt[j] *= gk; });
+            each([&](int j) { tt[j] *= tt[j]; sb[j] *= sbeff; });
+            each([&](int j) { r[g * kG + j] = __builtin_fma(sb[j], __builtin_fma(tt[j], rc[j], 1.0), r[g * kG + j]); });
+        };
+        Fetched F[2];
+        if constexpr (kG == 1) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                fetch(g, F[0]);
+                finish(g, F[0]);
+            }
+        } else {
+            fetch(0, F[0]);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) fetch(g + 1, F[(g + 1) & 1]);
+                finish(g, F[g & 1]);
+                __builtin_amdgcn_sched_barrier(0);          // two groups in flight, not more (registers)
+            }
+        }
+        cur = nxt;
     }
     blank_margin();
 }

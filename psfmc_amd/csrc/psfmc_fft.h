@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include "psfmc_trig_table.h"
+#include "psfmc_device.h"
 
 namespace psfmc {
 
@@ -490,15 +491,7 @@ template <int SIGN> struct Dft<2, SIGN, 2> {
     }
 };
 
-// LDS hand-off between lanes of ONE wave.  A wave's DS instructions execute in
-// program order, so a ds_read issued after a ds_write of the same wave observes
-// it; all that is needed is that the compiler keeps that order (the fences) and
-// that the wave is converged here.  No s_barrier: waves never wait for each other.
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
+// wave_lds_sync (the wave-local LDS hand-off the transforms use between stages): psfmc_device.h
 
 // Per-lane inter-stage twiddles W_N^(t*c), c < P, from the table tw[k] =
 // exp(-2 pi i k/N).  Three homes (PSFMC_TW_MODE):

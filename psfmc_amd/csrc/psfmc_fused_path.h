@@ -63,11 +63,26 @@ constexpr int kInvRemapMaxWalkers = 24;
 #ifndef PSFMC_INV_CHUNK
 #define PSFMC_INV_CHUNK 8             /* field pixels per load chunk of k_rows_inv at nx = 512, 1024 */
 #endif
+#ifndef PSFMC_DEBUG_FWD
+#define PSFMC_DEBUG_FWD 0            /* timing experiments on k_rows_fwd: 1 = no store phase, 2 = no transform */
+#endif
 #ifndef PSFMC_COLS_PREFETCH
 #define PSFMC_COLS_PREFETCH 1         /* register double-buffering of the column loads */
 #endif
 
 template <int NX> constexpr int row_group() { return FftShape<NX>::TPW; }         // rows per wave
+// Sersic pixels per lane that the forward kernel's rasteriser takes through the profile together (raster_row's
+// G), by measurement (same box, 2 ... 4 components): 4 for the general shapes that hold more than 16 complex
+// registers per lane and run at two waves per SIMD whatever the rasteriser needs (k_rows_fwd<300> 58.9 -> 52.5 us,
+// <600> 54.3 -> 48.2, <768> 70 -> 63: whole step +2 ... +5 %); 1 for the power-of-two shapes (512 / 1024: 43.5 vs
+// 47.1 us and 66.7 vs 68.9 us -- the grouped form spills there -- and the small ones live on four waves per SIMD)
+// and for three sides that the grouped form takes from three waves per SIMD to two (252, 286, 294: +5 % kernel time)
+#ifndef PSFMC_RASTER_GROUP
+#define PSFMC_RASTER_GROUP 4
+#endif
+template <int NX> constexpr int raster_group() {
+    return (!FftShape<NX>::kPlain && FftShape<NX>::R > 16 && NX != 252 && NX != 286 && NX != 294) ? PSFMC_RASTER_GROUP : 1;
+}
 // rows that share a contiguous run of T per kx (the "RG" of the layout comment above): the rows
 // of one wave for the power-of-two shapes, 4 otherwise (ny is rounded up to a multiple of it in
 // the layout; the spare rows are never read)
@@ -93,8 +108,10 @@ template <int NX, bool FAST = FftShape<NX>::kPlain> constexpr int row_waves() {
 }
 template <int NX, bool FAST = FftShape<NX>::kPlain> constexpr int row_threads() { return 64 * row_waves<NX, FAST>(); }
 // per wave: the exchange regions of its RG transforms, then its twiddle table
+// (at least the rasteriser's tables, which borrow the region before the transform starts: psfmc_device.h)
 template <int NX> constexpr size_t fused_row_wave_lds_doubles() {
-    return (size_t)row_group<NX>() * fft_lds_elems<NX>() + 2 * (size_t)fft_tw_lds_elems<NX>();
+    constexpr size_t fft = (size_t)row_group<NX>() * fft_lds_elems<NX>() + 2 * (size_t)fft_tw_lds_elems<NX>();
+    return fft > (size_t)kRasterLdsDoubles ? fft : (size_t)kRasterLdsDoubles;
 }
 template <int NX, bool FAST = FftShape<NX>::kPlain> constexpr size_t fused_row_lds_bytes() {
     return (size_t)row_waves<NX, FAST>() * fused_row_wave_lds_doubles<NX>() * sizeof(double);
@@ -156,6 +173,9 @@ constexpr bool row_fwd_wrap_two_waves(int n) { return n == 768; }
 template <int N, bool INVERSE, bool WRAP = false> constexpr int fused_row_min_waves() {
     if (WRAP && !INVERSE && row_fwd_wrap_two_waves(N)) return 2;
     if (PSFMC_FWD512_WAVES && N == 512 && !INVERSE) return PSFMC_FWD512_WAVES;
+    // (the rasteriser's grouped pixel stages let the allocator of the 512 / 1024 forward kernels drift past 256
+    // registers where it used to stop at 185 ... 220 by itself)
+    if (FftShape<N>::kPlain && !INVERSE && N >= 512) return 2;
     if (FftShape<N>::kPlain) return fused_min_waves<N>();
     if ((INVERSE ? row_inv_more_waves(N) : row_fwd_more_waves(N)) > 0) return INVERSE ? row_inv_more_waves(N) : row_fwd_more_waves(N);
     return (FftShape<N>::R > PSFMC_GEN_ROW_R_2WAVES && !row_two_waves_side(N)) ? 1 : 2;
@@ -278,16 +298,13 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
         const double* wprep = prep + (size_t)w * prep_len(n_ps, n_sersic);   // wave-uniform
         const double mu = wprep[kPrepMu];
         if (skipped) return;                          // a skipped walker's record may hold anything
-        // the rasteriser's log2 table borrows the start of the wave's transform exchange region,
-        // which is idle until the transform begins
-        static_assert((size_t)RG * fft_lds_elems<NX>() * sizeof(double) >= (size_t)kLogTabBytes, "exchange region too small");
+        // the rasteriser's tables borrow the start of the wave's transform region (exchange area and
+        // twiddle table), which is idle until the transform begins
+        static_assert(fused_row_wave_lds_doubles<NX>() >= (size_t)kRasterLdsDoubles, "wave region too small");
         double* log_tab = smem + (size_t)wave * fused_row_wave_lds_doubles<NX>();
-        if (!ps_only) {
-            load_log_table(log_tab, lane);
-            wave_lds_sync();
-        }
+        if (!ps_only && n_sersic > 0) load_a_table(log_tab, lane);       // (raster_row fences before its reads)
         double r[P];
-        raster_row<P, T, 0, WRAP>(wprep, n_ps, n_sersic, t, iy, ps_only != 0, log_tab, r, wr);
+        raster_row<P, T, 0, WRAP, raster_group<NX>()>(wprep, n_ps, n_sersic, t, iy, ps_only != 0, log_tab, r, wr);
         wave_lds_sync();
 #pragma unroll
         for (int k = 0; k < P; ++k) v[k] = cd{r[k], mu * r[k] * r[k]};
@@ -302,9 +319,20 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
     cd tw[fft_tw_regs<NX>()];
     load_twiddles<NX>(tw, twx, t, twl, lane);
     double* xbuf = wave_lds + (size_t)fe * fft_lds_elems<NX>();
+#if !(PSFMC_DEBUG_FWD & 2)
     fft_wave<NX, -1>(v, tw, twx, t, xbuf, twl, lane_on);
+#endif
 
     cd* ubuf = reinterpret_cast<cd*>(xbuf);
+#if PSFMC_DEBUG_FWD & 1
+    {   // timing experiment: no untangle / store phase (one value kept alive)
+        double acc = 0.0;
+#pragma unroll
+        for (int e = 0; e < R; ++e) acc += v[e].x + v[e].y;
+        if (acc == 1.2345e300) Tbuf[0] = TS{};
+        return;
+    }
+#endif
     TS* wbase = Tbuf + (size_t)w * 2 * NXH * nyp;                    // wave-uniform
     constexpr unsigned kEl = sizeof(TS);                             // bytes of a T element
     const unsigned kstride = 2u * (unsigned)nyp * kEl;               // bytes between kx columns
@@ -1025,7 +1053,7 @@ template <int P> constexpr int raster_seg() { return P <= 16 ? P : (P % 16 == 0 
 template <int NX, int K0, int SEG, bool WRAP>
 __device__ __forceinline__ void raster_sums_segment(const double* __restrict__ prep, int plen, int w0, int w1, int psf,
                                                     int n_ps, int n_sersic, int t, int iy, bool row_on,
-                                                    const double* __restrict__ log_tab, double* __restrict__ out,
+                                                    double* __restrict__ log_tab, double* __restrict__ out,
                                                     size_t S, const WrapDesc& wr) {
     constexpr int T = FftShape<NX>::T;
     double a[SEG], b[SEG], cps[SEG];
@@ -1061,7 +1089,7 @@ __device__ __forceinline__ void raster_sums_segment(const double* __restrict__ p
 template <int NX, int K0, bool WRAP>
 __device__ __forceinline__ void raster_sums_all(const double* __restrict__ prep, int plen, int w0, int w1, int psf,
                                                 int n_ps, int n_sersic, int t, int iy, bool row_on,
-                                                const double* __restrict__ log_tab, double* __restrict__ out, size_t S,
+                                                double* __restrict__ log_tab, double* __restrict__ out, size_t S,
                                                 const WrapDesc& wr) {
     constexpr int P = FftShape<NX>::P, SEG = raster_seg<P>();
     if constexpr (K0 < P) {
@@ -1083,14 +1111,14 @@ __global__ void __launch_bounds__(64) k_raster_sums(const double* __restrict__ p
     using S = FftShape<NX>;
     constexpr int T = S::T, RG = S::TPW;
     static_assert(S::P % raster_seg<S::P>() == 0, "segment");
-    __shared__ __align__(16) double log_tab[kLogTabBytes / sizeof(double)];
+    __shared__ __align__(16) double log_tab[kRasterLdsDoubles];
     const int lane = threadIdx.x;
     const int f = lane / T, t = lane % T;
     const int iy = blockIdx.x * RG + f;
     const bool row_on = f < RG && iy < ny;
     const int g = blockIdx.y;
     const int w0 = g * group_size, w1 = w0 + group_size < n_w ? w0 + group_size : n_w;
-    load_log_table(log_tab, lane);
+    load_a_table(log_tab, lane);
     wave_lds_sync();
     const size_t Spx = (size_t)ny * NX;
     const int psf0 = per_field > 0 ? (f0 + w0 / per_field) * npf : 0;      // (wave-uniform)

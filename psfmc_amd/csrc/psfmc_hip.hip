@@ -1324,7 +1324,7 @@ extern "C" double psfmc_get_option(const psfmc_ctx* cc, const char* key) {
 // ---------------------------------------------------------------------------
 static int hipfft_convolve(psfmc_ctx* c, int n, const double* d_prep, const uint8_t* d_skip,
                            hipStream_t st, int ps_only) {
-    const size_t lds = (size_t)c->plen * sizeof(double);
+    const size_t lds = (size_t)prep_rec_len(c->n_ps, c->n_sersic) * sizeof(double);
     RC_TRY(use_plans(c, 2 * n));
     hipLaunchKernelGGL(k_raster, dim3((c->S + 1023) / 1024, n), dim3(256), lds, st, d_prep, d_skip,
                        c->d_real, c->n_ps, c->n_sersic, c->ny, c->nx, ps_only);
@@ -1419,10 +1419,32 @@ static int run_pipeline(psfmc_ctx* c, int W, const uint8_t* d_skip, hipStream_t 
     return PSFMC_OK;
 }
 
+// The power tables of every (walker, Sersic component) of a batch, behind the walkers' prep records
+// (psfmc_device.h: what the fused rasteriser reads instead of a log2 and an exp2 per pixel).  One wave per
+// pair; p = 1 / (2n) is the record's own value, so a table and the record it belongs to always agree.
+__global__ void __launch_bounds__(256) k_pow_tables(double* __restrict__ prep, const uint8_t* __restrict__ skip,
+                                                    int n_pairs, int n_ps, int n_sersic) {
+    const int pair = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (pair >= n_pairs) return;                                   // wave-uniform
+    const int w = pair / n_sersic, k = pair - w * n_sersic;
+    if (skip && skip[w]) return;
+    double* rec = prep + (size_t)w * prep_len(n_ps, n_sersic);
+    const double p = rec[kPrepHead + kPrepPs * n_ps + kPrepSersic * k + 7];
+    build_pow_table(p, rec + prep_rec_len(n_ps, n_sersic) + (size_t)k * kPowTab, lane);
+}
+// walkers [w_off, w_off + n) of c->d_prep; after the kernel that wrote their records, same stream
+static void launch_pow_tables(psfmc_ctx* c, int n, int w_off, const uint8_t* skip, hipStream_t st) {
+    if (c->backend != PSFMC_BACKEND_FUSED || c->n_sersic == 0 || n <= 0) return;
+    const int pairs = n * c->n_sersic;
+    hipLaunchKernelGGL(k_pow_tables, dim3((pairs + 3) / 4), dim3(256), 0, st, c->d_prep + (size_t)w_off * c->plen,
+                       skip, pairs, c->n_ps, c->n_sersic);
+}
+
 static int eval_device(psfmc_ctx* c, int W, const double* d_rows, const uint8_t* d_skip,
                        double* d_like, hipStream_t st) {
     hipLaunchKernelGGL(k_prep, dim3((W + 127) / 128), dim3(128), 0, st, d_rows, c->d_prep, W, c->n_ps,
                        c->n_sersic, c->ly, c->lx, c->d_rho, c->n_psf, 0);
+    launch_pow_tables(c, W, 0, d_skip, st);
     RC_TRY(run_pipeline(c, W, d_skip, st));
     hipLaunchKernelGGL(k_finish, dim3(finish_blocks(W)), dim3(kFinishThreads), 0, st, c->d_partial, d_skip, d_like,
                        W, c->nblk);
@@ -1446,6 +1468,7 @@ static void launch_theta_prep(psfmc_ctx* c, int W, const double* d_theta, const 
                        dim3(kThetaThreads, theta_task_waves(c->n_ps, c->n_sersic)), c->theta_lds, st,
                        L, d_theta, d_extra, d_rows, c->d_prep + (size_t)w_off * c->plen, c->d_lnprior + w_off,
                        c->d_skip + w_off, W, c->ly, c->lx, c->d_rho, sp, field * c->n_psf_field, segs);
+    launch_pow_tables(c, W * n_seg, w_off, c->d_skip + w_off, st);
 }
 
 // raw vectors -> log-posterior, everything on the device
@@ -1520,6 +1543,7 @@ static int eval_images_impl(psfmc_ctx* c, int field, int W, const double* rows, 
     HIP_TRY(hipMemcpyAsync(c->d_rows, rows, (size_t)W * c->rlen * sizeof(double), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_prep, dim3((W + 127) / 128), dim3(128), 0, st, c->d_rows, c->d_prep, W, c->n_ps,
                        c->n_sersic, c->ly, c->lx, c->d_rho, c->n_psf_field, field * c->n_psf_field);
+    launch_pow_tables(c, W, 0, nullptr, st);
     RC_TRY(ensure_image_staging(c));
     double *d_out = nullptr, *d_rawdev = nullptr;     // [chunk] staging for derived images / the raw models (transform shape)
     HIP_TRY(hipMalloc(&d_out, (size_t)c->chunk * img));
@@ -2067,6 +2091,7 @@ extern "C" int psfmc_accumulate_images(psfmc_ctx* c, int W, const double* rows) 
     HIP_TRY(hipMemcpyAsync(c->d_rows, rows, (size_t)W * c->rlen * sizeof(double), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_prep, dim3((W + 127) / 128), dim3(128), 0, st, c->d_rows, c->d_prep, W, c->n_ps,
                        c->n_sersic, c->ly, c->lx, c->d_rho, c->n_psf, 0);
+    launch_pow_tables(c, W, 0, nullptr, st);
     rc = accumulate_from_prep(c, W, st);
     (void)hipStreamSynchronize(st);
     if (rc == PSFMC_OK) HIP_TRY(hipGetLastError());
@@ -2717,6 +2742,22 @@ extern "C" int psfmc_group_eval_theta(psfmc_group* g, int W, const double* theta
 __global__ void k_debug_math(int op, int n, const double* __restrict__ in, double* __restrict__ out) {
     __shared__ __align__(16) double tab[4][kLogTabBytes / sizeof(double)];   // one copy per wave, as in k_rows_fwd
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (op >= 100) {
+        // op = 100: x^p through the rasteriser's power tables, p = in[n]; the tables are built in `out + n`
+        // (kPowTab doubles of scratch behind the n results) by this wave, as k_pow_tables builds them
+        __shared__ __align__(16) double ptab[4][kRasterLdsDoubles];
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const double p = in[n];
+        double* g = out + n + (size_t)(blockIdx.x * 4 + wave) * kPowTab;
+        build_pow_table(p, g, lane);
+        __threadfence_block();
+        wave_lds_sync();
+        load_a_table(ptab[wave], lane);
+        load_pow_table(ptab[wave], g, lane);
+        wave_lds_sync();
+        if (i < n) out[i] = fast_pow_tab(in[i], pow_poly(p), ptab[wave]);
+        return;
+    }
     load_log_table(tab[threadIdx.x >> 6], threadIdx.x & 63);
     wave_lds_sync();
     if (i >= n) return;
@@ -2831,17 +2872,21 @@ extern "C" int psfmc_debug_valu_rate(int device, int waves_per_simd, int iters, 
     return rc;
 }
 
+// op 100: in[n] holds the exponent p of x^p through the rasteriser's power tables (in has n + 1 values)
 extern "C" int psfmc_debug_math(int device, int op, int n, const double* in, double* out) {
-    if (n < 0 || op < 0 || op > 6 || (n > 0 && (!in || !out))) return fail(PSFMC_EINVAL, "bad argument");
+    const bool pw = op == 100;
+    if (n < 0 || op < 0 || (op > 6 && !pw) || (n > 0 && (!in || !out))) return fail(PSFMC_EINVAL, "bad argument");
     if (n == 0) return PSFMC_OK;
     HIP_TRY(hipSetDevice(device));
     double *d_in = nullptr, *d_out = nullptr;
-    HIP_TRY(hipMalloc(&d_in, (size_t)n * sizeof(double)));
+    const int blocks = (n + 255) / 256;
+    const size_t n_in = (size_t)n + (pw ? 1 : 0), n_out = (size_t)n + (pw ? (size_t)blocks * 4 * kPowTab : 0);
+    HIP_TRY(hipMalloc(&d_in, n_in * sizeof(double)));
     int rc = PSFMC_OK;
-    if (hipMalloc(&d_out, (size_t)n * sizeof(double)) != hipSuccess) rc = fail(PSFMC_ENOMEM, "hipMalloc");
+    if (hipMalloc(&d_out, n_out * sizeof(double)) != hipSuccess) rc = fail(PSFMC_ENOMEM, "hipMalloc");
     if (rc == PSFMC_OK) {
-        (void)hipMemcpy(d_in, in, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
-        hipLaunchKernelGGL(k_debug_math, dim3((n + 255) / 256), dim3(256), 0, 0, op, n, d_in, d_out);
+        (void)hipMemcpy(d_in, in, n_in * sizeof(double), hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(k_debug_math, dim3(blocks), dim3(256), 0, 0, op, n, d_in, d_out);
         if (hipMemcpy(out, d_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
             rc = fail(PSFMC_EHIP, "debug_math copy failed: %s", hipGetErrorString(hipGetLastError()));
     }

@@ -26,8 +26,8 @@ k_raster(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
     const int w = blockIdx.y;
     if (skip && skip[w]) return;
     extern __shared__ double s_prep[];
-    const int plen = prep_len(n_ps, n_sersic);
-    for (int i = threadIdx.x; i < plen; i += blockDim.x) s_prep[i] = prep[(size_t)w * plen + i];
+    const int plen = prep_len(n_ps, n_sersic), rec = prep_rec_len(n_ps, n_sersic);   // the power tables stay behind
+    for (int i = threadIdx.x; i < rec; i += blockDim.x) s_prep[i] = prep[(size_t)w * plen + i];
     __syncthreads();
     const int S = ny * nx;
     double* raw = real + (size_t)(2 * w) * S;

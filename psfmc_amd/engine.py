@@ -256,6 +256,19 @@ def debug_math(op, values, device=0):
     return out.reshape(np.shape(values))
 
 
+def debug_pow_tab(values, p, device=0):
+    """values ** p through the rasteriser's power tables (k_pow_tables' builder + `fast_pow_tab`, the
+    function that replaced log2 + exp2 per Sersic pixel): test hook."""
+    lib = load_library()
+    x = _f64(np.ravel(values))
+    buf = np.concatenate([x, [float(p)]])
+    out = np.empty_like(x)
+    rc = lib.psfmc_debug_math(int(device), 100, x.size, _dp(buf), _dp(out))
+    if rc != 0:
+        raise NativeError(rc, lib.psfmc_last_error().decode('utf-8', 'replace'))
+    return out.reshape(np.shape(values))
+
+
 def debug_sweep(mode, nbytes, reps=20, device=0):
     """Average microseconds of a plain memory sweep over `nbytes` of scratch ('write', 'read_write',
     'read'): the traffic of the three kernels of a pass without their arithmetic (measurement hook)."""
