@@ -328,21 +328,29 @@ __device__ __forceinline__ void load_pow_table(double* __restrict__ lds, const d
         lds[2 * kPowTabB + lane + 64 * i] = e[i];
     }
 }
-// 2^(p x) with the product carried in two pieces (hi + lo exactly p x), OCML exp2 (< 1 ulp)
-__device__ inline double pow2_product(double p, double x) {
+// 2^(p x) with the product carried in two pieces (hi + lo exactly p x): 2^hi from OCML's exp2 (< 1 ulp; with
+// the rasteriser's own 2-ulp exp2 the tables' errors -- shared by every pixel of a mantissa cell -- showed in the
+// weight map of a 6e3-count peak, test_general_sides_match_oracle[400x120]) times 1 + lo ln 2.  The same
+// function serves k_pow_tables and the row waves that build their own entries (small batches): same bits.
+// |p x| beyond the double range of 2^y saturates (entries no pixel reads).
+__device__ __forceinline__ double pow2_product(double p, double x) {
     const double hi = p * x;
     const double lo = __builtin_fma(p, x, -hi);
     const double v = exp2(hi);
     const double c = __builtin_fma(v, lo * 0.69314718055994530942, v);
     return (v > 0.0 && v < 1e300 && lo == lo) ? c : v;
 }
+// entry i of the 8 a lane owns (i < 4: PB[lane + 64 i], else PE[lane + 64 (i - 4)])
+__device__ __forceinline__ double pow_tab_entry(double p, int lane, int i) {
+    const int j = lane + 64 * (i & 3);
+    return pow2_product(p, i < 4 ? kLog2Tab[j][1] : (double)(j - kPowTabEBias));
+}
 // the power tables of one (walker, component): all 64 lanes of a wave, 8 entries each
 __device__ inline void build_pow_table(double p, double* __restrict__ g, int lane) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int j = lane + 64 * i;
-        g[j] = pow2_product(p, kLog2Tab[j][1]);
-        g[kPowTabB + j] = pow2_product(p, (double)(j - kPowTabEBias));
+        g[lane + 64 * i] = pow_tab_entry(p, lane, i);
+        g[kPowTabB + lane + 64 * i] = pow_tab_entry(p, lane, 4 + i);
     }
 }
 struct PowPoly { double q1, q2, q3, q4, q5; };
@@ -458,7 +466,8 @@ __device__ __forceinline__ int wrap_coord(int p, int a, int l) {
 template <int P, int T, int K0 = 0, bool WRAP = false, int G = 1>
 __device__ __forceinline__ void raster_row(const double* __restrict__ prep, int n_ps, int n_sersic,
                                            int t, int iy, bool ps_only, double* __restrict__ log_tab,
-                                           double (&r)[P], const WrapDesc& wr = WrapDesc{0, 0, 0, 0, 0, 0}) {
+                                           double (&r)[P], const WrapDesc& wr = WrapDesc{0, 0, 0, 0, 0, 0},
+                                           bool tabs_in_wave = false) {
     const double sky = ps_only ? 0.0 : prep[0];
 #pragma unroll
     for (int k = 0; k < P; ++k) r[k] = sky;
@@ -477,6 +486,17 @@ __device__ __forceinline__ void raster_row(const double* __restrict__ prep, int 
     struct Block { double par, b[4], e[4]; };
     auto issue = [&](int c, Block& B) {
         B.par = sersic0[c * kPrepSersic + (lane_id < kPrepSersic ? lane_id : 0)];
+        if (tabs_in_wave) {
+            // small batches: no k_pow_tables launch, every row wave forms the 8 entries per lane it needs
+            // (the same function, the same bits; ~400 instructions per component)
+            const double pw = sersic0[c * kPrepSersic + 7];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                B.b[i] = pow_tab_entry(pw, lane_id, i);
+                B.e[i] = pow_tab_entry(pw, lane_id, 4 + i);
+            }
+            return;
+        }
         const double* g = pow_tabs + (size_t)c * kPowTab;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {

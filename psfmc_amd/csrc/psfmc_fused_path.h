@@ -262,7 +262,7 @@ __global__ void __launch_bounds__((row_threads<NX, FAST>()), (fused_row_min_wave
 k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
            const cd* __restrict__ twx, TS* __restrict__ Tbuf, int n_ps, int n_sersic, int ny,
            int ps_only, const double* __restrict__ img, const double* __restrict__ img_scale,
-           double* __restrict__ raw_out, WrapDesc wr) {
+           double* __restrict__ raw_out, WrapDesc wr, int tabs_in_wave) {
     using S = FftShape<NX>;
     constexpr int P = S::P, T = S::T, R = S::R, RG = row_group<NX>();
     constexpr int NXH = NX / 2 + 1;
@@ -304,7 +304,8 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
         double* log_tab = smem + (size_t)wave * fused_row_wave_lds_doubles<NX>();
         if (!ps_only && n_sersic > 0) load_a_table(log_tab, lane);       // (raster_row fences before its reads)
         double r[P];
-        raster_row<P, T, 0, WRAP, raster_group<NX>()>(wprep, n_ps, n_sersic, t, iy, ps_only != 0, log_tab, r, wr);
+        raster_row<P, T, 0, WRAP, raster_group<NX>()>(wprep, n_ps, n_sersic, t, iy, ps_only != 0, log_tab, r, wr,
+                                                      tabs_in_wave != 0);
         wave_lds_sync();
 #pragma unroll
         for (int k = 0; k < P; ++k) v[k] = cd{r[k], mu * r[k] * r[k]};

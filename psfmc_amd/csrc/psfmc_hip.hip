@@ -305,6 +305,9 @@ struct psfmc_ctx {
     int n_fields = 1, n_psf_field = 0;       // observed fields of this context (psfmc_ctx_create_fields), PSFs of each
     size_t field_len = 0;                    // packed pixels (FieldPx) of one field
     int max_walkers = 0, chunk = 0, backend = 0;
+    // the records now in d_prep have their power tables behind them (k_pow_tables ran); false: small batch,
+    // the forward row waves form the entries they need themselves (psfmc_device.h raster_row)
+    bool prep_tabs_built = false;
     int single_cap = 0;                               // walkers T buffer 0 holds (>= chunk)
     int rlen = 0, plen = 0;
     int nblk = 0;                 // chi^2 partial sums per walker
@@ -428,7 +431,7 @@ static int launch_rows_fwd_kernel(psfmc_ctx* c, int n, const double* prep, const
     constexpr int waves = row_waves<NX, FAST>();
     hipLaunchKernelGGL((k_rows_fwd<NX, FROM_IMAGE, TS, FAST, WRAP>), dim3((c->nblk + waves - 1) / waves, n),
                        dim3((row_threads<NX, FAST>())), lds, st, prep, skip, c->d_twx, Tbuf, c->n_ps, c->n_sersic,
-                       c->ny, ps_only, img, img_scale, raw_out, c->wrap);
+                       c->ny, ps_only, img, img_scale, raw_out, c->wrap, c->prep_tabs_built ? 0 : 1);
     return PSFMC_OK;
 }
 
@@ -1432,10 +1435,19 @@ __global__ void __launch_bounds__(256) k_pow_tables(double* __restrict__ prep, c
     const double p = rec[kPrepHead + kPrepPs * n_ps + kPrepSersic * k + 7];
     build_pow_table(p, rec + prep_rec_len(n_ps, n_sersic) + (size_t)k * kPowTab, lane);
 }
-// walkers [w_off, w_off + n) of c->d_prep; after the kernel that wrote their records, same stream
-static void launch_pow_tables(psfmc_ctx* c, int n, int w_off, const uint8_t* skip, hipStream_t st) {
+// Batches of up to this many (walker, component) pairs run WITHOUT the launch: their forward row waves form the
+// table entries they read themselves (same function, same bits) -- a kernel boundary plus a one-wave-per-pair
+// kernel are 4 ... 5 us of a default-size ensemble's 45-us half-step, the in-wave form 1 us.
+constexpr int kInWavePowTabPairs = 96;
+// walkers [w_off, w_off + n) of c->d_prep; after the kernel that wrote their records, same stream.
+// `force`: the caller's next kernel reads the tables from memory whatever the batch size (k_raster_sums).
+static void launch_pow_tables(psfmc_ctx* c, int n, int w_off, const uint8_t* skip, hipStream_t st, bool force = false) {
     if (c->backend != PSFMC_BACKEND_FUSED || c->n_sersic == 0 || n <= 0) return;
     const int pairs = n * c->n_sersic;
+    const bool build = force || pairs > kInWavePowTabPairs;
+    // a batch written in several pieces (w_off > 0) reads its tables from memory only if every piece has them
+    c->prep_tabs_built = w_off == 0 ? build : (c->prep_tabs_built && build);
+    if (!build) return;
     hipLaunchKernelGGL(k_pow_tables, dim3((pairs + 3) / 4), dim3(256), 0, st, c->d_prep + (size_t)w_off * c->plen,
                        skip, pairs, c->n_ps, c->n_sersic);
 }
@@ -2040,6 +2052,8 @@ static int accumulate_from_prep(psfmc_ctx* c, int W, hipStream_t st, int f0 = 0,
     const bool fused = c->backend == PSFMC_BACKEND_FUSED;
     if (fused && c->linear_acc) {
         if (!c->d_lin) return fail(PSFMC_EINVAL, "linear sums not allocated");
+        // k_raster_sums reads the power tables from memory: a small batch's were left to its row waves
+        if (!c->prep_tabs_built) launch_pow_tables(c, W, 0, nullptr, st, true);
         return accumulate_linear(c, W, st, f0, nf, per);
     }
     if (c->n_fields > 1) return fail(PSFMC_EINVAL, "contexts of several fields accumulate images as linear sums only");
