@@ -43,6 +43,17 @@ __host__ __device__ inline int row_len(int n_ps, int n_sersic) {
 //   [256, 512)  PE[i] = 2^(p (i - 128)): the exponent e = i - 128 of rho^2 = 2^e m, clamped to [-128, 127]
 constexpr int kPowTabB = 256, kPowTabE = 256, kPowTabEBias = 128;
 constexpr int kPowTab = kPowTabB + kPowTabE;
+// Which form a rasterising kernel uses is a property of its row length (raster_row's TABS, chosen by
+// pow_tabs_side): power tables for transforms with more than 256 pixels per row, log2 + exp2 per pixel (round
+// 2's form, unchanged) up to 256 -- there the step is memory-bound and the tables measured as a loss with one
+// component (256^2: -1.3 % whole step, same box; 128^2 -1.4 %, 64^2 -3 %: 4 KB of tables per row wave through
+// the L2 against 16 instructions per pixel), as a small gain with two (+0.7 ... 2.8 %).  Both forms in one
+// kernel behind a run-time switch cost 84 spilled registers at 256 and half the rate.  Where the tables are used,
+// a batch either has them behind its prep records (kPowTabsBuilt: k_pow_tables ran) or is small and lets every
+// row wave form the entries it reads (kPowTabsInWave; same function, same bits), so a walker's result never
+// depends on what it is batched with.
+__host__ __device__ constexpr bool pow_tabs_side(int nx) { return nx > 256; }
+constexpr int kPowTabsBuilt = 0, kPowTabsInWave = 1;
 __host__ __device__ inline int prep_rec_len(int n_ps, int n_sersic) {
     return kPrepHead + kPrepPs * n_ps + kPrepSersic * n_sersic;
 }
@@ -463,11 +474,12 @@ __device__ __forceinline__ int wrap_coord(int p, int a, int l) {
 // K0: the lane's pixels are x = T (K0 + k) + t, k < P (a segment of a longer row; 0 for whole rows)
 // WRAP: `iy` and x are transform coordinates of an embedded image (see WrapDesc)
 // G: Sersic pixels per lane that go through the profile's stages together (1: pixel after pixel)
-template <int P, int T, int K0 = 0, bool WRAP = false, int G = 1>
+template <int P, int T, int K0 = 0, bool WRAP = false, int G = 1, bool TABS = true>
 __device__ __forceinline__ void raster_row(const double* __restrict__ prep, int n_ps, int n_sersic,
                                            int t, int iy, bool ps_only, double* __restrict__ log_tab,
                                            double (&r)[P], const WrapDesc& wr = WrapDesc{0, 0, 0, 0, 0, 0},
-                                           bool tabs_in_wave = false) {
+                                           int pow_mode = kPowTabsBuilt) {
+    const bool tabs_in_wave = pow_mode == kPowTabsInWave;
     const double sky = ps_only ? 0.0 : prep[0];
 #pragma unroll
     for (int k = 0; k < P; ++k) r[k] = sky;
@@ -504,8 +516,13 @@ __device__ __forceinline__ void raster_row(const double* __restrict__ prep, int 
             B.e[i] = g[kPowTabB + lane_id + 64 * i];
         }
     };
+    // PF (the grouped kernels, G > 1): prefetch as described below.  The kernels that keep the serial pixel
+    // order (the power-of-two shapes; four waves per SIMD hide a load) read each component where they use it,
+    // parameters through scalar loads: the prefetching form measured 2 % slower at 256^2 (same box, whole step)
+    // and equal at 512^2 / 1024^2.
+    constexpr bool PF = TABS && G > 1;
     Block cur{}, nxt{};
-    if (!ps_only && n_sersic > 0) issue(0, cur);                  // in flight during the point sources
+    if (PF && !ps_only && n_sersic > 0) issue(0, cur);            // in flight during the point sources
     for (int c = 0; c < n_ps; ++c, p += kPrepPs) {
         const int ty = iy - (int)p[0];
         const bool row_in = ty >= 0 && ty < (int)p[1];
@@ -545,15 +562,39 @@ __device__ __forceinline__ void raster_row(const double* __restrict__ prep, int 
                                 __builtin_amdgcn_readlane(__double2loint(v), src));
     };
     for (int c = 0; c < n_sersic; ++c) {
-        if (c + 1 < n_sersic) issue(c + 1, nxt);           // in flight during this component's pixels
-        const double x0 = bcast(cur.par, 0), y0 = bcast(cur.par, 1), m00 = bcast(cur.par, 2), m01 = bcast(cur.par, 3),
-                     m10 = bcast(cur.par, 4), m11 = bcast(cur.par, 5);
-        const double kappa = bcast(cur.par, 6), pw = bcast(cur.par, 7), sbeff = bcast(cur.par, 8);
+        double x0, y0, m00, m01, m10, m11, kappa, pw, sbeff;
+        if constexpr (PF) {
+            if (c + 1 < n_sersic) issue(c + 1, nxt);       // in flight during this component's pixels
+            x0 = bcast(cur.par, 0); y0 = bcast(cur.par, 1); m00 = bcast(cur.par, 2); m01 = bcast(cur.par, 3);
+            m10 = bcast(cur.par, 4); m11 = bcast(cur.par, 5);
+            kappa = bcast(cur.par, 6); pw = bcast(cur.par, 7); sbeff = bcast(cur.par, 8);
+        } else {
+            const double* sp = sersic0 + c * kPrepSersic;   // wave-uniform: scalar loads
+            x0 = sp[0]; y0 = sp[1]; m00 = sp[2]; m01 = sp[3]; m10 = sp[4]; m11 = sp[5];
+            kappa = sp[6]; pw = sp[7]; sbeff = sp[8];
+            if constexpr (TABS) issue(c, cur);
+        }
         const double dy = y - y0;
         const double uy = m01 * dy, vy = m11 * dy, dy2 = dy * dy;
         const double nkl = -kappa * kLog2e;                // sb = 2^(nkl (t - 1))
         // g = gk t / sqrt(rho2); the 1/12 of the centroid term rides on gk
         const double gk = -2.0 * kappa * pw * 0.28867513459481288225;   // sqrt(1/12)
+        if constexpr (!TABS) {
+            // (log_tab holds {a_j, b_j}: load_log_table)
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                const double dx = (double)(WRAP ? xm[k] : T * (K0 + k) + t) - x0;   // exact pixel coordinate, one rounding
+                const double u = __builtin_fma(m00, dx, uy);
+                const double v = __builtin_fma(m10, dx, vy);
+                const double rho2 = __builtin_fma(u, u, v * v);
+                const double d2 = __builtin_fma(dx, dx, dy2);
+                const double tt = fast_exp2_noclamp(pw * fast_log2_tab(rho2, log_tab));
+                const double sb = fast_exp2_floor(__builtin_fma(nkl, tt, -nkl));
+                // g^2 q / 12 = (gk t)^2 / rho2 * rho2 / d2: the elliptical radius cancels
+                const double gt = gk * tt;
+                r[k] = __builtin_fma(sbeff * sb, __builtin_fma(gt * gt, fast_rcp1(d2), 1.0), r[k]);
+            }
+        } else {
         const PowPoly q = pow_poly(pw);
         wave_lds_sync();                                   // the previous component's reads are done
 #pragma unroll
@@ -631,7 +672,8 @@ __device__ __forceinline__ void raster_row(const double* __restrict__ prep, int 
                 __builtin_amdgcn_sched_barrier(0);          // two groups in flight, not more (registers)
             }
         }
-        cur = nxt;
+        if constexpr (PF) cur = nxt;
+        }   // TABS
     }
     blank_margin();
 }

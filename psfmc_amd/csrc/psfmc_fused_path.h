@@ -81,7 +81,7 @@ template <int NX> constexpr int row_group() { return FftShape<NX>::TPW; }       
 #define PSFMC_RASTER_GROUP 4
 #endif
 template <int NX> constexpr int raster_group() {
-    return (!FftShape<NX>::kPlain && FftShape<NX>::R > 16 && NX != 252 && NX != 286 && NX != 294) ? PSFMC_RASTER_GROUP : 1;
+    return (pow_tabs_side(NX) && !FftShape<NX>::kPlain && FftShape<NX>::R > 16 && NX != 286 && NX != 294) ? PSFMC_RASTER_GROUP : 1;
 }
 // rows that share a contiguous run of T per kx (the "RG" of the layout comment above): the rows
 // of one wave for the power-of-two shapes, 4 otherwise (ny is rounded up to a multiple of it in
@@ -262,7 +262,7 @@ __global__ void __launch_bounds__((row_threads<NX, FAST>()), (fused_row_min_wave
 k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
            const cd* __restrict__ twx, TS* __restrict__ Tbuf, int n_ps, int n_sersic, int ny,
            int ps_only, const double* __restrict__ img, const double* __restrict__ img_scale,
-           double* __restrict__ raw_out, WrapDesc wr, int tabs_in_wave) {
+           double* __restrict__ raw_out, WrapDesc wr, int pow_mode) {
     using S = FftShape<NX>;
     constexpr int P = S::P, T = S::T, R = S::R, RG = row_group<NX>();
     constexpr int NXH = NX / 2 + 1;
@@ -302,10 +302,17 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
         // twiddle table), which is idle until the transform begins
         static_assert(fused_row_wave_lds_doubles<NX>() >= (size_t)kRasterLdsDoubles, "wave region too small");
         double* log_tab = smem + (size_t)wave * fused_row_wave_lds_doubles<NX>();
-        if (!ps_only && n_sersic > 0) load_a_table(log_tab, lane);       // (raster_row fences before its reads)
+        if (!ps_only && n_sersic > 0) {
+            if constexpr (!pow_tabs_side(NX)) {
+                load_log_table(log_tab, lane);
+                wave_lds_sync();
+            } else {
+                load_a_table(log_tab, lane);                              // (raster_row fences before its reads)
+            }
+        }
         double r[P];
-        raster_row<P, T, 0, WRAP, raster_group<NX>()>(wprep, n_ps, n_sersic, t, iy, ps_only != 0, log_tab, r, wr,
-                                                      tabs_in_wave != 0);
+        raster_row<P, T, 0, WRAP, raster_group<NX>(), pow_tabs_side(NX)>(wprep, n_ps, n_sersic, t, iy, ps_only != 0,
+                                                                         log_tab, r, wr, pow_mode);
         wave_lds_sync();
 #pragma unroll
         for (int k = 0; k < P; ++k) v[k] = cd{r[k], mu * r[k] * r[k]};
@@ -1055,7 +1062,7 @@ template <int NX, int K0, int SEG, bool WRAP>
 __device__ __forceinline__ void raster_sums_segment(const double* __restrict__ prep, int plen, int w0, int w1, int psf,
                                                     int n_ps, int n_sersic, int t, int iy, bool row_on,
                                                     double* __restrict__ log_tab, double* __restrict__ out,
-                                                    size_t S, const WrapDesc& wr) {
+                                                    size_t S, const WrapDesc& wr, int pow_mode) {
     constexpr int T = FftShape<NX>::T;
     double a[SEG], b[SEG], cps[SEG];
 #pragma unroll
@@ -1064,14 +1071,14 @@ __device__ __forceinline__ void raster_sums_segment(const double* __restrict__ p
         const double* wprep = prep + (size_t)w * plen;                   // wave-uniform
         if ((int)wprep[kPrepPsfIdx] != psf) continue;
         double r[SEG];
-        raster_row<SEG, T, K0, WRAP>(wprep, n_ps, n_sersic, t, iy, false, log_tab, r, wr);
+        raster_row<SEG, T, K0, WRAP, 1, pow_tabs_side(NX)>(wprep, n_ps, n_sersic, t, iy, false, log_tab, r, wr, pow_mode);
 #pragma unroll
         for (int k = 0; k < SEG; ++k) {
             a[k] += r[k];
             b[k] = __builtin_fma(r[k], r[k], b[k]);
         }
         if (n_ps) {
-            raster_row<SEG, T, K0, WRAP>(wprep, n_ps, n_sersic, t, iy, true, log_tab, r, wr);
+            raster_row<SEG, T, K0, WRAP, 1, pow_tabs_side(NX)>(wprep, n_ps, n_sersic, t, iy, true, log_tab, r, wr, pow_mode);
 #pragma unroll
             for (int k = 0; k < SEG; ++k) cps[k] += r[k];
         }
@@ -1091,12 +1098,13 @@ template <int NX, int K0, bool WRAP>
 __device__ __forceinline__ void raster_sums_all(const double* __restrict__ prep, int plen, int w0, int w1, int psf,
                                                 int n_ps, int n_sersic, int t, int iy, bool row_on,
                                                 double* __restrict__ log_tab, double* __restrict__ out, size_t S,
-                                                const WrapDesc& wr) {
+                                                const WrapDesc& wr, int pow_mode) {
     constexpr int P = FftShape<NX>::P, SEG = raster_seg<P>();
     if constexpr (K0 < P) {
         raster_sums_segment<NX, K0, SEG, WRAP>(prep, plen, w0, w1, psf, n_ps, n_sersic, t, iy, row_on, log_tab, out, S,
-                                               wr);
-        raster_sums_all<NX, K0 + SEG, WRAP>(prep, plen, w0, w1, psf, n_ps, n_sersic, t, iy, row_on, log_tab, out, S, wr);
+                                               wr, pow_mode);
+        raster_sums_all<NX, K0 + SEG, WRAP>(prep, plen, w0, w1, psf, n_ps, n_sersic, t, iy, row_on, log_tab, out, S, wr,
+                                            pow_mode);
     }
 }
 
@@ -1108,7 +1116,7 @@ template <int NX, bool WRAP = false>
 __global__ void __launch_bounds__(64) k_raster_sums(const double* __restrict__ prep, int plen, int n_w, int group_size,
                                                     int n_ps, int n_sersic, int ny, int n_psf,
                                                     double* __restrict__ part, int per_field, int f0, int npf,
-                                                    WrapDesc wr) {
+                                                    WrapDesc wr, int pow_mode) {
     using S = FftShape<NX>;
     constexpr int T = S::T, RG = S::TPW;
     static_assert(S::P % raster_seg<S::P>() == 0, "segment");
@@ -1119,14 +1127,15 @@ __global__ void __launch_bounds__(64) k_raster_sums(const double* __restrict__ p
     const bool row_on = f < RG && iy < ny;
     const int g = blockIdx.y;
     const int w0 = g * group_size, w1 = w0 + group_size < n_w ? w0 + group_size : n_w;
-    load_a_table(log_tab, lane);
+    if constexpr (!pow_tabs_side(NX)) load_log_table(log_tab, lane);
+    else load_a_table(log_tab, lane);
     wave_lds_sync();
     const size_t Spx = (size_t)ny * NX;
     const int psf0 = per_field > 0 ? (f0 + w0 / per_field) * npf : 0;      // (wave-uniform)
     const int n_here = per_field > 0 ? npf : n_psf;
     for (int p = 0; p < n_here; ++p)
         raster_sums_all<NX, 0, WRAP>(prep, plen, w0, w1, psf0 + p, n_ps, n_sersic, t, row_on ? iy : 0, row_on, log_tab,
-                                     part + ((size_t)g * n_here + p) * 3 * Spx, Spx, wr);
+                                     part + ((size_t)g * n_here + p) * 3 * Spx, Spx, wr, pow_mode);
 }
 
 // lin[i] += part[0][i] + part[1][i] + ... (fixed order)

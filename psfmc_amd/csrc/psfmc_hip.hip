@@ -308,6 +308,9 @@ struct psfmc_ctx {
     // the records now in d_prep have their power tables behind them (k_pow_tables ran); false: small batch,
     // the forward row waves form the entries they need themselves (psfmc_device.h raster_row)
     bool prep_tabs_built = false;
+    // false: this context's rasterising kernels evaluate log2 + exp2 per pixel (row lengths up to 256:
+    // psfmc_device.h pow_tabs_side) and nothing builds tables
+    bool use_pow_tabs = true;
     int single_cap = 0;                               // walkers T buffer 0 holds (>= chunk)
     int rlen = 0, plen = 0;
     int nblk = 0;                 // chi^2 partial sums per walker
@@ -431,7 +434,8 @@ static int launch_rows_fwd_kernel(psfmc_ctx* c, int n, const double* prep, const
     constexpr int waves = row_waves<NX, FAST>();
     hipLaunchKernelGGL((k_rows_fwd<NX, FROM_IMAGE, TS, FAST, WRAP>), dim3((c->nblk + waves - 1) / waves, n),
                        dim3((row_threads<NX, FAST>())), lds, st, prep, skip, c->d_twx, Tbuf, c->n_ps, c->n_sersic,
-                       c->ny, ps_only, img, img_scale, raw_out, c->wrap, c->prep_tabs_built ? 0 : 1);
+                       c->ny, ps_only, img, img_scale, raw_out, c->wrap,
+                       c->prep_tabs_built ? kPowTabsBuilt : kPowTabsInWave);
     return PSFMC_OK;
 }
 
@@ -591,12 +595,12 @@ static int launch_raster_sums(psfmc_ctx* c, int n, const double* prep, int group
     if (c->embed) {
         hipLaunchKernelGGL((k_raster_sums<NX, true>), dim3((c->ny + RG - 1) / RG, groups), dim3(64), 0, st, prep,
                            c->plen, n, group_size, c->n_ps, c->n_sersic, c->ny, c->n_psf, c->d_linpart, per_field,
-                           f0, c->n_psf_field, c->wrap);
+                           f0, c->n_psf_field, c->wrap, kPowTabsBuilt);
         return PSFMC_OK;
     }
     hipLaunchKernelGGL((k_raster_sums<NX, false>), dim3((c->ny + RG - 1) / RG, groups), dim3(64), 0, st, prep, c->plen, n,
                        group_size, c->n_ps, c->n_sersic, c->ny, c->n_psf, c->d_linpart, per_field, f0,
-                       c->n_psf_field, c->wrap);
+                       c->n_psf_field, c->wrap, kPowTabsBuilt);
     return PSFMC_OK;
 }
 
@@ -1117,6 +1121,8 @@ static int ctx_create_impl(psfmc_ctx** out, int device, int ny, int nx, int n_fi
     c->max_walkers = max_walkers; c->backend = backend;
     c->rlen = row_len(n_ps, n_sersic);
     c->plen = prep_len(n_ps, n_sersic);
+    // the rasteriser's form of (rho^2)^p for this context's kernels (psfmc_device.h pow_tabs_side)
+    c->use_pow_tabs = pow_tabs_side(nx);
     c->nyp = ny;
     if (backend == PSFMC_BACKEND_FUSED) {
         c->nblk = row_tiles;
@@ -1306,6 +1312,7 @@ extern "C" double psfmc_get_option(const psfmc_ctx* cc, const char* key) {
     }
     if (!strcmp(key, "row_group")) return 1 << c->rg_log2;
     if (!strcmp(key, "speculate")) return c->speculate;
+    if (!strcmp(key, "pow_tabs")) return c->use_pow_tabs ? 1.0 : 0.0;
     if (!strcmp(key, "speculated_runs")) return (double)c->speculated_runs;
     if (!strcmp(key, "transform_ny")) return c->ny;        // the transform shape (the image's own, or the one it is embedded in)
     if (!strcmp(key, "transform_nx")) return c->nx;
@@ -1442,7 +1449,7 @@ constexpr int kInWavePowTabPairs = 96;
 // walkers [w_off, w_off + n) of c->d_prep; after the kernel that wrote their records, same stream.
 // `force`: the caller's next kernel reads the tables from memory whatever the batch size (k_raster_sums).
 static void launch_pow_tables(psfmc_ctx* c, int n, int w_off, const uint8_t* skip, hipStream_t st, bool force = false) {
-    if (c->backend != PSFMC_BACKEND_FUSED || c->n_sersic == 0 || n <= 0) return;
+    if (c->backend != PSFMC_BACKEND_FUSED || c->n_sersic == 0 || n <= 0 || !c->use_pow_tabs) return;
     const int pairs = n * c->n_sersic;
     const bool build = force || pairs > kInWavePowTabPairs;
     // a batch written in several pieces (w_off > 0) reads its tables from memory only if every piece has them
@@ -2053,7 +2060,7 @@ static int accumulate_from_prep(psfmc_ctx* c, int W, hipStream_t st, int f0 = 0,
     if (fused && c->linear_acc) {
         if (!c->d_lin) return fail(PSFMC_EINVAL, "linear sums not allocated");
         // k_raster_sums reads the power tables from memory: a small batch's were left to its row waves
-        if (!c->prep_tabs_built) launch_pow_tables(c, W, 0, nullptr, st, true);
+        if (c->use_pow_tabs && !c->prep_tabs_built) launch_pow_tables(c, W, 0, nullptr, st, true);
         return accumulate_linear(c, W, st, f0, nf, per);
     }
     if (c->n_fields > 1) return fail(PSFMC_EINVAL, "contexts of several fields accumulate images as linear sums only");

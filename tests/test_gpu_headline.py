@@ -267,3 +267,30 @@ def test_single_precision_storage_is_refused_for_general_sides():
     with pytest.raises(engine.NativeError):
         model.engine.set_option('storage_f32', 1)
     model.close()
+
+
+@pytest.mark.gpu
+def test_rasteriser_forms_by_row_length():
+    """The fused rasteriser has two forms of (rho^2)^p per Sersic pixel (psfmc_device.h pow_tabs_side): per-walker
+    power tables for transforms of more than 256 pixels per row, log2 + exp2 per pixel up to 256 (there the
+    tables' L2 traffic costs more than their instructions save).  Both forms are held against the oracle by
+    tests/test_gpu_random.py (106 shapes on either side of 256) and tests/test_gpu_fullsize.py; here: the rule
+    as the context reports it, and that the table form does not depend on the batch -- small batches form the
+    table entries in the row waves, large ones read k_pow_tables' output, subsets and permutations of a batch
+    return the same bits."""
+    import synth_field
+    from test_gpu_fullsize import make_model
+    for side, want in ((128, 0.0), (256, 0.0), (264, 1.0), (512, 1.0)):
+        m, fld = make_model(side, 2, 'fused', max_walkers=256)
+        assert m.engine.get_option('pow_tabs') == want, side
+        if side in (264, 512):
+            theta = np.vstack([fld['truth'][None, :],
+                               synth_field.draw_walkers(side, 2, 199, seed=3, near_truth=fld['truth'])])
+            got = m.log_posterior_batch(theta)                       # 400 (walker, component) pairs: k_pow_tables
+            assert np.isfinite(got).sum() > 100
+            assert np.array_equal(m.log_posterior_batch(theta[5:9]), got[5:9])        # 8 pairs: in the row waves
+            assert np.array_equal(m.log_posterior_batch(theta[40:88]), got[40:88])    # 96 pairs: the last in-wave size
+            assert np.array_equal(m.log_posterior_batch(theta[40:89]), got[40:89])    # 98 pairs: the first with tables
+            perm = np.random.RandomState(2).permutation(len(got))
+            assert np.array_equal(m.log_posterior_batch(theta[perm]), got[perm])
+        m.close()
