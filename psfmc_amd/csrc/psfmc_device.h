@@ -474,7 +474,7 @@ __device__ __forceinline__ int wrap_coord(int p, int a, int l) {
 // K0: the lane's pixels are x = T (K0 + k) + t, k < P (a segment of a longer row; 0 for whole rows)
 // WRAP: `iy` and x are transform coordinates of an embedded image (see WrapDesc)
 // G: Sersic pixels per lane that go through the profile's stages together (1: pixel after pixel)
-template <int P, int T, int K0 = 0, bool WRAP = false, int G = 1, bool TABS = true>
+template <int P, int T, int K0 = 0, bool WRAP = false, int G = 1>
 __device__ __forceinline__ void raster_row(const double* __restrict__ prep, int n_ps, int n_sersic,
                                            int t, int iy, bool ps_only, double* __restrict__ log_tab,
                                            double (&r)[P], const WrapDesc& wr = WrapDesc{0, 0, 0, 0, 0, 0},
@@ -520,7 +520,7 @@ __device__ __forceinline__ void raster_row(const double* __restrict__ prep, int 
     // order (the power-of-two shapes; four waves per SIMD hide a load) read each component where they use it,
     // parameters through scalar loads: the prefetching form measured 2 % slower at 256^2 (same box, whole step)
     // and equal at 512^2 / 1024^2.
-    constexpr bool PF = TABS && G > 1;
+    constexpr bool PF = G > 1;
     Block cur{}, nxt{};
     if (PF && !ps_only && n_sersic > 0) issue(0, cur);            // in flight during the point sources
     for (int c = 0; c < n_ps; ++c, p += kPrepPs) {
@@ -572,29 +572,13 @@ __device__ __forceinline__ void raster_row(const double* __restrict__ prep, int 
             const double* sp = sersic0 + c * kPrepSersic;   // wave-uniform: scalar loads
             x0 = sp[0]; y0 = sp[1]; m00 = sp[2]; m01 = sp[3]; m10 = sp[4]; m11 = sp[5];
             kappa = sp[6]; pw = sp[7]; sbeff = sp[8];
-            if constexpr (TABS) issue(c, cur);
+            issue(c, cur);
         }
         const double dy = y - y0;
         const double uy = m01 * dy, vy = m11 * dy, dy2 = dy * dy;
         const double nkl = -kappa * kLog2e;                // sb = 2^(nkl (t - 1))
         // g = gk t / sqrt(rho2); the 1/12 of the centroid term rides on gk
         const double gk = -2.0 * kappa * pw * 0.28867513459481288225;   // sqrt(1/12)
-        if constexpr (!TABS) {
-            // (log_tab holds {a_j, b_j}: load_log_table)
-#pragma unroll
-            for (int k = 0; k < P; ++k) {
-                const double dx = (double)(WRAP ? xm[k] : T * (K0 + k) + t) - x0;   // exact pixel coordinate, one rounding
-                const double u = __builtin_fma(m00, dx, uy);
-                const double v = __builtin_fma(m10, dx, vy);
-                const double rho2 = __builtin_fma(u, u, v * v);
-                const double d2 = __builtin_fma(dx, dx, dy2);
-                const double tt = fast_exp2_noclamp(pw * fast_log2_tab(rho2, log_tab));
-                const double sb = fast_exp2_floor(__builtin_fma(nkl, tt, -nkl));
-                // g^2 q / 12 = (gk t)^2 / rho2 * rho2 / d2: the elliptical radius cancels
-                const double gt = gk * tt;
-                r[k] = __builtin_fma(sbeff * sb, __builtin_fma(gt * gt, fast_rcp1(d2), 1.0), r[k]);
-            }
-        } else {
         const PowPoly q = pow_poly(pw);
         wave_lds_sync();                                   // the previous component's reads are done
 #pragma unroll
@@ -673,7 +657,79 @@ __device__ __forceinline__ void raster_row(const double* __restrict__ prep, int 
             }
         }
         if constexpr (PF) cur = nxt;
-        }   // TABS
+    }
+    blank_margin();
+}
+
+// Round 2's form, unchanged (rows of up to 256 pixels: pow_tabs_side): log2 + exp2 per Sersic pixel, the log2
+// through the {a_j, b_j} table in LDS (load_log_table).
+// K0: the lane's pixels are x = T (K0 + k) + t, k < P (a segment of a longer row; 0 for whole rows)
+// WRAP: `iy` and x are transform coordinates of an embedded image (see WrapDesc)
+template <int P, int T, int K0 = 0, bool WRAP = false>
+__device__ __forceinline__ void raster_row_logexp(const double* __restrict__ prep, int n_ps, int n_sersic,
+                                           int t, int iy, bool ps_only, const double* __restrict__ log_tab,
+                                           double (&r)[P], const WrapDesc& wr = WrapDesc{0, 0, 0, 0, 0, 0}) {
+    const double sky = ps_only ? 0.0 : prep[0];
+#pragma unroll
+    for (int k = 0; k < P; ++k) r[k] = sky;
+    int xm[WRAP ? P : 1];              // model column of pixel k
+    bool live_row = true;
+    if constexpr (WRAP) {
+        live_row = iy < wr.ey;
+        iy = wrap_coord(iy, wr.ay, wr.ly);
+#pragma unroll
+        for (int k = 0; k < P; ++k) xm[k] = wrap_coord(T * (K0 + k) + t, wr.ax, wr.lx);
+    }
+    const double* p = prep + kPrepHead;
+    for (int c = 0; c < n_ps; ++c, p += kPrepPs) {
+        const int ty = iy - (int)p[0];
+        const bool row_in = ty >= 0 && ty < (int)p[1];
+        if (__any(row_in)) {
+            const double wy = row_in ? p[4 + (row_in ? ty : 0)] : 0.0;
+            const int xlo = (int)p[2], xn = (int)p[3];
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                const int tx = (WRAP ? xm[k] : T * (K0 + k) + t) - xlo;
+                const bool in = (unsigned)tx < (unsigned)xn;
+                const double wx = p[4 + kTaps + (in ? tx : 0)];
+                r[k] += in ? wy * wx : 0.0;
+            }
+        }
+    }
+    // beyond the wrap-around margin of an embedded image the transform pixels are zero
+    auto blank_margin = [&]() {
+        if constexpr (WRAP) {
+#pragma unroll
+            for (int k = 0; k < P; ++k) r[k] = (live_row && T * (K0 + k) + t < wr.ex) ? r[k] : 0.0;
+        }
+    };
+    if (ps_only) {
+        blank_margin();
+        return;
+    }
+    constexpr double kLog2e = 1.44269504088896340736;
+    const double y = (double)iy;
+    for (int c = 0; c < n_sersic; ++c, p += kPrepSersic) {
+        const double x0 = p[0], y0 = p[1], m00 = p[2], m01 = p[3], m10 = p[4], m11 = p[5];
+        const double kappa = p[6], pw = p[7], sbeff = p[8];
+        const double dy = y - y0;
+        const double uy = m01 * dy, vy = m11 * dy, dy2 = dy * dy;
+        const double nkl = -kappa * kLog2e;                // sb = 2^(nkl (t - 1))
+        // g = gk t / sqrt(rho2); the 1/12 of the centroid term rides on gk
+        const double gk = -2.0 * kappa * pw * 0.28867513459481288225;   // sqrt(1/12)
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            const double dx = (double)(WRAP ? xm[k] : T * (K0 + k) + t) - x0;   // exact pixel coordinate, one rounding
+            const double u = __builtin_fma(m00, dx, uy);
+            const double v = __builtin_fma(m10, dx, vy);
+            const double rho2 = __builtin_fma(u, u, v * v);
+            const double d2 = __builtin_fma(dx, dx, dy2);
+            const double tt = fast_exp2_noclamp(pw * fast_log2_tab(rho2, log_tab));
+            const double sb = fast_exp2_floor(__builtin_fma(nkl, tt, -nkl));
+            // g^2 q / 12 = (gk t)^2 / rho2 * rho2 / d2: the elliptical radius cancels
+            const double gt = gk * tt;
+            r[k] = __builtin_fma(sbeff * sb, __builtin_fma(gt * gt, fast_rcp1(d2), 1.0), r[k]);
+        }
     }
     blank_margin();
 }

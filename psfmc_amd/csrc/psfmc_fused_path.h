@@ -76,12 +76,12 @@ template <int NX> constexpr int row_group() { return FftShape<NX>::TPW; }       
 // registers per lane and run at two waves per SIMD whatever the rasteriser needs (k_rows_fwd<300> 58.9 -> 52.5 us,
 // <600> 54.3 -> 48.2, <768> 70 -> 63: whole step +2 ... +5 %); 1 for the power-of-two shapes (512 / 1024: 43.5 vs
 // 47.1 us and 66.7 vs 68.9 us -- the grouped form spills there -- and the small ones live on four waves per SIMD)
-// and for three sides that the grouped form takes from three waves per SIMD to two (252, 286, 294: +5 % kernel time)
+// and for three sides that the grouped form takes from three waves per SIMD to two (264, 286, 294: +5 % kernel time)
 #ifndef PSFMC_RASTER_GROUP
 #define PSFMC_RASTER_GROUP 4
 #endif
 template <int NX> constexpr int raster_group() {
-    return (pow_tabs_side(NX) && !FftShape<NX>::kPlain && FftShape<NX>::R > 16 && NX != 286 && NX != 294) ? PSFMC_RASTER_GROUP : 1;
+    return (pow_tabs_side(NX) && !FftShape<NX>::kPlain && FftShape<NX>::R > 16 && NX != 264 && NX != 286 && NX != 294) ? PSFMC_RASTER_GROUP : 1;
 }
 // rows that share a contiguous run of T per kx (the "RG" of the layout comment above): the rows
 // of one wave for the power-of-two shapes, 4 otherwise (ny is rounded up to a multiple of it in
@@ -111,7 +111,8 @@ template <int NX, bool FAST = FftShape<NX>::kPlain> constexpr int row_threads() 
 // (at least the rasteriser's tables, which borrow the region before the transform starts: psfmc_device.h)
 template <int NX> constexpr size_t fused_row_wave_lds_doubles() {
     constexpr size_t fft = (size_t)row_group<NX>() * fft_lds_elems<NX>() + 2 * (size_t)fft_tw_lds_elems<NX>();
-    return fft > (size_t)kRasterLdsDoubles ? fft : (size_t)kRasterLdsDoubles;
+    constexpr size_t ras = pow_tabs_side(NX) ? (size_t)kRasterLdsDoubles : (size_t)kLogTabBytes / sizeof(double);
+    return fft > ras ? fft : ras;
 }
 template <int NX, bool FAST = FftShape<NX>::kPlain> constexpr size_t fused_row_lds_bytes() {
     return (size_t)row_waves<NX, FAST>() * fused_row_wave_lds_doubles<NX>() * sizeof(double);
@@ -176,6 +177,9 @@ template <int N, bool INVERSE, bool WRAP = false> constexpr int fused_row_min_wa
     // (the rasteriser's grouped pixel stages let the allocator of the 512 / 1024 forward kernels drift past 256
     // registers where it used to stop at 185 ... 220 by itself)
     if (FftShape<N>::kPlain && !INVERSE && N >= 512) return 2;
+    // ... and so did the general sides from 640 on (one accumulation register over 256 = one wave per SIMD); the
+    // four whose forward kernel runs at one wave by measurement (fused_row_min_waves' history above) stay there
+    if (!INVERSE && pow_tabs_side(N) && N >= 640 && N != 728 && N != 784 && N != 840 && N != 900) return 2;
     if (FftShape<N>::kPlain) return fused_min_waves<N>();
     if ((INVERSE ? row_inv_more_waves(N) : row_fwd_more_waves(N)) > 0) return INVERSE ? row_inv_more_waves(N) : row_fwd_more_waves(N);
     return (FftShape<N>::R > PSFMC_GEN_ROW_R_2WAVES && !row_two_waves_side(N)) ? 1 : 2;
@@ -300,19 +304,26 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
         if (skipped) return;                          // a skipped walker's record may hold anything
         // the rasteriser's tables borrow the start of the wave's transform region (exchange area and
         // twiddle table), which is idle until the transform begins
-        static_assert(fused_row_wave_lds_doubles<NX>() >= (size_t)kRasterLdsDoubles, "wave region too small");
+        static_assert(fused_row_wave_lds_doubles<NX>() >= (pow_tabs_side(NX) ? (size_t)kRasterLdsDoubles : (size_t)kLogTabBytes / 8),
+                      "wave region too small");
         double* log_tab = smem + (size_t)wave * fused_row_wave_lds_doubles<NX>();
-        if (!ps_only && n_sersic > 0) {
-            if constexpr (!pow_tabs_side(NX)) {
+        if constexpr (!pow_tabs_side(NX)) {
+            if (!ps_only) {
                 load_log_table(log_tab, lane);
                 wave_lds_sync();
-            } else {
-                load_a_table(log_tab, lane);                              // (raster_row fences before its reads)
             }
+        } else {
+            if (!ps_only && n_sersic > 0) load_a_table(log_tab, lane);   // (raster_row fences before its reads)
         }
         double r[P];
-        raster_row<P, T, 0, WRAP, raster_group<NX>(), pow_tabs_side(NX)>(wprep, n_ps, n_sersic, t, iy, ps_only != 0,
-                                                                         log_tab, r, wr, pow_mode);
+        if constexpr (!pow_tabs_side(NX)) {
+            raster_row_logexp<P, T, 0, WRAP>(wprep, n_ps, n_sersic, t, iy, ps_only != 0, log_tab, r, wr);
+        } else {
+            // (the WRAP variants keep the serial pixel order: with their P wrapped coordinates on top, the grouped
+            // form spilled or lost a wave -- embedded 586^2 -17 %, 698^2 -21 % whole step)
+            raster_row<P, T, 0, WRAP, WRAP ? 1 : raster_group<NX>()>(wprep, n_ps, n_sersic, t, iy, ps_only != 0, log_tab, r,
+                                                                    wr, pow_mode);
+        }
         wave_lds_sync();
 #pragma unroll
         for (int k = 0; k < P; ++k) v[k] = cd{r[k], mu * r[k] * r[k]};
@@ -1071,14 +1082,16 @@ __device__ __forceinline__ void raster_sums_segment(const double* __restrict__ p
         const double* wprep = prep + (size_t)w * plen;                   // wave-uniform
         if ((int)wprep[kPrepPsfIdx] != psf) continue;
         double r[SEG];
-        raster_row<SEG, T, K0, WRAP, 1, pow_tabs_side(NX)>(wprep, n_ps, n_sersic, t, iy, false, log_tab, r, wr, pow_mode);
+        if constexpr (!pow_tabs_side(NX)) raster_row_logexp<SEG, T, K0, WRAP>(wprep, n_ps, n_sersic, t, iy, false, log_tab, r, wr);
+        else raster_row<SEG, T, K0, WRAP, 1>(wprep, n_ps, n_sersic, t, iy, false, log_tab, r, wr, pow_mode);
 #pragma unroll
         for (int k = 0; k < SEG; ++k) {
             a[k] += r[k];
             b[k] = __builtin_fma(r[k], r[k], b[k]);
         }
         if (n_ps) {
-            raster_row<SEG, T, K0, WRAP, 1, pow_tabs_side(NX)>(wprep, n_ps, n_sersic, t, iy, true, log_tab, r, wr, pow_mode);
+            if constexpr (!pow_tabs_side(NX)) raster_row_logexp<SEG, T, K0, WRAP>(wprep, n_ps, n_sersic, t, iy, true, log_tab, r, wr);
+            else raster_row<SEG, T, K0, WRAP, 1>(wprep, n_ps, n_sersic, t, iy, true, log_tab, r, wr, pow_mode);
 #pragma unroll
             for (int k = 0; k < SEG; ++k) cps[k] += r[k];
         }
