@@ -334,7 +334,9 @@ int psfmc_get_spectra(psfmc_ctx* ctx, double* psf_spec, double* var_spec);
  * iteration -- the first half's proposals and both candidate proposals of every second-half walker (partner
  * moved / partner stayed) -- instead of two half-steps; the chain is the same bit for bit.  0 never, n > 0 that
  * bound, -1 (default) n = 3e6 / transform pixels, the measured break-even; needs max_walkers >= 1.5 W.
- * get_option only: "transform_ny" / "transform_nx" (the transform shape: the image's own, or the built sides an
+ * get_option only: "pow_tabs" (1: this context's rasterising kernels take (rho^2)^p from per-walker power tables --
+ * transforms of more than 256 pixels per row --, 0: log2 + exp2 per pixel; a property of the transform shape),
+ * "transform_ny" / "transform_nx" (the transform shape: the image's own, or the built sides an
  * image of unbuilt sides is embedded in), "speculated_runs", "graph_launches", "row_group",
  * "partials_per_walker". */
 int psfmc_set_option(psfmc_ctx* ctx, const char* key, double value);
@@ -343,7 +345,8 @@ double psfmc_get_option(const psfmc_ctx* ctx, const char* key);
 /*
  * Diagnostic hook: evaluate one of the library's fp64 device functions on n host
  * values (op 0 log2, 1 exp2, 2 reciprocal, 3 single-Newton reciprocal, 4 exp2 without
- * clamp, 5 the rasteriser's table-driven log2, 6 exp2 with the lower clamp only) so tests can
+ * clamp, 5 the rasteriser's table-driven log2, 6 exp2 with the lower clamp only; op 100: x^p through the
+ * rasteriser's per-walker power tables, with p passed as in[n], i.e. `in` holds n + 1 values) so tests can
  * check the hand-written elementary functions of the rasteriser against numpy.
  */
 int psfmc_debug_math(int device, int op, int n, const double* in, double* out);

@@ -516,10 +516,6 @@ __device__ __forceinline__ void raster_row(const double* __restrict__ prep, int 
             B.e[i] = g[kPowTabB + lane_id + 64 * i];
         }
     };
-    // PF (the grouped kernels, G > 1): prefetch as described below.  The kernels that keep the serial pixel
-    // order (the power-of-two shapes; four waves per SIMD hide a load) read each component where they use it,
-    // parameters through scalar loads: the prefetching form measured 2 % slower at 256^2 (same box, whole step)
-    // and equal at 512^2 / 1024^2.
     constexpr bool PF = G > 1;
     Block cur{}, nxt{};
     if (PF && !ps_only && n_sersic > 0) issue(0, cur);            // in flight during the point sources
@@ -551,12 +547,13 @@ __device__ __forceinline__ void raster_row(const double* __restrict__ prep, int 
     }
     constexpr double kLog2e = 1.44269504088896340736;
     const double y = (double)iy;
-    // A component's parameters and power tables are PREFETCHED through vector loads while the previous
+    // PF: a component's parameters and power tables are PREFETCHED through vector loads while the previous
     // component's pixels are evaluated (lane i < 9 brings parameter i, every lane eight table entries), and
-    // the parameters are then broadcast into scalar registers with v_readlane.  Read as scalar loads at the head
-    // of each component (round 2), every wave stood still for the round trip of the s_load, then again for the
-    // table's: 40 % of a wave's lifetime in k_rows_fwd<1024> with four components was s_waitcnt
-    // (SQ_WAIT_INST_ANY), and two waves per SIMD do not hide that for each other.
+    // the parameters are then broadcast into scalar registers with v_readlane (scalar loads share lgkmcnt with
+    // the LDS reads of the pixel loop and cannot be waited for separately).  Measured (same box, 2 ... 3
+    // components): with the grouped pixel stages k_rows_fwd<300> 58.9 -> 52.5 us, <600> 54.3 -> 48.2, <768> 70 ->
+    // 63; on the power-of-two kernels nothing (512 / 1024) or a loss (256: -2 % whole step), so they read each
+    // component where they use it.
     auto bcast = [](double v, int src) {
         return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src),
                                 __builtin_amdgcn_readlane(__double2loint(v), src));
