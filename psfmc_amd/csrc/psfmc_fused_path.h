@@ -80,7 +80,11 @@ template <int NX> constexpr int row_group() { return FftShape<NX>::TPW; }       
 #ifndef PSFMC_RASTER_GROUP
 #define PSFMC_RASTER_GROUP 4
 #endif
+#ifndef PSFMC_RASTER_GROUP_PLAIN
+#define PSFMC_RASTER_GROUP_PLAIN 1    /* the 512 / 1024 kernels; 2 (236 registers, no spills) measured +1.0 % / 0 % whole step: not taken */
+#endif
 template <int NX> constexpr int raster_group() {
+    if (FftShape<NX>::kPlain && NX >= 512) return PSFMC_RASTER_GROUP_PLAIN;
     return (pow_tabs_side(NX) && !FftShape<NX>::kPlain && FftShape<NX>::R > 16 && NX != 264 && NX != 286 && NX != 294) ? PSFMC_RASTER_GROUP : 1;
 }
 // rows that share a contiguous run of T per kx (the "RG" of the layout comment above): the rows
