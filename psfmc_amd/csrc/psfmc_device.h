@@ -51,7 +51,8 @@ constexpr int kPowTab = kPowTabB + kPowTabE;
 // kernel behind a run-time switch cost 84 spilled registers at 256 and half the rate.  Where the tables are used,
 // a batch either has them behind its prep records (kPowTabsBuilt: k_pow_tables ran) or is small and lets every
 // row wave form the entries it reads (kPowTabsInWave; same function, same bits), so a walker's result never
-// depends on what it is batched with.
+// depends on what it is batched with.  The forward row kernels only: k_raster_sums (posterior-image sums, 7 ... 16
+// pixels per lane and call) keeps the log2 + exp2 form at every size.
 __host__ __device__ constexpr bool pow_tabs_side(int nx) { return nx > 256; }
 constexpr int kPowTabsBuilt = 0, kPowTabsInWave = 1;
 __host__ __device__ inline int prep_rec_len(int n_ps, int n_sersic) {

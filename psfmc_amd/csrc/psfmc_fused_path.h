@@ -1077,7 +1077,7 @@ template <int NX, int K0, int SEG, bool WRAP>
 __device__ __forceinline__ void raster_sums_segment(const double* __restrict__ prep, int plen, int w0, int w1, int psf,
                                                     int n_ps, int n_sersic, int t, int iy, bool row_on,
                                                     double* __restrict__ log_tab, double* __restrict__ out,
-                                                    size_t S, const WrapDesc& wr, int pow_mode) {
+                                                    size_t S, const WrapDesc& wr) {
     constexpr int T = FftShape<NX>::T;
     double a[SEG], b[SEG], cps[SEG];
 #pragma unroll
@@ -1086,16 +1086,16 @@ __device__ __forceinline__ void raster_sums_segment(const double* __restrict__ p
         const double* wprep = prep + (size_t)w * plen;                   // wave-uniform
         if ((int)wprep[kPrepPsfIdx] != psf) continue;
         double r[SEG];
-        if constexpr (!pow_tabs_side(NX)) raster_row_logexp<SEG, T, K0, WRAP>(wprep, n_ps, n_sersic, t, iy, false, log_tab, r, wr);
-        else raster_row<SEG, T, K0, WRAP, 1>(wprep, n_ps, n_sersic, t, iy, false, log_tab, r, wr, pow_mode);
+        // (log2 + exp2 form at every size: a segment is 7 ... 16 pixels per lane, and the power tables would be
+        // fetched again for each -- 512^2, 256 walkers: 0.59 ms per iteration of image sums with them, 0.46 without)
+        raster_row_logexp<SEG, T, K0, WRAP>(wprep, n_ps, n_sersic, t, iy, false, log_tab, r, wr);
 #pragma unroll
         for (int k = 0; k < SEG; ++k) {
             a[k] += r[k];
             b[k] = __builtin_fma(r[k], r[k], b[k]);
         }
         if (n_ps) {
-            if constexpr (!pow_tabs_side(NX)) raster_row_logexp<SEG, T, K0, WRAP>(wprep, n_ps, n_sersic, t, iy, true, log_tab, r, wr);
-            else raster_row<SEG, T, K0, WRAP, 1>(wprep, n_ps, n_sersic, t, iy, true, log_tab, r, wr, pow_mode);
+            raster_row_logexp<SEG, T, K0, WRAP>(wprep, n_ps, n_sersic, t, iy, true, log_tab, r, wr);
 #pragma unroll
             for (int k = 0; k < SEG; ++k) cps[k] += r[k];
         }
@@ -1115,13 +1115,12 @@ template <int NX, int K0, bool WRAP>
 __device__ __forceinline__ void raster_sums_all(const double* __restrict__ prep, int plen, int w0, int w1, int psf,
                                                 int n_ps, int n_sersic, int t, int iy, bool row_on,
                                                 double* __restrict__ log_tab, double* __restrict__ out, size_t S,
-                                                const WrapDesc& wr, int pow_mode) {
+                                                const WrapDesc& wr) {
     constexpr int P = FftShape<NX>::P, SEG = raster_seg<P>();
     if constexpr (K0 < P) {
         raster_sums_segment<NX, K0, SEG, WRAP>(prep, plen, w0, w1, psf, n_ps, n_sersic, t, iy, row_on, log_tab, out, S,
-                                               wr, pow_mode);
-        raster_sums_all<NX, K0 + SEG, WRAP>(prep, plen, w0, w1, psf, n_ps, n_sersic, t, iy, row_on, log_tab, out, S, wr,
-                                            pow_mode);
+                                               wr);
+        raster_sums_all<NX, K0 + SEG, WRAP>(prep, plen, w0, w1, psf, n_ps, n_sersic, t, iy, row_on, log_tab, out, S, wr);
     }
 }
 
@@ -1133,26 +1132,25 @@ template <int NX, bool WRAP = false>
 __global__ void __launch_bounds__(64) k_raster_sums(const double* __restrict__ prep, int plen, int n_w, int group_size,
                                                     int n_ps, int n_sersic, int ny, int n_psf,
                                                     double* __restrict__ part, int per_field, int f0, int npf,
-                                                    WrapDesc wr, int pow_mode) {
+                                                    WrapDesc wr) {
     using S = FftShape<NX>;
     constexpr int T = S::T, RG = S::TPW;
     static_assert(S::P % raster_seg<S::P>() == 0, "segment");
-    __shared__ __align__(16) double log_tab[kRasterLdsDoubles];
+    __shared__ __align__(16) double log_tab[kLogTabBytes / sizeof(double)];
     const int lane = threadIdx.x;
     const int f = lane / T, t = lane % T;
     const int iy = blockIdx.x * RG + f;
     const bool row_on = f < RG && iy < ny;
     const int g = blockIdx.y;
     const int w0 = g * group_size, w1 = w0 + group_size < n_w ? w0 + group_size : n_w;
-    if constexpr (!pow_tabs_side(NX)) load_log_table(log_tab, lane);
-    else load_a_table(log_tab, lane);
+    load_log_table(log_tab, lane);
     wave_lds_sync();
     const size_t Spx = (size_t)ny * NX;
     const int psf0 = per_field > 0 ? (f0 + w0 / per_field) * npf : 0;      // (wave-uniform)
     const int n_here = per_field > 0 ? npf : n_psf;
     for (int p = 0; p < n_here; ++p)
         raster_sums_all<NX, 0, WRAP>(prep, plen, w0, w1, psf0 + p, n_ps, n_sersic, t, row_on ? iy : 0, row_on, log_tab,
-                                     part + ((size_t)g * n_here + p) * 3 * Spx, Spx, wr, pow_mode);
+                                     part + ((size_t)g * n_here + p) * 3 * Spx, Spx, wr);
 }
 
 // lin[i] += part[0][i] + part[1][i] + ... (fixed order)

@@ -595,12 +595,12 @@ static int launch_raster_sums(psfmc_ctx* c, int n, const double* prep, int group
     if (c->embed) {
         hipLaunchKernelGGL((k_raster_sums<NX, true>), dim3((c->ny + RG - 1) / RG, groups), dim3(64), 0, st, prep,
                            c->plen, n, group_size, c->n_ps, c->n_sersic, c->ny, c->n_psf, c->d_linpart, per_field,
-                           f0, c->n_psf_field, c->wrap, kPowTabsBuilt);
+                           f0, c->n_psf_field, c->wrap);
         return PSFMC_OK;
     }
     hipLaunchKernelGGL((k_raster_sums<NX, false>), dim3((c->ny + RG - 1) / RG, groups), dim3(64), 0, st, prep, c->plen, n,
                        group_size, c->n_ps, c->n_sersic, c->ny, c->n_psf, c->d_linpart, per_field, f0,
-                       c->n_psf_field, c->wrap, kPowTabsBuilt);
+                       c->n_psf_field, c->wrap);
     return PSFMC_OK;
 }
 
@@ -1447,11 +1447,11 @@ __global__ void __launch_bounds__(256) k_pow_tables(double* __restrict__ prep, c
 // kernel are 4 ... 5 us of a default-size ensemble's 45-us half-step, the in-wave form 1 us.
 constexpr int kInWavePowTabPairs = 96;
 // walkers [w_off, w_off + n) of c->d_prep; after the kernel that wrote their records, same stream.
-// `force`: the caller's next kernel reads the tables from memory whatever the batch size (k_raster_sums).
-static void launch_pow_tables(psfmc_ctx* c, int n, int w_off, const uint8_t* skip, hipStream_t st, bool force = false) {
+// (Only the forward row kernels read the tables: k_raster_sums keeps the log2 + exp2 form at every size.)
+static void launch_pow_tables(psfmc_ctx* c, int n, int w_off, const uint8_t* skip, hipStream_t st) {
     if (c->backend != PSFMC_BACKEND_FUSED || c->n_sersic == 0 || n <= 0 || !c->use_pow_tabs) return;
     const int pairs = n * c->n_sersic;
-    const bool build = force || pairs > kInWavePowTabPairs;
+    const bool build = pairs > kInWavePowTabPairs;
     // a batch written in several pieces (w_off > 0) reads its tables from memory only if every piece has them
     c->prep_tabs_built = w_off == 0 ? build : (c->prep_tabs_built && build);
     if (!build) return;
@@ -2059,8 +2059,6 @@ static int accumulate_from_prep(psfmc_ctx* c, int W, hipStream_t st, int f0 = 0,
     const bool fused = c->backend == PSFMC_BACKEND_FUSED;
     if (fused && c->linear_acc) {
         if (!c->d_lin) return fail(PSFMC_EINVAL, "linear sums not allocated");
-        // k_raster_sums reads the power tables from memory: a small batch's were left to its row waves
-        if (c->use_pow_tabs && !c->prep_tabs_built) launch_pow_tables(c, W, 0, nullptr, st, true);
         return accumulate_linear(c, W, st, f0, nf, per);
     }
     if (c->n_fields > 1) return fail(PSFMC_EINVAL, "contexts of several fields accumulate images as linear sums only");
