@@ -294,3 +294,45 @@ def test_rasteriser_forms_by_row_length():
             perm = np.random.RandomState(2).permutation(len(got))
             assert np.array_equal(m.log_posterior_batch(theta[perm]), got[perm])
         m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('side', [288, 512])
+def test_power_table_rasteriser_extreme_indices(side):
+    """The power-table form over the Sersic indices a prior can reach (n = 0.1 ... 15: exponents p = 1 / (2n) from
+    5 down to 1/30), a centre on a pixel corner and one a hair off a pixel centre (rho^2 down to 1e-14), against the
+    fp64 oracle: log-likelihood and raw model."""
+    from test_gpu_fullsize import make_model
+    model, fld = make_model(side, 1, 'fused', max_walkers=16)
+    assert model.engine.get_option('pow_tabs') == 1
+    field = orc.make_field(fld['sci'], fld['ivm'], [fld['psf']], [fld['psf_ivm']], mag_zp=fld['mag_zp'])
+    layout = helpers.synth_layout(1)
+    base = fld['truth'].copy()                       # [ps mag, x, y | angle, index, mag, reff, reff_b, x, y]
+    thetas = []
+    for n_index in (0.1, 0.3, 0.5, 1.0, 2.5, 6.0, 15.0):
+        t = base.copy()
+        t[4] = n_index
+        thetas.append(t)
+    for cx, cy in ((side / 2 + 0.5, side / 2 + 0.5), (side / 2 + 1e-7, side / 2 - 3e-8)):
+        t = base.copy()
+        t[8], t[9] = cx, cy
+        thetas.append(t)
+    thetas = np.array(thetas)
+    got = model.log_likelihood_batch(thetas)
+    imgs = model.sample_images(thetas, ('raw_model',))['raw_model']
+    for i, t in enumerate(thetas):
+        want = helpers.oracle_loglike(field, layout, t)
+        # the last case puts a pixel 1e-7 px from the centre: the reference's centroid term makes it 1e9 times its
+        # neighbours, and ANY fp64 transform of that image carries eps x 1e9 into the rest (the oracle's numpy FFT and
+        # the kernels differ by 1.6e-7 in the log-likelihood there): the raw model is the check, BASELINE's 1e-5 the bound
+        tol = 1e-5 if i == len(thetas) - 1 else 2e-10
+        assert np.isfinite(want) and abs(got[i] - want) <= tol * abs(want), (side, i, got[i], want)
+        comps, psf_index = helpers.comps_from_theta(layout, t)
+        _, ref = orc.evaluate(field, comps, psf_index, raw_dtype=np.float64)
+        raw = ref['raw_model']
+        assert np.all(np.isfinite(raw)) and np.all(np.isfinite(imgs[i]))
+        # per pixel, relative: every pixel's Sersic value to a few 1e-14 whatever the image's peak
+        big = np.abs(raw) > 1e-280                     # (n = 0.1 underflows to 0 a few r_eff out)
+        assert np.max(np.abs(imgs[i][big] - raw[big]) / np.abs(raw[big])) <= 1e-11, (side, i)
+        assert np.all(np.abs(imgs[i][~big]) <= 1e-279), (side, i)
+    model.close()
