@@ -1442,16 +1442,18 @@ __global__ void __launch_bounds__(256) k_pow_tables(double* __restrict__ prep, c
     const double p = rec[kPrepHead + kPrepPs * n_ps + kPrepSersic * k + 7];
     build_pow_table(p, rec + prep_rec_len(n_ps, n_sersic) + (size_t)k * kPowTab, lane);
 }
-// Batches of up to this many (walker, component) pairs run WITHOUT the launch: their forward row waves form the
-// table entries they read themselves (same function, same bits) -- a kernel boundary plus a one-wave-per-pair
-// kernel are 4 ... 5 us of a default-size ensemble's 45-us half-step, the in-wave form 1 us.
-constexpr int kInWavePowTabPairs = 96;
+// Small batches run WITHOUT the launch: their forward row waves form the table entries they read themselves (same
+// function, same bits; ~400 instructions per wave and component) -- a kernel boundary plus a one-wave-per-pair
+// kernel are 4 ... 5 us of a small ensemble's half-step.  "Small" = up to this many (row wave, component) pairs in
+// the forward launch, about where the chip's wave slots are full and the extra instructions stop being free
+// (64 (walker, component) pairs at 512^2, 16 at 1024^2, ~110 at 288^2).
+constexpr int kInWavePowTabWaves = 8192;
 // walkers [w_off, w_off + n) of c->d_prep; after the kernel that wrote their records, same stream.
 // (Only the forward row kernels read the tables: k_raster_sums keeps the log2 + exp2 form at every size.)
 static void launch_pow_tables(psfmc_ctx* c, int n, int w_off, const uint8_t* skip, hipStream_t st) {
     if (c->backend != PSFMC_BACKEND_FUSED || c->n_sersic == 0 || n <= 0 || !c->use_pow_tabs) return;
     const int pairs = n * c->n_sersic;
-    const bool build = pairs > kInWavePowTabPairs;
+    const bool build = (long long)pairs * c->nblk > kInWavePowTabWaves;
     // a batch written in several pieces (w_off > 0) reads its tables from memory only if every piece has them
     c->prep_tabs_built = w_off == 0 ? build : (c->prep_tabs_built && build);
     if (!build) return;

@@ -277,7 +277,7 @@ def test_rasteriser_forms_by_row_length():
     tests/test_gpu_random.py (106 shapes on either side of 256) and tests/test_gpu_fullsize.py; here: the rule
     as the context reports it, and that the table form does not depend on the batch -- small batches form the
     table entries in the row waves, large ones read k_pow_tables' output, subsets and permutations of a batch
-    return the same bits."""
+    return the same bits (also across the size at which the library switches between the two)."""
     import synth_field
     from test_gpu_fullsize import make_model
     for side, want in ((128, 0.0), (256, 0.0), (264, 1.0), (512, 1.0)):
@@ -289,8 +289,11 @@ def test_rasteriser_forms_by_row_length():
             got = m.log_posterior_batch(theta)                       # 400 (walker, component) pairs: k_pow_tables
             assert np.isfinite(got).sum() > 100
             assert np.array_equal(m.log_posterior_batch(theta[5:9]), got[5:9])        # 8 pairs: in the row waves
-            assert np.array_equal(m.log_posterior_batch(theta[40:88]), got[40:88])    # 96 pairs: the last in-wave size
-            assert np.array_equal(m.log_posterior_batch(theta[40:89]), got[40:89])    # 98 pairs: the first with tables
+            # the boundary: batches of up to 8192 (row wave, component) pairs form their entries in the row waves
+            last = 8192 // (2 * int(m.engine.get_option('partials_per_walker')))      # walkers of the last such batch
+            assert 4 < last < 150
+            assert np.array_equal(m.log_posterior_batch(theta[40:40 + last]), got[40:40 + last])
+            assert np.array_equal(m.log_posterior_batch(theta[40:41 + last]), got[40:41 + last])
             perm = np.random.RandomState(2).permutation(len(got))
             assert np.array_equal(m.log_posterior_batch(theta[perm]), got[perm])
         m.close()
