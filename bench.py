@@ -27,6 +27,16 @@ Prints ONE JSON line on rank 0 (contract in the task description), including
                  evals/s -- an equivalent rate of an unfused design, not a fraction of peak
   cpu_baseline   the numpy oracle (a port of the reference algorithm) timed on this host,
                  one walker per call like the reference
+  configs        (N = 1) the other single-GPU workloads of BASELINE.json, each timed for >= 1 s after the
+                 headline: config 3 (512^2, 2 Sersic, 1024 walkers), config 4's per-GPU share (1024^2, 4
+                 Sersic, 256 walkers), config 5's share (8 fields x 256 walkers: evaluations and stretch-move
+                 iterations), one embedded side (170^2) -- value, roofline by measured bytes, the two
+                 ceilings and a check of >= 4 walkers against the CPU oracle
+  multi_gpu      the product's sharded paths at this N: config 4 strong-scaled
+                 (1024^2, 2048 walkers over the ranks), the device sampler with sharded half-steps at 256
+                 walkers, config 5 with its 64 fields dealt to the ranks
+With N > 1 the timed step itself goes through `parallel.ShardedLogPosterior.evaluate_device`: N x --walkers
+vectors resident on every rank, each rank evaluating its block, one RCCL all-gather per batch.
 """
 import argparse
 import json
@@ -61,9 +71,10 @@ def pmc_table(args):
     passes (profiles/pmc_traffic.json; FETCH_SIZE doubled per MI355X_MICROARCH.md section
     HBM, plus WRITE_SIZE), or {} when that shape was not profiled."""
     path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    size = args if isinstance(args, int) else args.size
     try:
         with open(path) as f:
-            return json.load(f)['%dx%d' % (args.size, args.size)]
+            return json.load(f)['%dx%d' % (size, size)]
     except (IOError, OSError, KeyError, ValueError):
         return {}
 
@@ -138,34 +149,44 @@ def usable_cores():
                'cgroup_cpu_quota': quota}
 
 
-def draw_theta(args, fld, n, seed=1):
+def draw_theta(args, fld, n, seed=1, size=None, sersic=None):
     import synth_field
+    size, sersic = size or args.size, args.sersic if sersic is None else sersic
     half = n // 2
     return np.vstack([
-        synth_field.draw_walkers(args.size, args.sersic, half, seed=seed),
-        synth_field.draw_walkers(args.size, args.sersic, n - half, seed=seed + 1,
+        synth_field.draw_walkers(size, sersic, half, seed=seed),
+        synth_field.draw_walkers(size, sersic, n - half, seed=seed + 1,
                                  near_truth=fld['truth'])])
 
 
-def build_problem(args, device, seed=0):
-    """Synthetic field + walker vectors.  Returns (model, theta[W,P], field dict)."""
+def build_problem(args, device, seed=0, size=None, sersic=None, walkers=None, max_walkers=None):
+    """Synthetic field + walker vectors.  Returns (model, theta[W,P], field dict).  size / sersic / walkers
+    default to the command line's; max_walkers (the context's capacity) to `walkers`."""
     import tempfile
     import synth_field
     from psfmc_amd import MultiComponentModel, fits_io
-    fld = synth_field.make_field(args.size, args.sersic, seed=seed)
+    size, sersic = size or args.size, args.sersic if sersic is None else sersic
+    walkers = walkers or args.walkers
+    fld = synth_field.make_field(size, sersic, seed=seed)
     tmp = tempfile.mkdtemp(prefix='psfmc_bench_')
     for key, name in (('sci', 'sci.fits'), ('ivm', 'ivm.fits'), ('psf', 'psf.fits'),
                       ('psf_ivm', 'psf_ivm.fits')):
         fits_io.write_image(os.path.join(tmp, name), fld[key])
     path = os.path.join(tmp, 'model.py')
     with open(path, 'w') as f:
-        f.write(synth_field.model_file_text(args.size, args.sersic))
+        f.write(synth_field.model_file_text(size, sersic))
     model = MultiComponentModel(path, device=device, backend=args.backend,
-                                max_walkers=args.walkers)
-    return model, draw_theta(args, fld, args.walkers), fld
+                                max_walkers=max_walkers or walkers)
+    return model, draw_theta(args, fld, walkers, size=size, sersic=sersic), fld
 
 
-def engine_mod_column_engine(n):
+def column_kernel_name(eng, n):
+    """The column kernel this context launches NOW (the library's own decision: options such as cols3 and
+    storage_f32 and the row-group size go into it), or psfmc_amd.engine.column_engine's static answer for a
+    library that does not report it."""
+    code = eng.get_option('column_engine')
+    if code == code:
+        return {0: 'k_cols', 1: 'k_cols3', 2: 'k_cols3g'}[int(code)]
     from psfmc_amd.engine import column_engine
     return column_engine(n)[0]
 
@@ -180,7 +201,7 @@ def kernel_profile(eng, args, one_batch, torch, dev, reps):
     t_bytes = 2 * nxh * n * 16                  # transposed half-spectra of one walker
     designed = {'rows_fwd': t_bytes, 'cols': 2 * t_bytes, 'rows_inv': t_bytes}
     names = {'rows_fwd': 'k_rows_fwd<%d, false>' % n, 'rows_inv': 'k_rows_inv<%d>' % n,
-             'cols': '%s<%d, true>' % (engine_mod_column_engine(n), n)}
+             'cols': '%s<%d, true>' % (column_kernel_name(eng, n), n)}
     streams = eng.get_option('streams')
     eng.set_option('streams', 1)
     eng.set_option('profile', 1)
@@ -602,6 +623,247 @@ def many_fields(args, torch, dist, world, rank, local, dev, gloo):
         dist.destroy_process_group()
 
 
+
+def timed_calls(call, sync, min_s=1.0, decide=None):
+    """Seconds per call of `call()` (asynchronous launches; `sync()` waits for the device): two calls
+    sized, then enough of them for >= min_s between two synchronisations.  `decide(n)` lets rank 0's
+    count be every rank's (multi-rank runs).  Returns (seconds per call, calls timed)."""
+    call()
+    sync()
+    t0 = time.perf_counter()
+    call()
+    call()
+    sync()
+    one = max((time.perf_counter() - t0) / 2, 1e-6)
+    n = max(3, int(np.ceil(min_s / one)))
+    if decide is not None:
+        n = decide(n)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        call()
+    sync()
+    return (time.perf_counter() - t0) / n, n
+
+
+def oracle_check(model, fld, sersic, theta, got, count=4):
+    """max relative difference of `count` walkers' log-posteriors (spread over the batch) from the CPU
+    oracle's log-likelihood + the host priors (scipy): the bench's own parity check of a timed batch."""
+    for p_ in (os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')):
+        if p_ not in sys.path:
+            sys.path.insert(0, p_)
+    import psfmc_oracle as orc
+    import helpers
+    field = orc.make_field(fld['sci'], fld['ivm'], [fld['psf']], [fld['psf_ivm']], mag_zp=fld['mag_zp'])
+    layout = helpers.synth_layout(sersic)
+    idx = np.unique(np.linspace(0, len(theta) - 1, count * 3).astype(int))
+    prior = model.log_priors_batch(theta[idx])
+    idx, prior = idx[np.isfinite(prior)][:count], prior[np.isfinite(prior)][:count]   # (walkers that reach the likelihood)
+    worst = 0.0
+    for i, lp in zip(idx, prior):
+        want = helpers.oracle_loglike(field, layout, theta[i]) + lp
+        if np.isfinite(want):
+            worst = max(worst, abs(got[i] - want) / abs(want))
+        elif np.isfinite(got[i]):
+            return float('inf'), len(idx)
+    return float(worst), len(idx)
+
+
+def step_rooflines(size, rate, per_pass, engine_mod, device, n_simd):
+    """The step's roofline by measured bytes and the two measured ceilings for a rate of `rate` evals/s at
+    `per_pass` walkers per pass (objects as on the headline line)."""
+    table = pmc_table(size)
+    per_walker = [pmc_lookup(table, k) for k in ('k_rows_fwd<', 'k_cols', 'k_rows_inv<')]
+    measured = sum(per_walker) if all(per_walker) else None
+    out = {'roofline_step': {
+        'bound': 'hbm', 'achieved': measured * rate / 1e9 if measured else None, 'peak': HBM_PEAK_GBPS,
+        'unit': 'GB/s', 'frac': measured * rate / 1e9 / HBM_PEAK_GBPS if measured else None,
+        'measured_bytes_per_eval': measured,
+        'algorithmic_equiv_GBps': algorithmic_bytes_per_eval(size) * rate / 1e9}}
+    t_bytes = 2 * (size // 2 + 1) * size * 16
+    sc = sweep_ceiling(engine_mod, device, t_bytes * per_pass, per_pass, rate)
+    out['sweep_ceiling'] = {k: sc[k] for k in ('pass_floor_us', 'step_us_per_pass', 'step_over_floor', 'walkers_per_pass')}
+    vc = valu_ceiling(engine_mod, device, table, per_pass, rate, n_simd)
+    if vc:
+        out['valu_ceiling'] = {k: vc[k] for k in ('pass_floor_us', 'step_over_valu_floor',
+                                                  'valu_wave_instructions_per_walker')}
+        out['step_over_larger_floor'] = sc['step_us_per_pass'] / max(vc['pass_floor_us'], sc['pass_floor_us'])
+    return out
+
+
+def other_configs(args, torch, dev, local):
+    """N = 1: the single-GPU workloads of BASELINE.json besides the headline, each for >= 1 s of timed
+    device-resident evaluations after a warm-up, on this same box in this same run."""
+    from psfmc_amd import engine as engine_mod
+    n_simd = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+    sync = lambda: torch.cuda.synchronize(dev)
+    out = {}
+    for key, size, sersic, walkers, what in (
+            ('config3_512', 512, 2, 1024, 'BASELINE config 3: synthetic 512x512, 1 PointSource + 2 Sersic, 1024 walkers'),
+            ('config4_share_1024', 1024, 4, 256, "BASELINE config 4's per-GPU share: synthetic 1024x1024, 1 PointSource + "
+                                                 '4 Sersic, 256 of the 2048 walkers'),
+            ('embedded_170', 170, 1, 4096, 'a side the transforms are not built for (170x170, embedded), 1 PointSource + '
+                                           '1 Sersic, 4096 walkers')):
+        model, theta, fld = build_problem(args, local, size=size, sersic=sersic, walkers=walkers)
+        eng = model.engine
+        th = torch.from_numpy(theta).to(dev)
+        res = torch.empty(walkers, dtype=torch.float64, device=dev)
+        stream = torch.cuda.Stream(dev)
+        call = lambda: eng.logpost_theta_device(walkers, th.data_ptr(), 0, res.data_ptr(), stream.cuda_stream)
+        per_call, n_calls = timed_calls(call, sync)
+        got = res.cpu().numpy()
+        rel, n_chk = oracle_check(model, fld, sersic, theta, got)
+        rec = {'workload': what + ', raw vectors resident in HBM -> log-posterior, fp64', 'value': walkers / per_call,
+               'unit': 'evals/s', 'timed_s': per_call * n_calls, 'calls': n_calls, 'walkers_per_call': walkers,
+               'finite_logposts': int(np.isfinite(got).sum()), 'check_vs_cpu_rel': rel, 'walkers_checked': n_chk,
+               'transform': [int(eng.get_option('transform_ny')), int(eng.get_option('transform_nx'))]}
+        if args.backend == 'fused':
+            rec.update(step_rooflines(int(eng.get_option('transform_nx')), rec['value'], eng.pass_size(walkers),
+                                      engine_mod, local, n_simd))
+        out[key] = rec
+        model.close()
+        del th, res
+    # config 5's per-GPU share: 8 independent 256^2 fields x 256 walkers in ONE context -- evaluations, and as a fit
+    import synth_field
+    from psfmc_amd import FieldSet, FieldSetSampler
+    n_f, n_w = 8, 256
+    probs = [build_problem(args, local, seed=100 + f, size=256, sersic=1, walkers=n_w) for f in range(n_f)]
+    fs = FieldSet([m for m, _, _ in probs], max_walkers=n_f * n_w, device=local)
+    all_theta = torch.from_numpy(np.concatenate([t for _, t, _ in probs])).to(dev)
+    all_out = torch.empty(n_f * n_w, dtype=torch.float64, device=dev)
+    seg_f, seg_n = list(range(n_f)), [n_w] * n_f
+    call = lambda: fs.context.logpost_theta_device(seg_f, seg_n, all_theta.data_ptr(), all_out.data_ptr(), None)
+    per_call, n_calls = timed_calls(call, sync)
+    got = all_out.cpu().numpy()
+    rel = max(oracle_check(probs[f][0], probs[f][2], 1, probs[f][1], got[f * n_w:(f + 1) * n_w], count=1)[0]
+              for f in (0, 3, 5, 7))
+    rec = {'workload': "BASELINE config 5's per-GPU share: 8 independent synthetic 256x256 fields x 256 walkers in one "
+                       'context (psfmc_ctx_create_fields), 1 PointSource + 1 Sersic, raw vectors resident in HBM -> '
+                       'log-posterior, fp64',
+           'value': n_f * n_w / per_call, 'unit': 'evals/s', 'timed_s': per_call * n_calls, 'calls': n_calls,
+           'finite_logposts': int(np.isfinite(got).sum()), 'check_vs_cpu_rel': rel, 'walkers_checked': 4}
+    rec.update(step_rooflines(256, rec['value'], int(fs.context.get_option('chunk_walkers')), engine_mod, local, n_simd))
+    sampler = FieldSetSampler(n_w, fs, accumulate=False)
+    p0 = [synth_field.draw_walkers(256, 1, n_w, seed=300 + f, near_truth=probs[f][2]['truth']) for f in range(n_f)]
+    for f, sub in enumerate(sampler.fields):
+        sub.random_state = np.random.RandomState(900 + f).get_state()
+    for _ in sampler.sample(p0, iterations=4):
+        pass
+    n_iter, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < 1.0:
+        for _ in sampler.sample(p0, iterations=32):
+            pass
+        n_iter += 32
+    dt = time.perf_counter() - t0
+    rec['mcmc'] = {'stretch_move_iterations_per_s': n_iter / dt, 'evals_per_s': n_f * n_w * n_iter / dt,
+                   'iterations': n_iter, 'timed_s': dt,
+                   'what': 'the 8 ensembles stepped together (FieldSetSampler); an iteration moves every walker of '
+                           'every field once'}
+    out['config5_share_8_fields'] = rec
+    fs.close()
+    for m, _, _ in probs:
+        m.close()
+    return out
+
+
+def multi_gpu_extras(args, torch, dist, world, rank, local, dev, gloo):
+    """The product's sharded paths at this world size, every rank taking part:
+    config 4 strong-scaled, the device sampler with sharded half-steps at 256 walkers, config 5's 64 fields
+    dealt to the ranks.  Times are the MAX over ranks; rank 0 returns the object."""
+    import synth_field
+    from psfmc_amd import FieldSet
+    from psfmc_amd.parallel import RankGroup, ShardedLogPosterior, shard_bounds
+    from psfmc_amd.sampler import DeviceEnsembleSampler
+    rg = RankGroup(None, dev) if world > 1 else None
+    sync = lambda: torch.cuda.synchronize(dev)
+
+    def decide(n):
+        return int(rg.broadcast_object(n)) if rg is not None else n
+
+    def rank_max(seconds):
+        if world == 1:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device='cpu' if gloo else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    out = {'n_gpus': world, 'dist_backend': (args.dist_backend if world > 1 else None)}
+    # (1) config 4, strong scaling: 1024^2, 1 PS + 4 Sersic, 2048 walkers over the ranks, one all-gather per batch
+    n_w = args.config4_walkers
+    block = -(-n_w // world)
+    model, theta, fld = build_problem(args, local, size=1024, sersic=4, walkers=n_w, max_walkers=block)
+    th = torch.from_numpy(theta).to(dev)
+    sharded = ShardedLogPosterior(model, group=rg, device=dev)
+    keep = {}
+
+    def call():
+        keep['out'] = sharded.evaluate_device(th)
+    if world > 1:
+        dist.barrier()
+    per_call, n_calls = timed_calls(call, sync, decide=decide)
+    per_call = rank_max(per_call)
+    got = keep['out'].cpu().numpy()
+    rel, n_chk = (oracle_check(model, fld, 4, theta, got) if rank == 0 else (None, 0))
+    out['config4_strong'] = {
+        'workload': 'BASELINE config 4, strong scaling: synthetic 1024x1024, 1 PointSource + 4 Sersic, %d walkers '
+                    'resident on every rank, %d per rank per batch, one all-gather of the log-posteriors per batch '
+                    '(parallel.ShardedLogPosterior.evaluate_device), fp64' % (n_w, block),
+        'value': n_w / per_call, 'unit': 'evals/s', 'scaling': 'strong', 'timed_s': per_call * n_calls, 'calls': n_calls,
+        'finite_logposts': int(np.isfinite(got).sum()), 'check_vs_cpu_rel': rel, 'walkers_checked': n_chk}
+    model.close()
+    del th, keep['out']
+    # (2) the device sampler with every half-step's proposals sharded: 256 walkers on the headline field
+    n_w = 256
+    model, theta, fld = build_problem(args, local, size=256, sersic=1, walkers=n_w)
+    p0 = synth_field.draw_walkers(256, 1, n_w, seed=41, near_truth=fld['truth'])
+    sampler = DeviceEnsembleSampler(n_w, model, block=32, group=rg)
+    sampler.random_state = np.random.RandomState(17).get_state()
+    for _ in sampler.sample(p0, iterations=32):
+        pass
+    if world > 1:
+        dist.barrier()
+    n_iter = decide(512 if world == 1 else 128)
+    t0 = time.perf_counter()
+    for _ in sampler.sample(p0, iterations=n_iter):
+        pass
+    dt = rank_max(time.perf_counter() - t0)
+    out['sampler_w256'] = {
+        'workload': 'stretch-move iterations of 256 walkers on the 256x256 headline field, walkers resident on the '
+                    'device, every half-step\'s 128 proposals sharded over the ranks and all-gathered '
+                    '(DeviceEnsembleSampler(group=...)); every rank holds the same chain',
+        'stretch_move_iterations_per_s': n_iter / dt, 'evals_per_s': n_w * n_iter / dt, 'iterations': n_iter,
+        'timed_s': dt, 'acceptance_fraction': float(np.mean(sampler.acceptance_fraction))}
+    model.close()
+    # (3) config 5: 64 independent 256^2 fields x 256 walkers, fields dealt to the ranks, no collective
+    n_fields, n_w = args.config5_fields, 256
+    lo, hi = shard_bounds(n_fields, world, rank)
+    probs = [build_problem(args, local, seed=100 + f, size=256, sersic=1, walkers=n_w) for f in range(lo, hi)]
+    mine = hi - lo
+    fs = FieldSet([m for m, _, _ in probs], max_walkers=mine * n_w, device=local)
+    all_theta = torch.from_numpy(np.concatenate([t for _, t, _ in probs])).to(dev)
+    all_out = torch.empty(mine * n_w, dtype=torch.float64, device=dev)
+    seg_f, seg_n = list(range(mine)), [n_w] * mine
+    call = lambda: fs.context.logpost_theta_device(seg_f, seg_n, all_theta.data_ptr(), all_out.data_ptr(), None)
+    if world > 1:
+        dist.barrier()
+    per_call, n_calls = timed_calls(call, sync, decide=decide)
+    per_call = rank_max(per_call)
+    got = all_out.cpu().numpy()
+    rel = oracle_check(probs[0][0], probs[0][2], 1, probs[0][1], got[:n_w], count=2)[0] if rank == 0 else None
+    finite = torch.tensor([float(np.isfinite(got).sum())], dtype=torch.float64, device='cpu' if gloo else dev)
+    if world > 1:
+        dist.all_reduce(finite, op=dist.ReduceOp.SUM)
+    out['config5_fields'] = {
+        'workload': 'BASELINE config 5: %d independent synthetic 256x256 fields x 256 walkers, %d fields per rank in '
+                    'one context each (FieldSet), 1 PointSource + 1 Sersic, raw vectors resident in HBM -> '
+                    'log-posterior, no data-path collective, fp64' % (n_fields, -(-n_fields // world)),
+        'value': n_fields * n_w / per_call, 'unit': 'evals/s', 'scaling': 'strong', 'timed_s': per_call * n_calls,
+        'calls': n_calls, 'finite_logposts': int(finite.item()), 'check_vs_cpu_rel': rel}
+    fs.close()
+    for m, _, _ in probs:
+        m.close()
+    return out if rank == 0 else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -639,6 +901,10 @@ def main():
     ap.add_argument('--cpu-procs', type=int, default=-1,
                     help='processes of the all-cores CPU baseline (-1 = one per physical core, 0 = skip)')
     ap.add_argument('--cpu-worker', type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument('--no-configs', action='store_true', help='skip the other single-GPU workloads (N = 1)')
+    ap.add_argument('--no-multi', action='store_true', help="skip the sharded paths' side figures (multi_gpu)")
+    ap.add_argument('--config4-walkers', type=int, default=2048, help='walkers of the strong-scaled config 4')
+    ap.add_argument('--config5-fields', type=int, default=64, help='fields of config 5, dealt to the ranks')
     args = ap.parse_args()
     if args.cpu_worker >= 0:
         return cpu_worker(args)
@@ -690,15 +956,21 @@ def main():
             dist.all_gather_into_tensor(got, probe)
             if not gloo:
                 torch.cuda.synchronize(dev)
-            if got.cpu().tolist() != [float(r) for r in range(world)]:
+            ranks_seen = [int(v) for v in got.cpu().tolist()]
+            if ranks_seen != list(range(world)):
                 raise RuntimeError('all_gather returned %r' % (got.cpu().tolist(),))
         except Exception as exc:           # noqa: BLE001 -- report and leave, whatever it was
             dog.failed(exc)
         dog.done()
+    else:
+        ranks_seen = [0]
 
     if args.fields > 1:
         return many_fields(args, torch, dist, world, rank, local, dev, gloo)
-    model, theta, fld = build_problem(args, local)
+    # N ranks: a batch is N x --walkers vectors, the SAME on every rank and resident in every rank's HBM; a rank
+    # evaluates its contiguous block of --walkers and the blocks are all-gathered (weak scaling)
+    w_all = args.walkers * world
+    model, theta, fld = build_problem(args, local, walkers=w_all, max_walkers=args.walkers)
     eng = model.engine
     if args.chunk:
         eng.set_option('chunk_walkers', args.chunk)
@@ -707,14 +979,25 @@ def main():
         eng.set_option(key, float(val))
     # the batches of a step cycle through n_sets sets of walkers of their own (same field); all resident in HBM
     n_sets = max(1, min(args.batches, args.distinct_batches))
-    thetas = [theta] + [draw_theta(args, fld, args.walkers, seed=11 + 2 * b) for b in range(1, n_sets)]
-    theta_dev = torch.from_numpy(np.ascontiguousarray(np.stack(thetas))).to(dev)      # [n_sets, W, P]
+    thetas = [theta] + [draw_theta(args, fld, w_all, seed=11 + 2 * b) for b in range(1, n_sets)]
+    theta_dev = torch.from_numpy(np.ascontiguousarray(np.stack(thetas))).to(dev)      # [n_sets, N W, P]
     out = torch.empty((n_sets, args.walkers), dtype=torch.float64, device=dev)
-    gathered = torch.empty(args.walkers * world, dtype=torch.float64, device='cpu' if gloo else dev)
-    # a real (non-NULL) stream: the library launches on the stream it is handed,
-    # and the HIP events below must sit on that same stream
-    stream = torch.cuda.Stream(dev)
-    torch.cuda.set_stream(stream)
+    sharded, gathered = None, {}
+    if world > 1:
+        # the product's sharded evaluator (psfmc_amd/parallel.py): this rank's block through
+        # psfmc_eval_theta_device, ONE all-gather of the log-posteriors per batch (RCCL with 'nccl'; host-staged
+        # with the 'gloo' rehearsal back end), every rank ends with all N W values
+        from psfmc_amd.parallel import RankGroup, ShardedLogPosterior
+        rgroup = RankGroup(None, dev)
+        sharded = ShardedLogPosterior(model, group=rgroup, device=dev)
+        stream_cm = rgroup.on_stream()
+        stream_cm.__enter__()                # torch's current stream = the sharded path's stream from here on
+        stream = torch.cuda.current_stream(dev)
+    else:
+        # a real (non-NULL) stream: the library launches on the stream it is handed,
+        # and the HIP events below must sit on that same stream
+        stream = torch.cuda.Stream(dev)
+        torch.cuda.set_stream(stream)
     sptr = stream.cuda_stream
 
     def one_batch(b=0):
@@ -723,25 +1006,50 @@ def main():
     def step():
         for i in range(args.batches):
             b = i % n_sets
-            one_batch(b)
-            if gloo:                         # host staging only in the rehearsal back end
-                dist.all_gather_into_tensor(gathered, out[b].cpu())
-            elif world > 1:
-                dist.all_gather_into_tensor(gathered, out[b])
+            if sharded is None:
+                one_batch(b)
+            else:
+                gathered[b] = sharded.evaluate_device(theta_dev[b])
 
     elapsed = timed_region(args, torch, dist, world, dev, step, gloo)
+    sharded_check = None
     if world > 1:
-        # every rank evaluated the same walkers of the same field: the gathered blocks agree
-        blocks = gathered.reshape(world, args.walkers)
-        assert bool((blocks == blocks[0]).all()), 'ranks disagree on the gathered log-posteriors'
+        # every rank holds every block: this rank's own block evaluated alone must be what the gather put in
+        # its place, and (rank 0) 64 walkers of the LAST rank's block evaluated here must equal what that rank sent
+        # (per-walker results do not depend on the batch: same bits)
+        full = gathered[0]
+        lo = rank * args.walkers
+        eng.logpost_theta_device(args.walkers, theta_dev[0][lo:lo + args.walkers].data_ptr(), 0, out[0].data_ptr(), sptr)
+        far = (world - 1) * args.walkers
+        probe_out = torch.empty(64, dtype=torch.float64, device=dev)
+        eng.logpost_theta_device(64, theta_dev[0][far:far + 64].data_ptr(), 0, probe_out.data_ptr(), sptr)
+        torch.cuda.synchronize(dev)
+        ok = bool(torch.equal(out[0], full[lo:lo + args.walkers]) and torch.equal(probe_out, full[far:far + 64]))
+        flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device='cpu' if gloo else dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        sharded_check = bool(flag.item() == 1.0)
+        assert sharded_check, 'a rank found the gathered log-posteriors different from its own evaluation'
 
     # sanity: the batch the timing ran on is numerically right
     lnpost = out[0].cpu().numpy()
-    n_finite = int(np.isfinite(out.cpu().numpy()).sum())
+    if world == 1:
+        n_finite = int(np.isfinite(out.cpu().numpy()).sum())
+    else:
+        n_finite = int(sum(int(torch.isfinite(g).sum().item()) for g in gathered.values()))
 
     kernels = []
     if rank == 0 and args.backend == 'fused':
         kernels = kernel_profile(eng, args, one_batch, torch, dev, max(2, min(args.steps, 5)))
+    # the sharded paths' side figures: every rank takes part (rank 0 comes from its profile pass)
+    multi = None
+    if world > 1:
+        stream_cm.__exit__(None, None, None)
+        dist.barrier()
+    if not args.no_multi and not args.no_extras and args.backend == 'fused':
+        t0 = time.perf_counter()
+        multi = multi_gpu_extras(args, torch, dist, world, rank, local, dev, gloo)
+        if multi is not None:
+            multi['wall_s'] = time.perf_counter() - t0
 
     if rank == 0:
         evals_per_step = args.walkers * args.batches
@@ -764,9 +1072,16 @@ def main():
                        'image': args.size, 'walkers_per_batch': args.walkers, 'batches_per_step': args.batches,
                        'value_is': 'device-resident vectors (psfmc_eval_theta_device); the Python call '
                                    'log_posterior_batch(theta) with HOST vectors is python_entry_point below',
-                       'evals_per_gpu_per_step': evals_per_step, 'entry_point': 'psfmc_eval_theta_device',
+                       'evals_per_gpu_per_step': evals_per_step,
+                       'entry_point': ('psfmc_eval_theta_device' if world == 1 else
+                                       'psfmc_amd.parallel.ShardedLogPosterior.evaluate_device: a batch = %d vectors '
+                                       'resident on every rank, each rank evaluates its block of %d '
+                                       '(psfmc_eval_theta_device), one all-gather of the log-posteriors per batch '
+                                       '(RankGroup.all_gather_blocks)' % (w_all, args.walkers)),
                        'backend': args.backend, 'parallelism': 'walkers sharded x%d' % world},
-            'finite_logposts': n_finite,
+            'finite_logposts': n_finite, 'ranks_seen': ranks_seen,
+            'dist_backend': args.dist_backend if world > 1 else None,
+            'gathered_equals_own_evaluation_bitwise': sharded_check,
         }
         per_walker = [pmc_lookup(table, k) for k in ('k_rows_fwd<', 'k_cols', 'k_rows_inv<')]
         measured = sum(per_walker) if all(per_walker) else None
@@ -866,6 +1181,12 @@ def main():
                 eng.set_option('storage_f32', 0)
                 one_batch()
                 torch.cuda.synchronize(dev)
+        if multi is not None:
+            line['multi_gpu'] = multi
+        if world == 1 and not args.no_configs and not args.no_extras and args.backend == 'fused':
+            t0 = time.perf_counter()
+            line['configs'] = other_configs(args, torch, dev, local)
+            line['configs']['wall_s'] = time.perf_counter() - t0
         if world == 1 and not args.no_example:
             ex = example_model_rate()
             if ex:
@@ -891,7 +1212,7 @@ def main():
         print(json.dumps(line))
     model.close()
     if world > 1:
-        dist.barrier()              # rank 0 may still have been in its profile pass
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -44,14 +44,17 @@ typedef struct psfmc_ctx psfmc_ctx;
 
 /* convolution back ends (both run entirely on the GPU) */
 #define PSFMC_BACKEND_FUSED   0  /* hand-written LDS FFT fused with rasteriser / spectral multiply / chi^2.
-                                    Sides: the powers of two 64..1024 and the even 5-smooth sides 96 100 120
+                                    BUILT sides: the powers of two 64..1024 and the even 5-smooth sides 96 100 120
                                     144 150 160 180 192 200 240 250 288 300 320 360 384 400 480 500 576 600
                                     640 720 768 800 900 960 and, with a factor 7, 84 98 112 126 140 168 196
                                     210 224 252 280 294 336 350 392 420 448 504 560 630 672 700 784 840 896,
                                     with a factor 11 or 13: 88 104 110 130 132 156 176 208 220 260 264 286 308 312
                                     330 352 364 390 416 440 484 520 528 572 616 624 650 660 676 704 728 780 832
-                                    (nx and ny independently, any combination);
-                                    psfmc_ctx_create returns PSFMC_EINVAL for any other shape */
+                                    (nx and ny independently, any combination).  Any OTHER even side is EMBEDDED
+                                    (round 3): it runs on the kernels of a built side >= side + PSF side - 1 of
+                                    that axis (overlap-save; every array at this boundary keeps the image's own
+                                    shape).  psfmc_ctx_create returns PSFMC_EINVAL only for odd sides and for an
+                                    unbuilt side with side + PSF side - 1 above the largest built side */
 #define PSFMC_BACKEND_HIPFFT  1  /* batched hipFFT D2Z/Z2D between separate kernels: any even shape
                                     (psfMC/utils.py:25-32 accepts those); also the cross-check path */
 
@@ -186,6 +189,8 @@ int psfmc_eval_theta_device(psfmc_ctx* ctx, int W, const double* d_theta, const 
  *   psfmc_accumulate_theta_field  posterior-image sums of ONE field from raw vectors (analysis/images.py:62-74)
  *   psfmc_get_accumulated_field   that field's five posterior images (models.py:74-97) and sample count
  *   psfmc_eval_images_field       the five per-sample images (models.py:222-226) of walkers of one field
+ *   psfmc_eval_batch_field        psfmc_eval_batch for derived rows of one field (round 4: models.py:213-216,
+ *                                 233-236 on caller-derived scalars; the rows' PSF index counts within the field)
  * psfmc_reset_accumulated clears every field's sums, psfmc_reset_accumulated_field one field's.  The raw-sum exchange for sharded ranks
  * (psfmc_get/set_accumulated_sums) and the half-step API (psfmc_stretch_open ...) serve one-field contexts.
  */
@@ -205,6 +210,8 @@ int psfmc_get_accumulated_field(psfmc_ctx* ctx, int field, double* raw, double* 
                                 double* ps_sub, long long* count);
 int psfmc_eval_images_field(psfmc_ctx* ctx, int field, int W, const double* rows, double* raw, double* conv,
                             double* resid, double* ivm, double* ps_sub);
+int psfmc_eval_batch_field(psfmc_ctx* ctx, int field, int W, const double* rows, const uint8_t* skip,
+                           double* loglike);
 int psfmc_eval_theta_fields(psfmc_ctx* ctx, int n_seg, const int* seg_field, const int* seg_count,
                             const double* theta, const double* extra_lnprior, double* lnprob);
 int psfmc_eval_theta_device_fields(psfmc_ctx* ctx, int n_seg, const int* seg_field, const int* seg_count,

@@ -780,13 +780,15 @@ constexpr Fft3gPick fft3g_pick(int n) {
         case 294: return {7, 7};
         case 600: case 660: case 720: return {5, 12};
         case 512: case 640: case 704: case 768: case 832: case 960: case 1024: return {8, 8};
+        // round 4: sides above 1024 -- no two-stage shape (P, T <= 32) reaches them; all 64 lanes, R1 = 18 ... 32
+        case 1152: case 1280: case 1536: case 2048: return {8, 8};
         default: return {0, 0};
     }
 }
 template <int N, int R2_ = fft3g_pick(N).r2, int R3_ = fft3g_pick(N).r3> struct Fft3gShape {
     static constexpr bool kBuilt = R2_ > 0;
     static constexpr int R2 = kBuilt ? R2_ : 1, R3 = kBuilt ? R3_ : 1, L = R2 * R3, R1 = kBuilt ? N / L : 1;
-    static_assert(!kBuilt || (R1 * L == N && L <= 64 && R1 <= 16 && R1 >= 4), "N = R1 R2 R3");
+    static_assert(!kBuilt || (R1 * L == N && L <= 64 && R1 <= 32 && R1 >= 4), "N = R1 R2 R3");
     static constexpr int NB2 = (R1 + R2 - 1) / R2, NB3 = (R1 * R2 + 63) / 64;
     static constexpr int S1 = 64 + R3;                      // >= 64 and = R3 (mod 32): stage 2's reads are conflict-free
     static constexpr int S2 = R1 | 1;

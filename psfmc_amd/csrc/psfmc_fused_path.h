@@ -737,8 +737,9 @@ template <class S> constexpr size_t fused_col3g_lds_bytes() {
 template <class S> constexpr bool cols3g_layout_ok(int rg_log2) { return S::L % 4 != 0 || S::L % (1 << rg_log2) == 0; }
 template <int NY> constexpr bool cols3g_side() { return Fft3gShape<NY>::kBuilt && NY > PSFMC_COLS3G_MIN; }
 
+// (sides above 1024 hold 18 ... 32 complex registers per lane in each of the two layouts: one wave per SIMD)
 template <int NY, bool CONVOLVE, class S = Fft3gShape<NY>>
-__global__ void __launch_bounds__(kColThreads, 2)
+__global__ void __launch_bounds__(kColThreads, (S::R1 > 16 ? 1 : 2))
 k_cols3g(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restrict__ prep,
          const uint8_t* __restrict__ skip, const cd* __restrict__ twy, int plen, int nxh, int n_w, int rg_log2) {
     constexpr int R1 = S::R1, R2 = S::R2, R3 = S::R3, L = S::L, NB3 = S::NB3, WPB = kColThreads / 64;
@@ -1071,6 +1072,17 @@ k_rows_inv(const TS* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const 
 // as the group's partial: part[group][psf][3][ny][NX].  k_sum_partials adds the groups up in order:
 // no atomics, the sums do not depend on how the walkers were grouped in time.
 // ---------------------------------------------------------------------------
+// which lane rasterises which pixel in k_raster_sums: the side's two-stage row shape, or -- sides above 1024,
+// which have none -- one row per wave, x = 64 k + lane
+constexpr bool two_stage_side(int n) { return n <= 1024; }
+template <int NX, bool TWO = two_stage_side(NX)> struct RasterShape {
+    static constexpr int T = FftShape<NX>::T, P = FftShape<NX>::P, TPW = FftShape<NX>::TPW;
+};
+template <int NX> struct RasterShape<NX, false> {
+    static_assert(NX % 64 == 0, "side");
+    static constexpr int T = 64, P = NX / 64, TPW = 1;
+};
+
 template <int P> constexpr int raster_seg() { return P <= 16 ? P : (P % 16 == 0 ? 16 : P % 15 == 0 ? 15 : P % 12 == 0 ? 12 : P % 10 == 0 ? 10 : P % 9 == 0 ? 9 : P % 7 == 0 ? 7 : P % 5 == 0 ? 5 : P); }
 
 template <int NX, int K0, int SEG, bool WRAP>
@@ -1078,7 +1090,7 @@ __device__ __forceinline__ void raster_sums_segment(const double* __restrict__ p
                                                     int n_ps, int n_sersic, int t, int iy, bool row_on,
                                                     double* __restrict__ log_tab, double* __restrict__ out,
                                                     size_t S, const WrapDesc& wr) {
-    constexpr int T = FftShape<NX>::T;
+    constexpr int T = RasterShape<NX>::T;
     double a[SEG], b[SEG], cps[SEG];
 #pragma unroll
     for (int k = 0; k < SEG; ++k) a[k] = b[k] = cps[k] = 0.0;
@@ -1116,7 +1128,7 @@ __device__ __forceinline__ void raster_sums_all(const double* __restrict__ prep,
                                                 int n_ps, int n_sersic, int t, int iy, bool row_on,
                                                 double* __restrict__ log_tab, double* __restrict__ out, size_t S,
                                                 const WrapDesc& wr) {
-    constexpr int P = FftShape<NX>::P, SEG = raster_seg<P>();
+    constexpr int P = RasterShape<NX>::P, SEG = raster_seg<P>();
     if constexpr (K0 < P) {
         raster_sums_segment<NX, K0, SEG, WRAP>(prep, plen, w0, w1, psf, n_ps, n_sersic, t, iy, row_on, log_tab, out, S,
                                                wr);
@@ -1133,7 +1145,7 @@ __global__ void __launch_bounds__(64) k_raster_sums(const double* __restrict__ p
                                                     int n_ps, int n_sersic, int ny, int n_psf,
                                                     double* __restrict__ part, int per_field, int f0, int npf,
                                                     WrapDesc wr) {
-    using S = FftShape<NX>;
+    using S = RasterShape<NX>;
     constexpr int T = S::T, RG = S::TPW;
     static_assert(S::P % raster_seg<S::P>() == 0, "segment");
     __shared__ __align__(16) double log_tab[kLogTabBytes / sizeof(double)];

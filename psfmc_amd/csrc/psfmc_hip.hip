@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -28,6 +29,7 @@
 #include "psfmc_hipfft_path.h"
 #endif
 #include "psfmc_fused_path.h"
+#include "psfmc_rows3_path.h"
 #include "psfmc_theta.h"
 
 using namespace psfmc;
@@ -78,7 +80,7 @@ int psfmc_fail_(int code, const char* fmt, ...) {
 
 // sides the fused kernels are instantiated for (FftShape in psfmc_fft.h): every power of two
 // 64..1024 and the even sides with factors 3, 5, 7, 11, 13 listed there
-#define PSFMC_FUSED_SIDES "64 84 88 96 98 100 104 110 112 120 126 128 130 132 140 144 150 156 160 168 176 180 192 196 200 208 210 220 224 240 250 252 256 260 264 280 286 288 294 300 308 312 320 330 336 350 352 360 364 384 390 392 400 416 420 440 448 480 484 500 504 512 520 528 560 572 576 600 616 624 630 640 650 660 672 676 700 704 720 728 768 780 784 800 832 840 896 900 960 1024"
+#define PSFMC_FUSED_SIDES "64 84 88 96 98 100 104 110 112 120 126 128 130 132 140 144 150 156 160 168 176 180 192 196 200 208 210 220 224 240 250 252 256 260 264 280 286 288 294 300 308 312 320 330 336 350 352 360 364 384 390 392 400 416 420 440 448 480 484 500 504 512 520 528 560 572 576 600 616 624 630 640 650 660 672 676 700 704 720 728 768 780 784 800 832 840 896 900 960 1024 1152 1280 1536 2048"
 // run BODY with `N_` a compile-time copy of the length n; in a split build only for this part's sides
 // (side i of the list belongs to part i mod PSFMC_NPARTS)
 #if PSFMC_NPARTS == 1
@@ -174,6 +176,10 @@ int psfmc_fail_(int code, const char* fmt, ...) {
         case 900: { constexpr int N_ = 900; BODY; } break; \
         case 960: { constexpr int N_ = 960; BODY; } break; \
         case 1024: { constexpr int N_ = 1024; BODY; } break; \
+        case 1152: { constexpr int N_ = 1152; BODY; } break; \
+        case 1280: { constexpr int N_ = 1280; BODY; } break; \
+        case 1536: { constexpr int N_ = 1536; BODY; } break; \
+        case 2048: { constexpr int N_ = 2048; BODY; } break; \
         default: return fail(PSFMC_EINVAL, "fused backend: side %d is not one of " PSFMC_FUSED_SIDES, n); \
     }
 #elif PSFMC_PART == 0
@@ -202,6 +208,7 @@ int psfmc_fail_(int code, const char* fmt, ...) {
         case 768: { constexpr int N_ = 768; BODY; } break; \
         case 832: { constexpr int N_ = 832; BODY; } break; \
         case 960: { constexpr int N_ = 960; BODY; } break; \
+        case 1536: { constexpr int N_ = 1536; BODY; } break; \
         default: return PSFMC_NOT_MINE; \
     }
 #elif PSFMC_PART == 1
@@ -230,6 +237,7 @@ int psfmc_fail_(int code, const char* fmt, ...) {
         case 780: { constexpr int N_ = 780; BODY; } break; \
         case 840: { constexpr int N_ = 840; BODY; } break; \
         case 1024: { constexpr int N_ = 1024; BODY; } break; \
+        case 2048: { constexpr int N_ = 2048; BODY; } break; \
         default: return PSFMC_NOT_MINE; \
     }
 #elif PSFMC_PART == 2
@@ -257,6 +265,7 @@ int psfmc_fail_(int code, const char* fmt, ...) {
         case 720: { constexpr int N_ = 720; BODY; } break; \
         case 784: { constexpr int N_ = 784; BODY; } break; \
         case 896: { constexpr int N_ = 896; BODY; } break; \
+        case 1152: { constexpr int N_ = 1152; BODY; } break; \
         default: return PSFMC_NOT_MINE; \
     }
 #elif PSFMC_PART == 3
@@ -284,6 +293,7 @@ int psfmc_fail_(int code, const char* fmt, ...) {
         case 728: { constexpr int N_ = 728; BODY; } break; \
         case 800: { constexpr int N_ = 800; BODY; } break; \
         case 900: { constexpr int N_ = 900; BODY; } break; \
+        case 1280: { constexpr int N_ = 1280; BODY; } break; \
         default: return PSFMC_NOT_MINE; \
     }
 #endif
@@ -308,6 +318,9 @@ struct psfmc_ctx {
     // the records now in d_prep have their power tables behind them (k_pow_tables ran); false: small batch,
     // the forward row waves form the entries they need themselves (psfmc_device.h raster_row)
     bool prep_tabs_built = false;
+    // every writer of d_prep clears this, launch_pow_tables sets it: a forward launch that rasterises from
+    // records whose table mode was not decided for THIS batch is an error, not wrong pixels
+    bool prep_tabs_valid = false;
     // false: this context's rasterising kernels evaluate log2 + exp2 per pixel (row lengths up to 256:
     // psfmc_device.h pow_tabs_side) and nothing builds tables
     bool use_pow_tabs = true;
@@ -341,6 +354,8 @@ struct psfmc_ctx {
     bool t_f32 = false;       // T stored as complex64 (set_option "storage_f32"); arithmetic stays fp64
     bool plain_shape = false; // both sides power-of-two shapes (what storage_f32 is built for)
     bool row_fast = false;    // nx a power-of-two shape and ny a whole number of its row workgroups
+    bool rows3 = false;       // the row kernels of this context are the one-row-per-wave three-stage ones (psfmc_rows3_path.h):
+                              // every side above 1024; PSFMC_ROWS3=1 in the environment also where both families are built
     long long speculated_runs = 0;   // psfmc_stretch_run calls that took the whole-iteration route
     int speculate = -1;       // device sampler: ensembles of up to 2 x this many walkers run ONE pipeline pass per iteration (0 = never, -1 = the default rule)
     int cols3 = 1;            // column kernel on the wave-wide three-stage engines: 0 never, 1 k_cols3 at 512 / 1024 and k_cols3g at the sides of fft3g_pick, 2 k_cols3g at 512 / 1024 as well
@@ -416,7 +431,74 @@ struct RowShape { int rg, fast_waves, fast_rg_log2, regs; bool plain; };
 // ---------------------------------------------------------------------------
 // TS = the T element type: cd (complex128) or cf (complex64 STORAGE, set_option "storage_f32";
 // built for the power-of-two shapes only)
-template <int N, typename TS> constexpr bool storage_built() { return sizeof(TS) == sizeof(cd) || FftShape<N>::kPlain; }
+template <int N> constexpr bool plain_side() {
+    if constexpr (two_stage_side(N)) return FftShape<N>::kPlain;
+    else return false;
+}
+template <int N, typename TS> constexpr bool storage_built() { return sizeof(TS) == sizeof(cd) || plain_side<N>(); }
+
+// ---- the three-stage row kernels (psfmc_rows3_path.h) ----
+template <int NX, bool FROM_IMAGE, bool WRAP>
+static int launch_rows3_fwd_kernel(psfmc_ctx* c, int n, const double* prep, const uint8_t* skip, cd* Tbuf, int ps_only,
+                                   const double* img, const double* img_scale, double* raw_out, hipStream_t st) {
+    using S = typename Rows3<NX>::S;
+    constexpr size_t lds = rows3_lds_bytes<S>();
+    if constexpr (lds > 64 * 1024) {
+        static thread_local int attr_device = -1;
+        if (attr_device != c->device) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows3_fwd<NX, FROM_IMAGE, WRAP>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_device = c->device;
+        }
+    }
+    if (!FROM_IMAGE && !c->prep_tabs_valid)
+        return fail(PSFMC_EINVAL, "internal: forward rows launched on prep records without a power-table decision");
+    hipLaunchKernelGGL((k_rows3_fwd<NX, FROM_IMAGE, WRAP>), dim3((c->ny + kRows3Waves - 1) / kRows3Waves, n),
+                       dim3(kRows3Threads), lds, st, prep, skip, c->d_twx, Tbuf, c->n_ps, c->n_sersic, c->ny, ps_only, img,
+                       img_scale, raw_out, c->wrap, c->prep_tabs_built ? kPowTabsBuilt : kPowTabsInWave);
+    return PSFMC_OK;
+}
+template <int NX, bool FROM_IMAGE>
+static int launch_rows3_fwd(psfmc_ctx* c, int n, const double* prep, const uint8_t* skip, cd* Tbuf, int ps_only,
+                            const double* img, const double* img_scale, double* raw_out, hipStream_t st) {
+    if constexpr (!rows3_side<NX>()) {
+        return fail(PSFMC_EINVAL, "side %d has no three-stage row kernels", NX);
+    } else {
+        if constexpr (!FROM_IMAGE) {
+            if (c->embed)
+                return launch_rows3_fwd_kernel<NX, false, true>(c, n, prep, skip, Tbuf, ps_only, img, img_scale, raw_out, st);
+        }
+        return launch_rows3_fwd_kernel<NX, FROM_IMAGE, false>(c, n, prep, skip, Tbuf, ps_only, img, img_scale, raw_out, st);
+    }
+}
+template <int NX, bool MULTI>
+static int launch_rows3_inv_kernel(psfmc_ctx* c, int n, const cd* Tbuf, const double* prep, const uint8_t* skip,
+                                   double* partial, double* conv_out, double* var_out, hipStream_t st) {
+    using S = typename Rows3<NX>::S;
+    constexpr size_t lds = rows3_lds_bytes<S>();
+    if constexpr (lds > 64 * 1024) {
+        static thread_local int attr_device = -1;
+        if (attr_device != c->device) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows3_inv<NX, MULTI>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_device = c->device;
+        }
+    }
+    hipLaunchKernelGGL((k_rows3_inv<NX, MULTI>), dim3((c->ny + kRows3Waves - 1) / kRows3Waves, n), dim3(kRows3Threads), lds,
+                       st, Tbuf, skip, c->d_twx, c->d_field, partial, c->ny, prep, c->plen, conv_out, var_out,
+                       c->n_fields > 1 ? c->n_psf_field : 0, (unsigned)c->field_len);
+    return PSFMC_OK;
+}
+template <int NX>
+static int launch_rows3_inv(psfmc_ctx* c, int n, const cd* Tbuf, const double* prep, const uint8_t* skip,
+                            double* partial, double* conv_out, double* var_out, hipStream_t st) {
+    if constexpr (!rows3_side<NX>()) {
+        return fail(PSFMC_EINVAL, "side %d has no three-stage row kernels", NX);
+    } else {
+        if (c->n_fields > 1) return launch_rows3_inv_kernel<NX, true>(c, n, Tbuf, prep, skip, partial, conv_out, var_out, st);
+        return launch_rows3_inv_kernel<NX, false>(c, n, Tbuf, prep, skip, partial, conv_out, var_out, st);
+    }
+}
 
 template <int NX, bool FROM_IMAGE, typename TS, bool FAST, bool WRAP>
 static int launch_rows_fwd_kernel(psfmc_ctx* c, int n, const double* prep, const uint8_t* skip, TS* Tbuf,
@@ -432,6 +514,8 @@ static int launch_rows_fwd_kernel(psfmc_ctx* c, int n, const double* prep, const
         }
     }
     constexpr int waves = row_waves<NX, FAST>();
+    if (!FROM_IMAGE && !c->prep_tabs_valid)
+        return fail(PSFMC_EINVAL, "internal: forward rows launched on prep records without a power-table decision");
     hipLaunchKernelGGL((k_rows_fwd<NX, FROM_IMAGE, TS, FAST, WRAP>), dim3((c->nblk + waves - 1) / waves, n),
                        dim3((row_threads<NX, FAST>())), lds, st, prep, skip, c->d_twx, Tbuf, c->n_ps, c->n_sersic,
                        c->ny, ps_only, img, img_scale, raw_out, c->wrap,
@@ -463,8 +547,15 @@ static int launch_rows_fwd(psfmc_ctx* c, int n, const double* prep, const uint8_
                            hipStream_t st) {
     if constexpr (!storage_built<NX, TS>()) {
         return fail(PSFMC_EINVAL, "single-precision storage is built for power-of-two sides only");
+    } else if constexpr (!two_stage_side(NX)) {
+        return launch_rows3_fwd<NX, FROM_IMAGE>(c, n, prep, skip, static_cast<cd*>(Tvoid), ps_only, img, img_scale, raw_out, st);
     } else {
         TS* Tbuf = static_cast<TS*>(Tvoid);
+        if constexpr (sizeof(TS) == sizeof(cd)) {
+            if (c->rows3)
+                return launch_rows3_fwd<NX, FROM_IMAGE>(c, n, prep, skip, static_cast<cd*>(Tvoid), ps_only, img, img_scale,
+                                                        raw_out, st);
+        }
         if constexpr (FftShape<NX>::kPlain) {
             if (c->row_fast)
                 return launch_rows_fwd_impl<NX, FROM_IMAGE, TS, true>(c, n, prep, skip, Tbuf, ps_only, img,
@@ -515,6 +606,10 @@ static int launch_cols(psfmc_ctx* c, void* Tvoid, int n_w, const double* prep, c
             return PSFMC_OK;
         }
     }
+    if constexpr (!two_stage_side(NY)) {
+        return fail(PSFMC_EINVAL, "side %d has only the three-stage column kernel (option cols3 = 0 and row groups "
+                    "other than 4 do not apply)", NY);
+    } else {
     constexpr size_t lds = fused_col_lds_bytes<NY>();
     static thread_local int attr_device = -1;          // raise the dynamic-LDS limit once per device
     if (attr_device != c->device) {
@@ -527,7 +622,19 @@ static int launch_cols(psfmc_ctx* c, void* Tvoid, int n_w, const double* prep, c
     hipLaunchKernelGGL((k_cols<NY, CONVOLVE, TS>), dim3(grid), dim3(kColThreads), lds, st, Tbuf, c->d_Kt,
                        prep, skip, c->d_twy, c->plen, c->nxh, n_w, c->rg_log2);
     return PSFMC_OK;
+    }
   }
+}
+
+// which column kernel launch_cols takes for this context: 0 k_cols, 1 k_cols3, 2 k_cols3g (the same conditions)
+template <int NY> static int col_engine_code(const psfmc_ctx* c) {
+    if constexpr (NY == 512 || NY == 1024) {
+        if (c->cols3 == 1 || (c->cols3 && c->t_f32)) return 1;
+    }
+    if constexpr (cols3g_side<NY>()) {
+        if (!c->t_f32 && c->cols3 && cols3g_layout_ok<Fft3gShape<NY>>(c->rg_log2)) return 2;
+    }
+    return 0;
 }
 
 template <int NX, typename TS, bool FAST, bool MULTI>
@@ -567,8 +674,14 @@ static int launch_rows_inv(psfmc_ctx* c, int n, const void* Tvoid, const double*
                            double* partial, double* conv_out, double* var_out, hipStream_t st) {
     if constexpr (!storage_built<NX, TS>()) {
         return fail(PSFMC_EINVAL, "single-precision storage is built for power-of-two sides only");
+    } else if constexpr (!two_stage_side(NX)) {
+        return launch_rows3_inv<NX>(c, n, static_cast<const cd*>(Tvoid), prep, skip, partial, conv_out, var_out, st);
     } else {
         const TS* Tbuf = static_cast<const TS*>(Tvoid);
+        if constexpr (sizeof(TS) == sizeof(cd)) {
+            if (c->rows3)
+                return launch_rows3_inv<NX>(c, n, static_cast<const cd*>(Tvoid), prep, skip, partial, conv_out, var_out, st);
+        }
         if constexpr (FftShape<NX>::kPlain) {
             if (c->row_fast)
                 return launch_rows_inv_impl<NX, TS, true>(c, n, Tbuf, prep, skip, partial, conv_out, var_out, st);
@@ -583,15 +696,45 @@ static int launch_rows_inv(psfmc_ctx* c, int n, const void* Tvoid, const double*
 
 template <int NX> static int pack_field(psfmc_ctx* c, int f) {
     const size_t px = (size_t)f * c->S;
-    hipLaunchKernelGGL((k_pack_field<NX>), dim3(256), dim3(256), 0, c->stream, c->d_sci + px, c->d_var + px,
-                       c->d_bad + px, c->d_field + (size_t)f * c->field_len, c->ny);
-    return PSFMC_OK;
+    if constexpr (rows3_side<NX>()) {
+        if (c->rows3) {
+            hipLaunchKernelGGL((k_pack_field3<NX>), dim3(256), dim3(256), 0, c->stream, c->d_sci + px, c->d_var + px,
+                               c->d_bad + px, c->d_field + (size_t)f * c->field_len, c->ny);
+            return PSFMC_OK;
+        }
+    }
+    if constexpr (two_stage_side(NX)) {
+        hipLaunchKernelGGL((k_pack_field<NX>), dim3(256), dim3(256), 0, c->stream, c->d_sci + px, c->d_var + px,
+                           c->d_bad + px, c->d_field + (size_t)f * c->field_len, c->ny);
+        return PSFMC_OK;
+    } else {
+        return fail(PSFMC_EINVAL, "side %d needs the three-stage row kernels", NX);
+    }
 }
+// per-side constants of the row kernels the context will launch (rows3: the three-stage family)
+template <int NX> static RowShape row_shape_of(bool rows3) {
+    if constexpr (rows3_side<NX>()) {
+        if (rows3 || !two_stage_side(NX)) return RowShape{1, kRows3Waves, kRows3RgLog2, Rows3<NX>::S::R1, false};
+    }
+    if constexpr (two_stage_side(NX))
+        return RowShape{row_group<NX>(), row_waves<NX, true>(), layout_rg_log2<NX, true>(), FftShape<NX>::R,
+                        FftShape<NX>::kPlain};
+    else
+        return RowShape{1, kRows3Waves, kRows3RgLog2, 0, false};
+}
+template <int NX> static size_t field_len_of(int ny, bool rows3) {
+    if constexpr (rows3_side<NX>()) {
+        if (rows3 || !two_stage_side(NX)) return rows3_field_len<NX>(ny);
+    }
+    if constexpr (two_stage_side(NX)) return fused_field_len<NX>(ny);
+    else return 0;
+}
+template <int NX> constexpr bool has_rows3() { return rows3_side<NX>(); }
 
 template <int NX>
 static int launch_raster_sums(psfmc_ctx* c, int n, const double* prep, int groups, int group_size, hipStream_t st,
                               int per_field, int f0) {
-    constexpr int RG = FftShape<NX>::TPW;
+    constexpr int RG = RasterShape<NX>::TPW;
     if (c->embed) {
         hipLaunchKernelGGL((k_raster_sums<NX, true>), dim3((c->ny + RG - 1) / RG, groups), dim3(64), 0, st, prep,
                            c->plen, n, group_size, c->n_ps, c->n_sersic, c->ny, c->n_psf, c->d_linpart, per_field,
@@ -608,7 +751,7 @@ static int launch_raster_sums(psfmc_ctx* c, int n, const double* prep, int group
 // ---------------------------------------------------------------------------
 // size-erased entry to the per-side launchers: what crosses the boundary between the parts
 // ---------------------------------------------------------------------------
-enum SizeOp { SZ_ROW_SHAPE, SZ_FIELD_LEN, SZ_PACK_FIELD, SZ_ROWS_FWD, SZ_COLS, SZ_ROWS_INV, SZ_RASTER_SUMS };
+enum SizeOp { SZ_ROW_SHAPE, SZ_FIELD_LEN, SZ_PACK_FIELD, SZ_ROWS_FWD, SZ_COLS, SZ_ROWS_INV, SZ_RASTER_SUMS, SZ_COL_ENGINE };
 struct SizeCall {
     psfmc_ctx* c = nullptr;
     int n = 0;                              // walkers
@@ -619,21 +762,22 @@ struct SizeCall {
     const double *img = nullptr, *img_scale = nullptr;
     double *raw_out = nullptr, *partial = nullptr, *conv_out = nullptr, *var_out = nullptr;
     hipStream_t st = nullptr;
-    bool from_image = false, convolve = true, f32 = false;
+    bool from_image = false, convolve = true, f32 = false, rows3 = false;
     int field = 0, groups = 0, group_size = 0, ny = 0, per_field = 0;
     RowShape* shape = nullptr;
     size_t* len = nullptr;
+    int* code = nullptr;
 };
 
 static int size_call_here(int op, int side, SizeCall& a) {
     psfmc_ctx* c = a.c;
     switch (op) {
         case SZ_ROW_SHAPE:
-            DISPATCH_LEN(side, (*a.shape = RowShape{row_group<N_>(), row_waves<N_, true>(), layout_rg_log2<N_, true>(),
-                                                    FftShape<N_>::R, FftShape<N_>::kPlain}));
+            // (a.rows3: the caller asks for the three-stage row family where the side has both; a.code: whether it has it)
+            DISPATCH_LEN(side, (*a.shape = row_shape_of<N_>(a.rows3), *a.code = has_rows3<N_>() ? (two_stage_side(N_) ? 1 : 2) : 0));
             return PSFMC_OK;
         case SZ_FIELD_LEN:
-            DISPATCH_LEN(side, *a.len = fused_field_len<N_>(a.ny));
+            DISPATCH_LEN(side, *a.len = field_len_of<N_>(a.ny, a.rows3));
             return PSFMC_OK;
         case SZ_PACK_FIELD:
             DISPATCH_LEN(side, RC_TRY(pack_field<N_>(c, a.field)));
@@ -672,6 +816,9 @@ static int size_call_here(int op, int side, SizeCall& a) {
             DISPATCH_LEN(side, RC_TRY((launch_raster_sums<N_>(c, a.n, a.prep, a.groups, a.group_size, a.st,
                                                               a.per_field, a.field))));
             return PSFMC_OK;
+        case SZ_COL_ENGINE:
+            DISPATCH_LEN(side, *a.code = col_engine_code<N_>(c));
+            return PSFMC_OK;
     }
     return fail(PSFMC_EINVAL, "unknown size operation %d", op);
 }
@@ -701,10 +848,17 @@ static int size_call(int op, int side, SizeCall& a) {
 #endif
 }
 
-static int row_shape_for(int nx, RowShape* out) {
+// rows3_wanted: take the three-stage row family where the side has both; *family: 0 the side has only the
+// two-stage kernels, 1 both, 2 only the three-stage ones
+static int row_shape_for(int nx, RowShape* out, bool rows3_wanted = false, int* family = nullptr) {
     SizeCall a;
+    int code = 0;
     a.shape = out;
-    return size_call(SZ_ROW_SHAPE, nx, a);
+    a.rows3 = rows3_wanted;
+    a.code = &code;
+    const int rc = size_call(SZ_ROW_SHAPE, nx, a);
+    if (family) *family = code;
+    return rc;
 }
 
 static int flush_linear_sums(psfmc_ctx* c);   // posterior-image sums: see psfmc_reset_accumulated
@@ -771,12 +925,13 @@ static int alloc_work(psfmc_ctx* c) {
 static int fused_pass_walkers(const psfmc_ctx* c) {
     const double per_walker = 2.0 * c->nxh * c->nyp * (c->t_f32 ? 8.0 : 16.0);
     const int fit = (int)(112.0 * 1048576.0 / per_walker);
-    int chunk = fit >= 64 ? ((fit + 4) & ~7) : fit >= 16 ? (fit & ~7) : (fit & ~1);
-    return chunk < 4 ? 4 : chunk;
+    int chunk = fit >= 64 ? ((fit + 4) & ~7) : fit >= 16 ? (fit & ~7) : fit >= 4 ? (fit & ~1) : fit;
+    // (sides above 1024: 2 walkers per pass at 1536^2, ONE at 2048^2 -- 67 MB of T each, two passes in flight)
+    return chunk < 1 ? 1 : chunk;
 }
 
 static bool fused_side(int n) {
-    static const int sides[] = {64,84,88,96,98,100,104,110,112,120,126,128,130,132,140,144,150,156,160,168,176,180,192,196,200,208,210,220,224,240,250,252,256,260,264,280,286,288,294,300,308,312,320,330,336,350,352,360,364,384,390,392,400,416,420,440,448,480,484,500,504,512,520,528,560,572,576,600,616,624,630,640,650,660,672,676,700,704,720,728,768,780,784,800,832,840,896,900,960,1024};
+    static const int sides[] = {64,84,88,96,98,100,104,110,112,120,126,128,130,132,140,144,150,156,160,168,176,180,192,196,200,208,210,220,224,240,250,252,256,260,264,280,286,288,294,300,308,312,320,330,336,350,352,360,364,384,390,392,400,416,420,440,448,480,484,500,504,512,520,528,560,572,576,600,616,624,630,640,650,660,672,676,700,704,720,728,768,780,784,800,832,840,896,900,960,1024,1152,1280,1536,2048};
     for (int v : sides)
         if (v == n) return true;
     return false;
@@ -952,7 +1107,7 @@ static int ctx_init(psfmc_ctx* c, const double* sci, const double* obs_var, cons
         size_t field_len = 0;
         {
             SizeCall a;
-            a.len = &field_len; a.ny = c->ny;
+            a.len = &field_len; a.ny = c->ny; a.rows3 = c->rows3;
             RC_TRY(size_call(SZ_FIELD_LEN, c->nx, a));
         }
         c->field_len = field_len;
@@ -994,7 +1149,7 @@ static int ctx_init(psfmc_ctx* c, const double* sci, const double* obs_var, cons
 }
 
 // the built sides in ascending order
-static const int kFusedSides[] = {64,84,88,96,98,100,104,110,112,120,126,128,130,132,140,144,150,156,160,168,176,180,192,196,200,208,210,220,224,240,250,252,256,260,264,280,286,288,294,300,308,312,320,330,336,350,352,360,364,384,390,392,400,416,420,440,448,480,484,500,504,512,520,528,560,572,576,600,616,624,630,640,650,660,672,676,700,704,720,728,768,780,784,800,832,840,896,900,960,1024};
+static const int kFusedSides[] = {64,84,88,96,98,100,104,110,112,120,126,128,130,132,140,144,150,156,160,168,176,180,192,196,200,208,210,220,224,240,250,252,256,260,264,280,286,288,294,300,308,312,320,330,336,350,352,360,364,384,390,392,400,416,420,440,448,480,484,500,504,512,520,528,560,572,576,600,616,624,630,640,650,660,672,676,700,704,720,728,768,780,784,800,832,840,896,900,960,1024,1152,1280,1536,2048};
 
 // One axis of an image whose side `l` the transforms are not built for: the smallest built side
 // m >= l + pk - 1 (pk the PSF's side on that axis), the margin a in front of the image and the extent e of
@@ -1066,6 +1221,7 @@ static int ctx_create_impl(psfmc_ctx** out, int device, int ny, int nx, int n_fi
     if (backend != PSFMC_BACKEND_HIPFFT && backend != PSFMC_BACKEND_FUSED)
         return fail(PSFMC_EINVAL, "unknown backend %d", backend);
     int row_tiles = 0;
+    bool rows3 = false;
     RowShape rs{};
     const int ly = ny, lx = nx;                       // the image's own sides
     WrapDesc wrap{0, 0, 0, 0, 0, 0};
@@ -1079,7 +1235,7 @@ static int ctx_create_impl(psfmc_ctx** out, int device, int ny, int nx, int n_fi
             wrap = WrapDesc{lx, 0, lx, ly, 0, ly};
             if (!choose_embedding(ly, lx, psf_ny, psf_nx, &ny, &nx))
                 return fail(PSFMC_EINVAL, "fused backend: image %d x %d + PSF %d x %d - 1 exceeds the largest built "
-                            "side (1024)", ly, lx, psf_ny, psf_nx);
+                            "side (2048)", ly, lx, psf_ny, psf_nx);
             if (nx != lx) embed_axis_at(lx, psf_nx, nx, &wrap.ax, &wrap.ex);
             if (ny != ly) embed_axis_at(ly, psf_ny, ny, &wrap.ay, &wrap.ey);
             // the field arrays in transform coordinates: the image at (ay, ax), every other pixel excluded
@@ -1097,7 +1253,10 @@ static int ctx_create_impl(psfmc_ctx** out, int device, int ny, int nx, int n_fi
                 }
             sci = pad_sci.data(); obs_var = pad_var.data(); bad_px = pad_bad.data();
         }
-        RC_TRY(row_shape_for(nx, &rs));
+        const char* want3 = getenv("PSFMC_ROWS3");
+        int family = 0;
+        RC_TRY(row_shape_for(nx, &rs, want3 && atoi(want3) != 0, &family));
+        rows3 = family == 2 || (family == 1 && want3 && atoi(want3) != 0);
         row_tiles = (ny + rs.rg - 1) / rs.rg;
     }
 
@@ -1126,14 +1285,15 @@ static int ctx_create_impl(psfmc_ctx** out, int device, int ny, int nx, int n_fi
     c->nyp = ny;
     if (backend == PSFMC_BACKEND_FUSED) {
         c->nblk = row_tiles;
+        c->rows3 = rows3;
         // the power-of-two row kernels run without row guards: whole workgroups of rows only;
         // any other ny takes the guarded code path of the same shape (layout groups of 4 rows)
-        c->row_fast = rs.plain && ny % (rs.rg * rs.fast_waves) == 0;
+        c->row_fast = !rows3 && rs.plain && ny % (rs.rg * rs.fast_waves) == 0;
         c->rg_log2 = c->row_fast ? rs.fast_rg_log2 : 2;
         c->nyp = t_col_len(ny, c->rg_log2);
         RowShape cs{};
         RC_TRY(row_shape_for(ny, &cs));
-        c->plain_shape = rs.plain && cs.plain;
+        c->plain_shape = !rows3 && rs.plain && cs.plain;
         c->cols_grid = prop.multiProcessorCount * 2;
         c->chunk = fused_pass_walkers(c);
         // measured (gpurun_out/stag*_quick.txt, same-box A/B): 64^2 +2.7 %, 128^2 +1.7 %, 256^2 +4.6 %
@@ -1311,6 +1471,14 @@ extern "C" double psfmc_get_option(const psfmc_ctx* cc, const char* key) {
         if (!strcmp(key, name)) { prof_collect(c); return (double)c->prof_n[i]; }
     }
     if (!strcmp(key, "row_group")) return 1 << c->rg_log2;
+    if (!strcmp(key, "rows3")) return c->rows3 ? 1.0 : 0.0;
+    if (!strcmp(key, "column_engine")) {       // the column kernel this context launches NOW: 0 k_cols, 1 k_cols3, 2 k_cols3g
+        if (c->backend != PSFMC_BACKEND_FUSED) return NAN;
+        int code = 0;
+        SizeCall a;
+        a.c = c; a.code = &code;
+        return size_call(SZ_COL_ENGINE, c->ny, a) == PSFMC_OK ? (double)code : NAN;
+    }
     if (!strcmp(key, "speculate")) return c->speculate;
     if (!strcmp(key, "pow_tabs")) return c->use_pow_tabs ? 1.0 : 0.0;
     if (!strcmp(key, "speculated_runs")) return (double)c->speculated_runs;
@@ -1451,6 +1619,7 @@ constexpr int kInWavePowTabWaves = 8192;
 // walkers [w_off, w_off + n) of c->d_prep; after the kernel that wrote their records, same stream.
 // (Only the forward row kernels read the tables: k_raster_sums keeps the log2 + exp2 form at every size.)
 static void launch_pow_tables(psfmc_ctx* c, int n, int w_off, const uint8_t* skip, hipStream_t st) {
+    c->prep_tabs_valid = true;
     if (c->backend != PSFMC_BACKEND_FUSED || c->n_sersic == 0 || n <= 0 || !c->use_pow_tabs) return;
     const int pairs = n * c->n_sersic;
     const bool build = (long long)pairs * c->nblk > kInWavePowTabWaves;
@@ -1461,10 +1630,13 @@ static void launch_pow_tables(psfmc_ctx* c, int n, int w_off, const uint8_t* ski
                        skip, pairs, c->n_ps, c->n_sersic);
 }
 
+// field < 0: the rows' PSF index counts over every kernel spectrum of the context; field >= 0: within that field
 static int eval_device(psfmc_ctx* c, int W, const double* d_rows, const uint8_t* d_skip,
-                       double* d_like, hipStream_t st) {
+                       double* d_like, hipStream_t st, int field = -1) {
+    c->prep_tabs_valid = false;                       // d_prep is being rewritten
     hipLaunchKernelGGL(k_prep, dim3((W + 127) / 128), dim3(128), 0, st, d_rows, c->d_prep, W, c->n_ps,
-                       c->n_sersic, c->ly, c->lx, c->d_rho, c->n_psf, 0);
+                       c->n_sersic, c->ly, c->lx, c->d_rho, field < 0 ? c->n_psf : c->n_psf_field,
+                       field < 0 ? 0 : field * c->n_psf_field);
     launch_pow_tables(c, W, 0, d_skip, st);
     RC_TRY(run_pipeline(c, W, d_skip, st));
     hipLaunchKernelGGL(k_finish, dim3(finish_blocks(W)), dim3(kFinishThreads), 0, st, c->d_partial, d_skip, d_like,
@@ -1485,6 +1657,7 @@ static void launch_theta_prep(psfmc_ctx* c, int W, const double* d_theta, const 
     const ThetaLayout& L = field == 0 ? c->layout : c->more_layouts[field - 1];
     FieldSegs segs{nullptr, 0};
     if (n_seg > 1) segs = FieldSegs{c->d_field_layouts + field, c->n_psf_field};
+    if (w_off == 0) c->prep_tabs_valid = false;       // d_prep is being rewritten (w_off > 0: a further piece of one batch)
     hipLaunchKernelGGL(k_theta_prep, dim3((W + kThetaThreads - 1) / kThetaThreads, n_seg),
                        dim3(kThetaThreads, theta_task_waves(c->n_ps, c->n_sersic)), c->theta_lds, st,
                        L, d_theta, d_extra, d_rows, c->d_prep + (size_t)w_off * c->plen, c->d_lnprior + w_off,
@@ -1519,15 +1692,29 @@ extern "C" int psfmc_eval_batch_device(psfmc_ctx* c, int W, const double* d_rows
     return eval_device(c, W, d_rows, d_skip, d_like, stream ? (hipStream_t)stream : c->stream);
 }
 
+static int eval_batch_impl(psfmc_ctx* c, int field, int W, const double* rows, const uint8_t* skip, double* loglike);
+
 extern "C" int psfmc_eval_batch(psfmc_ctx* c, int W, const double* rows, const uint8_t* skip,
                                 double* loglike) {
+    return eval_batch_impl(c, -1, W, rows, skip, loglike);
+}
+
+// the log-likelihoods of derived rows of ONE field of a psfmc_ctx_create_fields context (the rows' PSF index
+// counts within the field, as for psfmc_eval_images_field)
+extern "C" int psfmc_eval_batch_field(psfmc_ctx* c, int field, int W, const double* rows, const uint8_t* skip,
+                                      double* loglike) {
+    if (c && (field < 0 || field >= c->n_fields)) return fail(PSFMC_EINVAL, "field %d of %d", field, c->n_fields);
+    return eval_batch_impl(c, field, W, rows, skip, loglike);
+}
+
+static int eval_batch_impl(psfmc_ctx* c, int field, int W, const double* rows, const uint8_t* skip, double* loglike) {
     int rc = check_call(c, W, rows, loglike);
     if (rc != PSFMC_OK || W == 0) return rc;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     HIP_TRY(hipMemcpyAsync(c->d_rows, rows, (size_t)W * c->rlen * sizeof(double), hipMemcpyHostToDevice, st));
     if (skip) HIP_TRY(hipMemcpyAsync(c->d_skip, skip, (size_t)W, hipMemcpyHostToDevice, st));
-    rc = eval_device(c, W, c->d_rows, skip ? c->d_skip : nullptr, c->d_like, st);
+    rc = eval_device(c, W, c->d_rows, skip ? c->d_skip : nullptr, c->d_like, st, field);
     if (rc != PSFMC_OK) return rc;
     HIP_TRY(hipMemcpyAsync(loglike, c->d_like, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -1562,6 +1749,7 @@ static int eval_images_impl(psfmc_ctx* c, int field, int W, const double* rows, 
     const size_t S_img = (size_t)c->ly * c->lx;                 // pixels of a host image
     const size_t img = S_img * sizeof(double);
     HIP_TRY(hipMemcpyAsync(c->d_rows, rows, (size_t)W * c->rlen * sizeof(double), hipMemcpyHostToDevice, st));
+    c->prep_tabs_valid = false;                       // d_prep is being rewritten
     hipLaunchKernelGGL(k_prep, dim3((W + 127) / 128), dim3(128), 0, st, c->d_rows, c->d_prep, W, c->n_ps,
                        c->n_sersic, c->ly, c->lx, c->d_rho, c->n_psf_field, field * c->n_psf_field);
     launch_pow_tables(c, W, 0, nullptr, st);
@@ -1597,8 +1785,8 @@ static int eval_images_impl(psfmc_ctx* c, int field, int W, const double* rows, 
         };
         if (raw && !fused) {   // raw model before the inverse transform overwrites it
             hipLaunchKernelGGL(k_raster, dim3((c->S + 1023) / 1024, n), dim3(256),
-                               (size_t)c->plen * sizeof(double), st, prep, (const uint8_t*)nullptr,
-                               c->d_real, c->n_ps, c->n_sersic, c->ny, c->nx, 0);
+                               (size_t)prep_rec_len(c->n_ps, c->n_sersic) * sizeof(double), st, prep,
+                               (const uint8_t*)nullptr, c->d_real, c->n_ps, c->n_sersic, c->ny, c->nx, 0);
             rc = emit(raw, c->d_real, 2, 0, IMG_COPY);
             if (rc != PSFMC_OK) break;
         }
@@ -2082,8 +2270,8 @@ static int accumulate_from_prep(psfmc_ctx* c, int W, hipStream_t st, int f0 = 0,
             acc(c->d_rawstage, 1, 0, 0, n);
         } else {
             hipLaunchKernelGGL(k_raster, dim3((c->S + 1023) / 1024, n), dim3(256),
-                               (size_t)c->plen * sizeof(double), st, prep, (const uint8_t*)nullptr,
-                               c->d_real, c->n_ps, c->n_sersic, c->ny, c->nx, 0);
+                               (size_t)prep_rec_len(c->n_ps, c->n_sersic) * sizeof(double), st, prep,
+                               (const uint8_t*)nullptr, c->d_real, c->n_ps, c->n_sersic, c->ny, c->nx, 0);
             acc(c->d_real, 2, 0, 0, n);
             RC_TRY(hipfft_convolve(c, n, prep, nullptr, st, 0));
         }
@@ -2110,6 +2298,7 @@ extern "C" int psfmc_accumulate_images(psfmc_ctx* c, int W, const double* rows) 
     RC_TRY(ensure_linear_sums(c));
     hipStream_t st = c->stream;
     HIP_TRY(hipMemcpyAsync(c->d_rows, rows, (size_t)W * c->rlen * sizeof(double), hipMemcpyHostToDevice, st));
+    c->prep_tabs_valid = false;                       // d_prep is being rewritten
     hipLaunchKernelGGL(k_prep, dim3((W + 127) / 128), dim3(128), 0, st, c->d_rows, c->d_prep, W, c->n_ps,
                        c->n_sersic, c->ly, c->lx, c->d_rho, c->n_psf, 0);
     launch_pow_tables(c, W, 0, nullptr, st);

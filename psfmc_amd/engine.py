@@ -20,7 +20,9 @@ FUSED_SIDES = (64, 84, 88, 96, 98, 100, 104, 110, 112, 120, 126, 128, 130, 132, 
                280, 286, 288, 294, 300, 308, 312, 320, 330, 336, 350, 352, 360, 364, 384, 390, 392,
                400, 416, 420, 440, 448, 480, 484, 500, 504, 512, 520, 528, 560, 572, 576, 600, 616,
                624, 630, 640, 650, 660, 672, 676, 700, 704, 720, 728, 768, 780, 784, 800, 832, 840,
-               896, 900, 960, 1024)
+               896, 900, 960, 1024,
+               # round 4: sides above 1024 (three-stage row AND column kernels only: R1 x 8 x 8, R1 = 18 ... 32)
+               1152, 1280, 1536, 2048)
 
 
 def nearest_fused_sides(n):
@@ -39,7 +41,7 @@ for _sides, _shape in (((264, 308, 352, 484), (4, 11)), ((384, 528, 576), (4, 12
                        ((392, 504, 560, 616, 672, 728, 784, 840, 896), (4, 14)), ((480, 900), (4, 15)),
                        ((448,), (4, 16)), ((330, 440), (5, 11)), ((250, 500), (5, 10)), ((294,), (7, 7)),
                        ((600, 660, 720), (5, 12)),
-                       ((640, 704, 768, 832, 960), (8, 8))):
+                       ((640, 704, 768, 832, 960, 1152, 1280, 1536, 2048), (8, 8))):
     for _n in _sides:
         _COLS3G_SHAPES[_n] = _shape
 
@@ -61,7 +63,7 @@ def embedding_side(side, psf_side):
     """The smallest transform side an image side the kernels are not built for can be EMBEDDED in: the
     smallest built side >= side + psf_side - 1 (the image, a wrap-around margin of psf_side - 1 pixels,
     zeros: the circular convolution of that length equals the image's own on the image's pixels --
-    csrc/psfmc_device.h WrapDesc), or None when there is none (side + psf_side - 1 > 1024).  The library
+    csrc/psfmc_device.h WrapDesc), or None when there is none (side + psf_side - 1 > 2048).  The library
     may pick a LARGER built side whose kernels are cheaper per walker (psfmc_hip.hip choose_embedding,
     measured table csrc/psfmc_side_costs.h); `Context.get_option('transform_ny' / 'transform_nx')` tells."""
     need = side + psf_side - 1
@@ -140,6 +142,8 @@ def load_library():
     lib.psfmc_pass_size.argtypes = [vp, ci]
     lib.psfmc_eval_batch.restype = ci
     lib.psfmc_eval_batch.argtypes = [vp, ci, _c_double_p, _c_u8_p, _c_double_p]
+    lib.psfmc_eval_batch_field.restype = ci
+    lib.psfmc_eval_batch_field.argtypes = [vp, ci, ci, _c_double_p, _c_u8_p, _c_double_p]
     lib.psfmc_eval_batch_device.restype = ci
     lib.psfmc_eval_batch_device.argtypes = [vp, ci, vp, vp, vp, vp]
     lib.psfmc_eval_images.restype = ci
@@ -748,6 +752,21 @@ class FieldSetContext(object):
         """The part of `Context`'s interface a `MultiComponentModel` uses, for ONE field of this context."""
         return FieldView(self, field)
 
+    def loglike(self, field, rows, skip=None):
+        """[W] log-likelihoods of derived rows of one field (`Context.loglike` for a field of this context)."""
+        rows = _f64(rows)
+        n_w = rows.shape[0]
+        if n_w > self.max_walkers:
+            raise ValueError('W={} exceeds max_walkers={}'.format(n_w, self.max_walkers))
+        out = np.empty(n_w, dtype=np.float64)
+        skip_p = None
+        if skip is not None:
+            skip = np.ascontiguousarray(np.asarray(skip).astype(bool), dtype=np.uint8)
+            skip_p = skip.ctypes.data_as(_c_u8_p)
+        if n_w:
+            self._check(self._lib.psfmc_eval_batch_field(self._ctx, int(field), n_w, _dp(rows), skip_p, _dp(out)))
+        return out
+
     def images(self, field, rows, kinds=None):
         """dict kind -> [W, ny, nx] of the requested per-sample images for derived rows of one field."""
         rows = _f64(rows)
@@ -795,6 +814,23 @@ class FieldView(object):
 
     def images(self, rows, kinds=None):
         return self.owner.images(self.field, rows, kinds)
+
+    def loglike(self, rows, skip=None):
+        return self.owner.loglike(self.field, rows, skip)
+
+    def __getattr__(self, name):
+        # the rest of Context's interface (device-resident sampler, raw-sum exchange, device pointers, ...) has
+        # no per-field form on a shared context: say so instead of an AttributeError deep inside a caller
+        if callable(getattr(Context, name, None)):
+            field = self.__dict__.get('field')
+
+            def _unsupported(*args, **kwargs):
+                raise NotImplementedError(
+                    "'{}' is not available for field {} of a FieldSet (its context is shared by the set's "
+                    "fields): use FieldSet / FieldSetSampler / fitting.model_fields_mcmc, or a "
+                    "MultiComponentModel with a context of its own".format(name, field))
+            return _unsupported
+        raise AttributeError(name)
 
     def accumulate_theta(self, theta):
         self.owner.accumulate_theta(self.field, theta)

@@ -191,9 +191,21 @@ def model_fields_mcmc(model_files, output_names=None, write_fits=default_filetyp
             first = MultiComponentModel(model_files[0], device=device, backend='fused', max_walkers=1)
             model_files = [first] + list(model_files[1:])
         chains = 2 * first.num_params + 2
-    chains += chains % 2
+    if chains < 2 or chains % 2:
+        raise ValueError('chains must be an even number >= 2 (got {}): the stretch move updates the ensemble in '
+                         'two halves'.format(chains))
+    if random_states is not None and len(random_states) != n_f:
+        raise ValueError('random_states: one per field ({} given for {} fields)'.format(len(random_states), n_f))
+    if start_positions is not None and len(start_positions) != n_f:
+        raise ValueError('start_positions: one [chains, P] array per field ({} given for {} fields)'.format(
+            len(start_positions), n_f))
     fieldset = FieldSet(model_files, max_walkers=chains * n_f, device=device)
     models = fieldset.models
+    if start_positions is not None:
+        for f, p in enumerate(start_positions):
+            if np.shape(p) != (chains, fieldset.num_params):
+                raise ValueError('start_positions[{}] must be [{}, {}], got {}'.format(
+                    f, chains, fieldset.num_params, np.shape(p)))
     sampler = FieldSetSampler(chains, fieldset, accumulate=False)
     for f, sub in enumerate(sampler.fields):
         state = None if random_states is None else random_states[f]

@@ -8,6 +8,8 @@ scalars the GPU needs (flux, Sersic b_n, surface brightness at r_e, inverse
 ellipse matrix), NaN -> -inf mapping.  Device side (libpsfmc_hip): everything
 from models.py:213 to :236 for all walkers of a batch at once.
 """
+import copy
+
 import numpy as np
 
 from .ModelComponents import Configuration, PointSource, Sersic, Sky
@@ -478,7 +480,9 @@ class FieldSet(object):
     models: MultiComponentModel objects (or model files) whose priors all have a device form."""
 
     def __init__(self, models, max_walkers=4096, device=0):
-        self.models = [m if isinstance(m, MultiComponentModel) else
+        # a model object handed in stays what it was (its own context, if it has one, included): the set works
+        # on shallow copies that share the components and the data but route through the shared context
+        self.models = [copy.copy(m) if isinstance(m, MultiComponentModel) else
                        MultiComponentModel(m, device=device, backend='fused', max_walkers=1) for m in models]
         first = self.models[0]
         for m in self.models:
@@ -499,9 +503,9 @@ class FieldSet(object):
                                  'GPU only'.format(f))
             # the model's images, posterior sums and log-posteriors go through ITS field of the shared
             # context (it never creates a context of its own)
-            if m._engine is not None:
-                m._engine.close()
             m._engine = self.context.view(f)
+            m.posterior_images = dict(m.posterior_images)      # (a copy's own running means and vector)
+            m._param_vector = m._param_vector.copy()
             m._max_walkers = int(max_walkers)
         self.num_params = first.num_params
         self.max_walkers = int(max_walkers)
@@ -513,5 +517,5 @@ class FieldSet(object):
     def close(self):
         self.context.close()
         for m in self.models:
-            m.close()
+            m._engine = None               # (views of the context just closed)
 

@@ -160,6 +160,31 @@ class ShardedLogPosterior(object):
             self._rg = RankGroup(self._group_arg, self._device_arg, shortcut=self._shortcut)
         return self._rg
 
+    def evaluate_device(self, theta_dev):
+        """The same with the walkers RESIDENT on this rank's GPU: `theta_dev` a contiguous [W, P] float64
+        torch tensor on the model's device (the same vectors on every rank) -> [W] float64 tensor on
+        that device with every rank's block in place.  Nothing crosses the host: the rank evaluates its
+        contiguous block (`psfmc_eval_theta_device`) and the blocks are exchanged by the one all-gather
+        (`RankGroup.all_gather_blocks`).  Needs a `MultiComponentModel` whose priors all have a device
+        form.  The result is ordered on the stream of `RankGroup.on_stream()`: synchronise the device (or
+        that stream) before reading it elsewhere."""
+        if self.model is None:
+            raise ValueError('evaluate_device needs a MultiComponentModel')
+        eng = self.model.engine                                     # creates context + layout
+        if self.model._host_priors:
+            raise ValueError('evaluate_device needs a model whose priors all have a device form')
+        rg = self.ranks
+        torch = rg.torch
+        n_w = int(theta_dev.shape[0])
+        lo, hi = rg.block(n_w)
+        with rg.on_stream():
+            stream = rg.stream_ptr()
+            send = torch.full((max(rg.slot(n_w), 1),), float('nan'), dtype=torch.float64, device=rg.device)
+            for a in range(lo, hi, eng.max_walkers):                # larger blocks go through in slices
+                b = min(a + eng.max_walkers, hi)
+                eng.logpost_theta_device(b - a, theta_dev[a:b].data_ptr(), 0, send[a - lo:].data_ptr(), stream)
+            return rg.all_gather_blocks(send, n_w)
+
     def __call__(self, theta):
         theta = np.ascontiguousarray(theta, dtype=np.float64)
         rg = self.ranks

@@ -305,7 +305,10 @@ class DeviceEnsembleSampler(EnsembleSampler):
         self.accumulate = bool(accumulate)
         if nwalkers > model._max_walkers:
             raise ValueError('model was built for at most {} walkers'.format(model._max_walkers))
-        model.engine                      # context + layout
+        eng = model.engine                # context + layout
+        if not hasattr(type(eng), 'stretch_run'):
+            # (a model of a FieldSet: its context is shared by the set's fields)
+            eng.stretch_run()             # raises NotImplementedError naming the FieldSet
         if model._host_priors:
             raise ValueError('priors {} are evaluated on the host: the device sampler cannot be '
                              'used'.format([p.name for p, _ in model._host_priors]))

@@ -82,9 +82,21 @@ def oracle_field_from_reference(model, sci, ivm, psfs, psf_ivms, mask):
     return fld
 
 
+def field_check(arrays):
+    """What a `light` fixture keeps of its input arrays (the tests regenerate them from the seed and compare):
+    float64 sums and a few pixels of every array."""
+    vals = []
+    for a in [arrays['sci'], arrays['ivm']] + list(arrays['psfs']) + list(arrays['psf_ivms']):
+        a = np.asarray(a, dtype=np.float64)
+        vals += [a.sum(), np.abs(a).sum(), (a * a).sum(), a[0, 0], a[a.shape[0] // 2, a.shape[1] // 3], a[-1, -1]]
+    return np.array(vals)
+
+
 def run_case(name, model_path, vectors, arrays, full_image_rows=(0,),
-             mask=None):
-    """Evaluate every vector with the reference; check the oracle; save."""
+             mask=None, light=False):
+    """Evaluate every vector with the reference; check the oracle; save.
+    light: keep only the vectors and the reference's scalars (the field is regenerated from its seed by
+    tools/synth_field.py on the test side and compared through `field_check`)."""
     model = MultiComponentModel(model_path)
     names = sum([c.stochastic_names() for c in model.components], [])
     fld = oracle_field_from_reference(model, arrays['sci'], arrays['ivm'],
@@ -150,11 +162,13 @@ def run_case(name, model_path, vectors, arrays, full_image_rows=(0,),
                lnprior=lnprior, loglike_f64=loglike, image_sums=sums,
                derived=dmat, param_names=np.array(names),
                mag_zp=np.float64(model.config.mag_zeropoint),
-               sci=arrays['sci'], ivm=arrays['ivm'],
-               psfs=np.asarray(arrays['psfs']),
-               psf_ivms=np.asarray(arrays['psf_ivms']),
                oracle_vs_ref_rel=np.float64(worst),
                oracle64_vs_ref_rel=np.float64(worst64))
+    if light:
+        out['field_check'] = field_check(arrays)
+    else:
+        out.update(sci=arrays['sci'], ivm=arrays['ivm'], psfs=np.asarray(arrays['psfs']),
+                   psf_ivms=np.asarray(arrays['psf_ivms']))
     if mask is not None:
         out['mask'] = mask
     out.update(images)
@@ -205,7 +219,7 @@ def _write_fits(path, arr):
     fits.PrimaryHDU(np.asarray(arr)).writeto(path, overwrite=True)
 
 
-def case_synth(name, n_side, n_sersic, n_prior, n_near, tmp):
+def case_synth(name, n_side, n_sersic, n_prior, n_near, tmp, light=False):
     fld = synth_field.make_field(n_side, n_sersic, seed=0)
     d = os.path.join(tmp, name)
     os.makedirs(d)
@@ -221,9 +235,16 @@ def case_synth(name, n_side, n_sersic, n_prior, n_near, tmp):
         synth_field.draw_walkers(n_side, n_sersic, n_prior, seed=1),
         synth_field.draw_walkers(n_side, n_sersic, n_near, seed=2,
                                  near_truth=fld['truth'])])
+    if light:
+        # (the large configurations: BASELINE configs 3 and 4) one vector with reff_b > reff of the first Sersic
+        # component (Sersic.py:41-45: -inf) and one with the first component's centre on a pixel (0/0 -> NaN -> -inf)
+        extra = np.repeat(fld['truth'][None, :], 2, axis=0)
+        extra[0, 7] = extra[0, 6] + 0.5                  # order per Sersic: angle, index, mag, reff, reff_b, x, y
+        extra[1, 8:10] = np.rint(extra[1, 8:10])
+        vec = np.vstack([vec, extra])
     arrays = dict(sci=fld['sci'], ivm=fld['ivm'], psfs=[fld['psf']],
                   psf_ivms=[fld['psf_ivm']])
-    run_case(name, path, vec, arrays, full_image_rows=())
+    run_case(name, path, vec, arrays, full_image_rows=(), light=light)
 
 
 def case_edge(tmp):
@@ -360,11 +381,23 @@ def case_galfit():
 
 
 def main():
+    # `make_golden.py synth512x2 synth1024x4` regenerates only the named light fixtures
+    only = set(sys.argv[1:]) or None
     tmp = tempfile.mkdtemp(prefix='psfmc_golden_')
     try:
+        if only is not None:
+            if 'synth512x2' in only:
+                case_synth('synth512x2', 512, 2, n_prior=14, n_near=11, tmp=tmp, light=True)
+            if 'synth1024x4' in only:
+                case_synth('synth1024x4', 1024, 4, n_prior=4, n_near=5, tmp=tmp, light=True)
+            return
         case_example()
         case_synth('synth256', 256, 1, n_prior=40, n_near=24, tmp=tmp)
         case_synth('synth128x2', 128, 2, n_prior=24, n_near=8, tmp=tmp)
+        if only is None or 'synth512x2' in only:
+            case_synth('synth512x2', 512, 2, n_prior=14, n_near=11, tmp=tmp, light=True)
+        if only is None or 'synth1024x4' in only:
+            case_synth('synth1024x4', 1024, 4, n_prior=4, n_near=5, tmp=tmp, light=True)
         case_edge(tmp)
         case_galfit()
     finally:

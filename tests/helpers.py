@@ -36,6 +36,35 @@ def load_case(name):
     return dict(np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False))
 
 
+# "light" golden cases (BASELINE configs 3 and 4): the fixture holds the vectors and the REFERENCE's scalars
+# only; the field is regenerated from its seed (tools/synth_field.py, the same code and seed
+# tests/golden/make_golden.py fed the reference with) and compared through the fixture's `field_check`
+LIGHT = {'synth512x2': (512, 2), 'synth1024x4': (1024, 4)}
+
+
+def field_check(arrays):
+    """tests/golden/make_golden.py field_check: float64 sums and a few pixels of every input array."""
+    vals = []
+    for a in [arrays['sci'], arrays['ivm']] + list(arrays['psfs']) + list(arrays['psf_ivms']):
+        a = np.asarray(a, dtype=np.float64)
+        vals += [a.sum(), np.abs(a).sum(), (a * a).sum(), a[0, 0], a[a.shape[0] // 2, a.shape[1] // 3], a[-1, -1]]
+    return np.array(vals)
+
+
+def load_light_case(name):
+    """(case dict with the regenerated arrays filled in, synth field dict)."""
+    n_side, n_sersic = LIGHT[name]
+    case = load_case(name)
+    fld = synth_field.make_field(n_side, n_sersic, seed=0)
+    case.update(sci=fld['sci'], ivm=fld['ivm'], psfs=np.asarray([fld['psf']]), psf_ivms=np.asarray([fld['psf_ivm']]))
+    # the arrays the reference was fed with are float32 FITS images: the regenerated ones must be those, to the bit
+    # (sums of ~1e6 float32 values as float64: differences of one ulp of a pixel would show at 1e-13)
+    got = field_check(case)
+    assert np.allclose(got, case['field_check'], rtol=1e-13, atol=0), 'regenerated field differs from the fixture\'s'
+    LAYOUT.setdefault(name, synth_layout(n_sersic))
+    return case, fld
+
+
 def synth_layout(n_sersic):
     return [('ps', 'lanczos3')] + [('sersic', True)] * n_sersic
 

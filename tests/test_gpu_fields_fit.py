@@ -120,3 +120,46 @@ def test_model_fields_mcmc_writes_each_fields_own_outputs(tmp_path):
         model.close()
     for m, _ in results:
         m.close()
+
+
+def test_field_set_leaves_the_callers_models_alone_and_serves_likelihood_calls():
+    """Round-3 advice: a model object handed to a `FieldSet` keeps its own context and every call it had; the
+    set's own copies answer the likelihood-level calls through their field of the shared context
+    (psfmc_eval_batch_field) and refuse -- by name -- what a shared context cannot do per field."""
+    from psfmc_amd import FieldSet, DeviceEnsembleSampler, engine
+    from psfmc_amd.fitting import model_fields_mcmc
+    n_f, n_w = 3, 64
+    own = _models(n_f, max_walkers=n_w)
+    thetas = [synth_field.draw_walkers(256, 1, n_w, seed=20 + f, near_truth=fld['truth'])
+              for f, (_, fld) in enumerate(own)]
+    thetas[1][:5] = synth_field.draw_walkers(256, 1, 5, seed=3)          # some prior draws, some of them -inf
+    before = [m.log_posterior_batch(t) for (m, _), t in zip(own, thetas)]   # the callers' models own contexts now
+    fs = FieldSet([m for m, _ in own], max_walkers=n_f * n_w)
+    for f, (model, _) in enumerate(own):
+        assert fs.models[f] is not model and isinstance(model._engine, engine.Context)
+        # the caller's model: same results as before, every call still there
+        assert np.array_equal(model.log_posterior_batch(thetas[f]), before[f])
+        ll_own = model.log_likelihood_batch(thetas[f])
+        host_own = model.log_posterior_batch_host(thetas[f])
+        # the set's copy of it: the same numbers through the shared context
+        view = fs.models[f]
+        assert np.array_equal(view.log_posterior_batch(thetas[f]), before[f])
+        assert np.array_equal(view.log_likelihood_batch(thetas[f]), ll_own)
+        assert np.array_equal(view.log_posterior_batch_host(thetas[f]), host_own)
+        with pytest.raises(NotImplementedError, match='FieldSet'):
+            DeviceEnsembleSampler(n_w, view)
+        with pytest.raises(NotImplementedError, match='accumulated_sums'):
+            view.engine.accumulated_sums()
+        solo = DeviceEnsembleSampler(n_w, model, block=2)                 # ... and the caller's still samples
+        for _ in solo.sample(thetas[f], iterations=2):
+            pass
+    with pytest.raises(ValueError, match='even'):
+        model_fields_mcmc([m for m, _ in own], chains=7, iterations=1, quiet=True)
+    with pytest.raises(ValueError, match='one per field'):
+        model_fields_mcmc([m for m, _ in own], chains=8, iterations=1, random_states=[1, 2], quiet=True)
+    with pytest.raises(ValueError, match='start_positions'):
+        model_fields_mcmc([m for m, _ in own], chains=8, iterations=1, quiet=True,
+                          start_positions=[np.zeros((6, 10))] * n_f)
+    fs.close()
+    for model, _ in own:
+        model.close()

@@ -68,30 +68,52 @@ def test_headline_batch_with_golden_vectors_at_every_pass_boundary(tmp_path, n_w
     model.close()
 
 
-@pytest.mark.parametrize('n_side,n_sersic,n_w', [(512, 2, 1024), (1024, 4, 256)])
-def test_config3_and_config4_share_at_full_batch(n_side, n_sersic, n_w):
+@pytest.mark.parametrize('name,n_w', [('synth512x2', 1024), ('synth1024x4', 256)])
+def test_config3_and_config4_share_at_full_batch(tmp_path, name, n_w):
     """BASELINE config 3 (512^2, 1 PS + 2 Sersic, 1024 walkers) and config 4's per-GPU share
-    (1024^2, 1 PS + 4 Sersic, 2048 / 8 = 256 walkers): the whole batch in one call with
-    default options; first / middle / last walker against the oracle, pass-boundary slots
-    bitwise equal to their evaluation in a small batch."""
-    from test_gpu_fullsize import make_model
-    model, fld = make_model(n_side, n_sersic, 'fused', max_walkers=n_w)
+    (1024^2, 1 PS + 4 Sersic, 2048 / 8 = 256 walkers): the whole batch in one call with default
+    options.  Vectors of the `light` golden fixtures (the REFERENCE's own log-posteriors at these sizes,
+    tests/golden/make_golden.py) sit at the first and last slot of every internal pass -- against the
+    reference (<= 1e-6, its float32 raw-model floor) and the fp64 oracle evaluated next to it (<= 1e-9);
+    32 random walkers of the batch against the oracle; pass-boundary slots bitwise equal to their
+    evaluation in a small batch."""
+    n_side, n_sersic = helpers.LIGHT[name]
+    case, fld = helpers.load_light_case(name)
+    # (the model file make_golden.py gave the reference: FITS images + tools/synth_field.py model_file_text)
+    model = helpers.build_model(name, case, tmp_path, backend='fused', max_walkers=n_w)
     eng = model.engine
     size, slots = pass_slots(eng, n_w)
+    assert size < n_w
     half = n_w // 2
     theta = np.vstack([synth_field.draw_walkers(n_side, n_sersic, half, seed=41),
                        synth_field.draw_walkers(n_side, n_sersic, n_w - half, seed=42,
                                                 near_truth=fld['truth'])])
-    theta[slots[-1]] = fld['truth']
+    n_gold = len(case['params'])
+    which = np.arange(len(slots)) % n_gold
+    theta[slots] = case['params'][which]
+    assert len(slots) >= n_gold or name == 'synth512x2'          # (every vector of the fixture is in the batch)
+    spare = [i for i in range(n_gold) if i not in set(which)]
+    free = [i for i in range(1, n_w - 1) if i not in set(slots)][:len(spare)]
+    theta[free] = case['params'][spare]                          # ... the rest of them anywhere inside a pass
     got = model.log_posterior_batch(theta)
-    assert np.isfinite(got).all()
-    field = orc.make_field(fld['sci'], fld['ivm'], [fld['psf']], [fld['psf_ivm']], mag_zp=fld['mag_zp'])
+    assert got.shape == (n_w,) and not np.isnan(got).any()
+    where, gold = np.array(list(slots) + free), np.concatenate([which, np.array(spare, dtype=int)])
+    # (1) the reference's own log-posteriors
+    assert (case['lnprob'][gold] == -np.inf).sum() >= 2
+    assert helpers.rel_err(got[where], case['lnprob'][gold]) <= REF_TOL
+    # (2) the fp64 oracle evaluated next to the reference
+    want = np.where(np.isfinite(case['lnprob'][gold]), case['loglike_f64'][gold] + case['lnprior'][gold], -np.inf)
+    assert helpers.rel_err(got[where], want) <= ORACLE_TOL
+    # (3) 32 random walkers of the batch against the oracle
+    field = helpers.oracle_field(case)
     layout = helpers.synth_layout(n_sersic)
-    sample = [0, n_w // 2 + 1, n_w - 1]
-    prior = model.log_priors_batch(theta[sample])
-    for i, p in zip(sample, prior):
-        want = helpers.oracle_loglike(field, layout, theta[i]) + p
-        assert abs(got[i] - want) <= 1e-10 * abs(want), (i, got[i], want)
+    pick = np.random.RandomState(6).choice(n_w, 32, replace=False)
+    prior = model.log_priors_batch(theta[pick])
+    ref = np.array([helpers.oracle_loglike(field, layout, t) if np.isfinite(p) else -np.inf
+                    for t, p in zip(theta[pick], prior)]) + np.where(np.isfinite(prior), prior, 0.0)
+    ref = np.where(np.isfinite(ref), ref, -np.inf)
+    assert helpers.rel_err(got[pick], ref) <= ORACLE_TOL
+    # (4) position independence, bitwise
     small = model.log_posterior_batch(theta[slots[:16]])
     assert np.array_equal(small, got[slots[:16]])
     assert np.array_equal(model.log_posterior_batch(theta[slots[-3:]]), got[slots[-3:]])

@@ -146,6 +146,10 @@ def general_shapes():
     shapes += list(zip(primes, mates)) + [(128, 286), (64, 676)]
     shapes += [(m, s) for s, m in zip(primes, mates) if (m, s) not in shapes]
     shapes += [(420, 420), (560, 560), (308, 308), (832, 832), (512, 100)]          # squares of the larger seven / prime sides
+    # round 4: sides above 1024 (three-stage row and column kernels only), as the row and as the column length,
+    # against two-stage, three-stage and power-of-two partners, and squares
+    shapes += [(1152, 64), (96, 1152), (1280, 100), (128, 1280), (1536, 480), (250, 1536), (2048, 64), (84, 2048),
+               (1152, 1152), (1280, 1536), (2048, 1152), (1536, 2048)]
     assert all(engine.fused_supports(ny, nx) for ny, nx in shapes)
     # the claim above, enforced: every built side runs as the column length AND as the row length
     assert {ny for ny, _ in shapes} >= set(engine.FUSED_SIDES), sorted(set(engine.FUSED_SIDES) - {ny for ny, _ in shapes})
@@ -154,7 +158,10 @@ def general_shapes():
     assert not engine.fused_supports(170, 170) and not engine.fused_supports(256, 90) and not engine.fused_supports(490, 64)
     # ... but given the PSF's shape it is embedded in the next built side (test_embedded_sides_match_oracle)
     assert engine.fused_supports(170, 170, (33, 33)) and engine.fused_supports(490, 64, (16, 9))
-    assert not engine.fused_supports(1000, 1000, (64, 64)) and not engine.fused_supports(171, 170, (9, 9))
+    assert not engine.fused_supports(171, 170, (9, 9))
+    # every even side up to 2048 - PSF side + 1 runs on the hand-written kernels
+    assert all(engine.fused_supports(n, n, (64, 64)) for n in range(64, 1986, 2))
+    assert not engine.fused_supports(1986, 1986, (64, 64)) and engine.fused_supports(2048, 2048, (64, 64))
     return shapes
 
 
@@ -241,7 +248,8 @@ def test_general_sides_with_distinct_walkers(n_side):
 # embedded in the next built side >= side + PSF side - 1 (psfmc_device.h WrapDesc), each axis on its own
 EMBEDDED_SHAPES = [(170, 170), (256, 90), (490, 64), (64, 490), (74, 74), (134, 256), (200, 134), (166, 226),
                    (238, 340), (68, 1000), (958, 70), (290, 292), (990, 82), (94, 102), (502, 514), (686, 98),
-                   (642, 70), (70, 642)]        # (642: the smallest sides that fit -- 650, 660, 676 -- have slow kernels)
+                   (642, 70), (70, 642),        # (642: the smallest sides that fit -- 650, 660, 676 -- have slow kernels)
+                   (1000, 1000), (1100, 1024), (66, 1030), (1300, 70), (1984, 64)]   # round 4: embedded above 1024
 
 
 @pytest.mark.parametrize('shape', EMBEDDED_SHAPES, ids=lambda s: '%dx%d' % s)

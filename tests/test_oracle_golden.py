@@ -37,6 +37,37 @@ def test_oracle_matches_reference_lnprob(name):
     assert helpers.rel_err(got64[~ok], ref[~ok]) <= 1e-6
 
 
+@pytest.mark.parametrize('name,step', [('synth512x2', 3), ('synth1024x4', 4)])
+def test_oracle_matches_reference_at_the_large_configurations(name, step):
+    """BASELINE configs 3 and 4 (512^2 / 2 Sersic, 1024^2 / 4 Sersic) pinned to the reference itself: the
+    `light` fixtures hold the reference's log-posteriors for vectors on the field tools/synth_field.py
+    regenerates from its seed (its checksums are in the fixture).  A subset here (CPU suite time); every vector
+    goes through the GPU in tests/test_gpu_headline.py."""
+    case, _ = helpers.load_light_case(name)
+    field = helpers.oracle_field(case)
+    layout = helpers.LAYOUT[name]
+    n = len(case['params'])
+    idx = sorted(set(list(range(0, n, step)) + [n - 2, n - 1]))       # ... and the two -inf vectors at the end
+    got32, got64 = [], []
+    for i in idx:
+        prior = case['lnprior'][i]
+        if not np.isfinite(prior):
+            got32.append(-np.inf)
+            got64.append(-np.inf)
+            continue
+        ll32 = helpers.oracle_loglike(field, layout, case['params'][i], False, None)
+        ll64 = helpers.oracle_loglike(field, layout, case['params'][i], False)
+        got32.append(ll32 + prior if np.isfinite(ll32) else -np.inf)
+        got64.append(ll64 + prior if np.isfinite(ll64) else -np.inf)
+        # the fixture's fp64 log-likelihood is this oracle's, evaluated next to the reference
+        if np.isfinite(ll64):
+            assert abs(ll64 - case['loglike_f64'][i]) <= 1e-11 * abs(ll64)
+    ref = case['lnprob'][idx]
+    assert (ref == -np.inf).sum() >= 2
+    assert helpers.rel_err(np.array(got32), ref) <= 1e-12
+    assert helpers.rel_err(np.array(got64), ref) <= 1e-6
+
+
 def test_oracle_images_match_reference():
     case = helpers.load_case('example')
     field = helpers.oracle_field(case)
