@@ -212,10 +212,11 @@ def test_nearest_fused_sides():
     assert engine.nearest_fused_sides(256) == (256, 256)
     assert engine.nearest_fused_sides(134) == (132, 140)
     assert engine.nearest_fused_sides(50) == (None, 64)
-    assert engine.nearest_fused_sides(2000) == (1024, None)
+    assert engine.nearest_fused_sides(2000) == (1536, 2048) and engine.nearest_fused_sides(3000) == (2048, None)
     assert engine.fused_supports(140, 256) and not engine.fused_supports(134, 256)
     assert engine.fused_supports(134, 256, (64, 64)) and engine.embedding_side(134, 64) == 200
-    assert engine.embedding_side(1000, 64) is None and engine.embedding_side(170, 33) == 208
+    assert engine.embedding_side(1000, 64) == 1152 and engine.embedding_side(170, 33) == 208
+    assert engine.embedding_side(1985, 64) == 2048 and engine.embedding_side(1986, 64) is None
 
 
 def test_side_tables_agree_between_python_and_the_kernels():
@@ -246,7 +247,7 @@ def test_side_tables_agree_between_python_and_the_kernels():
         elif n in picks:
             r2, r3 = picks[n]
             assert name == 'k_cols3g' and shape == (n // (r2 * r3), r2, r3), n
-            assert n % (r2 * r3) == 0 and r2 * r3 <= 64 and 4 <= n // (r2 * r3) <= 16
+            assert n % (r2 * r3) == 0 and r2 * r3 <= 64 and 4 <= n // (r2 * r3) <= (16 if n <= 1024 else 32)
         else:
             assert name == 'k_cols' and shape is None, n
     costs = open(os.path.join(csrc, 'psfmc_side_costs.h')).read()

@@ -47,7 +47,8 @@ def main():
         prof = bench.kernel_profile(eng, args, one_batch, torch, dev, 6)
         rec = {'side': n, 'walkers': walkers, 'evals_per_s': rate, 'ns_per_pixel_step': 1e9 / rate / (n * n)}
         for k in prof:
-            key = 'rows_fwd' if 'rows_fwd' in k['kernel'] else ('rows_inv' if 'rows_inv' in k['kernel'] else 'cols')
+            name = k['kernel']                     # k_rows_fwd / k_rows3_fwd, k_rows_inv / k_rows3_inv, k_cols*
+            key = 'rows_fwd' if '_fwd<' in name else ('rows_inv' if '_inv<' in name else 'cols')
             rec[key + '_ns_per_pixel'] = k['avg_ms'] * 1e6 / k['walkers_per_launch'] / (n * n)
             rec[key + '_kernel'] = k['kernel']
         print(json.dumps(rec), flush=True)
