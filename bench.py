@@ -200,9 +200,10 @@ def kernel_profile(eng, args, one_batch, torch, dev, reps):
     nxh = n // 2 + 1
     t_bytes = 2 * nxh * n * 16                  # transposed half-spectra of one walker
     designed = {'rows_fwd': t_bytes, 'cols': 2 * t_bytes, 'rows_inv': t_bytes}
-    rows3 = eng.get_option('rows3') == 1.0          # the one-row-per-wave three-stage row kernels (sides above 1024)
-    names = {'rows_fwd': ('k_rows3_fwd<%d, false>' if rows3 else 'k_rows_fwd<%d, false>') % n,
-             'rows_inv': ('k_rows3_inv<%d>' if rows3 else 'k_rows_inv<%d>') % n,
+    rows3 = eng.get_option('rows3')                 # the one-row-per-wave three-stage row kernels: bit 0 forward, bit 1 inverse
+    rows3 = int(rows3) if rows3 == rows3 else 0
+    names = {'rows_fwd': ('k_rows3_fwd<%d, false>' if rows3 & 1 else 'k_rows_fwd<%d, false>') % n,
+             'rows_inv': ('k_rows3_inv<%d>' if rows3 & 2 else 'k_rows_inv<%d>') % n,
              'cols': '%s<%d, true>' % (column_kernel_name(eng, n), n)}
     streams = eng.get_option('streams')
     eng.set_option('streams', 1)

@@ -475,7 +475,9 @@ __device__ __forceinline__ int wrap_coord(int p, int a, int l) {
 // K0: the lane's pixels are x = T (K0 + k) + t, k < P (a segment of a longer row; 0 for whole rows)
 // WRAP: `iy` and x are transform coordinates of an embedded image (see WrapDesc)
 // G: Sersic pixels per lane that go through the profile's stages together (1: pixel after pixel)
-template <int P, int T, int K0 = 0, bool WRAP = false, int G = 1>
+// PFETCH: a component's parameters and tables are fetched one component ahead (always with G > 1; the
+// one-row-per-wave kernels of psfmc_rows3_path.h ask for it with G = 1 too)
+template <int P, int T, int K0 = 0, bool WRAP = false, int G = 1, bool PFETCH = (G > 1)>
 __device__ __forceinline__ void raster_row(const double* __restrict__ prep, int n_ps, int n_sersic,
                                            int t, int iy, bool ps_only, double* __restrict__ log_tab,
                                            double (&r)[P], const WrapDesc& wr = WrapDesc{0, 0, 0, 0, 0, 0},
@@ -517,7 +519,7 @@ __device__ __forceinline__ void raster_row(const double* __restrict__ prep, int 
             B.e[i] = g[kPowTabB + lane_id + 64 * i];
         }
     };
-    constexpr bool PF = G > 1;
+    constexpr bool PF = PFETCH;
     Block cur{}, nxt{};
     if (PF && !ps_only && n_sersic > 0) issue(0, cur);            // in flight during the point sources
     for (int c = 0; c < n_ps; ++c, p += kPrepPs) {

@@ -354,8 +354,9 @@ struct psfmc_ctx {
     bool t_f32 = false;       // T stored as complex64 (set_option "storage_f32"); arithmetic stays fp64
     bool plain_shape = false; // both sides power-of-two shapes (what storage_f32 is built for)
     bool row_fast = false;    // nx a power-of-two shape and ny a whole number of its row workgroups
-    bool rows3 = false;       // the row kernels of this context are the one-row-per-wave three-stage ones (psfmc_rows3_path.h):
-                              // every side above 1024; PSFMC_ROWS3=1 in the environment also where both families are built
+    // which row kernels are the one-row-per-wave three-stage ones (psfmc_rows3_path.h): both above 1024, the inverse
+    // one at the sides of rows3_inv_default; PSFMC_ROWS3 = 1 / 0 in the environment forces every built one / none
+    bool rows3_fwd = false, rows3_inv = false;
     long long speculated_runs = 0;   // psfmc_stretch_run calls that took the whole-iteration route
     int speculate = -1;       // device sampler: ensembles of up to 2 x this many walkers run ONE pipeline pass per iteration (0 = never, -1 = the default rule)
     int cols3 = 1;            // column kernel on the wave-wide three-stage engines: 0 never, 1 k_cols3 at 512 / 1024 and k_cols3g at the sides of fft3g_pick, 2 k_cols3g at 512 / 1024 as well
@@ -461,7 +462,7 @@ static int launch_rows3_fwd_kernel(psfmc_ctx* c, int n, const double* prep, cons
 template <int NX, bool FROM_IMAGE>
 static int launch_rows3_fwd(psfmc_ctx* c, int n, const double* prep, const uint8_t* skip, cd* Tbuf, int ps_only,
                             const double* img, const double* img_scale, double* raw_out, hipStream_t st) {
-    if constexpr (!rows3_side<NX>()) {
+    if constexpr (!rows3_fwd_built(NX)) {
         return fail(PSFMC_EINVAL, "side %d has no three-stage row kernels", NX);
     } else {
         if constexpr (!FROM_IMAGE) {
@@ -552,7 +553,7 @@ static int launch_rows_fwd(psfmc_ctx* c, int n, const double* prep, const uint8_
     } else {
         TS* Tbuf = static_cast<TS*>(Tvoid);
         if constexpr (sizeof(TS) == sizeof(cd)) {
-            if (c->rows3)
+            if (c->rows3_fwd)
                 return launch_rows3_fwd<NX, FROM_IMAGE>(c, n, prep, skip, static_cast<cd*>(Tvoid), ps_only, img, img_scale,
                                                         raw_out, st);
         }
@@ -679,7 +680,7 @@ static int launch_rows_inv(psfmc_ctx* c, int n, const void* Tvoid, const double*
     } else {
         const TS* Tbuf = static_cast<const TS*>(Tvoid);
         if constexpr (sizeof(TS) == sizeof(cd)) {
-            if (c->rows3)
+            if (c->rows3_inv)
                 return launch_rows3_inv<NX>(c, n, static_cast<const cd*>(Tvoid), prep, skip, partial, conv_out, var_out, st);
         }
         if constexpr (FftShape<NX>::kPlain) {
@@ -697,7 +698,7 @@ static int launch_rows_inv(psfmc_ctx* c, int n, const void* Tvoid, const double*
 template <int NX> static int pack_field(psfmc_ctx* c, int f) {
     const size_t px = (size_t)f * c->S;
     if constexpr (rows3_side<NX>()) {
-        if (c->rows3) {
+        if (c->rows3_inv) {
             hipLaunchKernelGGL((k_pack_field3<NX>), dim3(256), dim3(256), 0, c->stream, c->d_sci + px, c->d_var + px,
                                c->d_bad + px, c->d_field + (size_t)f * c->field_len, c->ny);
             return PSFMC_OK;
@@ -721,6 +722,12 @@ template <int NX> static RowShape row_shape_of(bool rows3) {
                         FftShape<NX>::kPlain};
     else
         return RowShape{1, kRows3Waves, kRows3RgLog2, 0, false};
+}
+// bit 0: a two-stage family exists; bit 1: the three-stage inverse kernel is built; bit 2: the forward one;
+// bit 3: the three-stage inverse kernel is the default
+template <int NX> constexpr int row_families() {
+    return (two_stage_side(NX) ? 1 : 0) | (rows3_side<NX>() ? 2 : 0) | (rows3_fwd_built(NX) ? 4 : 0) |
+           (rows3_side<NX>() && rows3_inv_default(NX) ? 8 : 0);
 }
 template <int NX> static size_t field_len_of(int ny, bool rows3) {
     if constexpr (rows3_side<NX>()) {
@@ -774,7 +781,7 @@ static int size_call_here(int op, int side, SizeCall& a) {
     switch (op) {
         case SZ_ROW_SHAPE:
             // (a.rows3: the caller asks for the three-stage row family where the side has both; a.code: whether it has it)
-            DISPATCH_LEN(side, (*a.shape = row_shape_of<N_>(a.rows3), *a.code = has_rows3<N_>() ? (two_stage_side(N_) ? 1 : 2) : 0));
+            DISPATCH_LEN(side, (*a.shape = row_shape_of<N_>(a.rows3), *a.code = row_families<N_>()));
             return PSFMC_OK;
         case SZ_FIELD_LEN:
             DISPATCH_LEN(side, *a.len = field_len_of<N_>(a.ny, a.rows3));
@@ -848,8 +855,7 @@ static int size_call(int op, int side, SizeCall& a) {
 #endif
 }
 
-// rows3_wanted: take the three-stage row family where the side has both; *family: 0 the side has only the
-// two-stage kernels, 1 both, 2 only the three-stage ones
+// rows3_wanted: the shape of the three-stage row family where the side has both; *family: row_families' bits
 static int row_shape_for(int nx, RowShape* out, bool rows3_wanted = false, int* family = nullptr) {
     SizeCall a;
     int code = 0;
@@ -1107,7 +1113,7 @@ static int ctx_init(psfmc_ctx* c, const double* sci, const double* obs_var, cons
         size_t field_len = 0;
         {
             SizeCall a;
-            a.len = &field_len; a.ny = c->ny; a.rows3 = c->rows3;
+            a.len = &field_len; a.ny = c->ny; a.rows3 = c->rows3_inv;
             RC_TRY(size_call(SZ_FIELD_LEN, c->nx, a));
         }
         c->field_len = field_len;
@@ -1221,7 +1227,7 @@ static int ctx_create_impl(psfmc_ctx** out, int device, int ny, int nx, int n_fi
     if (backend != PSFMC_BACKEND_HIPFFT && backend != PSFMC_BACKEND_FUSED)
         return fail(PSFMC_EINVAL, "unknown backend %d", backend);
     int row_tiles = 0;
-    bool rows3 = false;
+    bool rows3_fwd = false, rows3_inv = false;
     RowShape rs{};
     const int ly = ny, lx = nx;                       // the image's own sides
     WrapDesc wrap{0, 0, 0, 0, 0, 0};
@@ -1253,11 +1259,16 @@ static int ctx_create_impl(psfmc_ctx** out, int device, int ny, int nx, int n_fi
                 }
             sci = pad_sci.data(); obs_var = pad_var.data(); bad_px = pad_bad.data();
         }
-        const char* want3 = getenv("PSFMC_ROWS3");
-        int family = 0;
-        RC_TRY(row_shape_for(nx, &rs, want3 && atoi(want3) != 0, &family));
-        rows3 = family == 2 || (family == 1 && want3 && atoi(want3) != 0);
-        row_tiles = (ny + rs.rg - 1) / rs.rg;
+        const char* env3 = getenv("PSFMC_ROWS3");
+        const int force = env3 ? (atoi(env3) != 0 ? 1 : 0) : -1;          // -1: the defaults
+        int fam = 0;
+        RC_TRY(row_shape_for(nx, &rs, false, &fam));                       // (the two-stage shape where there is one)
+        const bool two = fam & 1;
+        rows3_inv = !two || ((fam & 2) && (force == 1 || (force < 0 && (fam & 8))));
+        rows3_fwd = !two || ((fam & 4) && force == 1);
+        // a power-of-two side takes both kernels of a family (their layouts differ: row groups of 2 against 4)
+        if (two && rs.plain && rows3_inv != rows3_fwd) rows3_inv = rows3_fwd = false;
+        row_tiles = rows3_inv ? ny : (ny + rs.rg - 1) / rs.rg;             // chi^2 partial sums per walker
     }
 
     int ndev = 0;
@@ -1285,15 +1296,15 @@ static int ctx_create_impl(psfmc_ctx** out, int device, int ny, int nx, int n_fi
     c->nyp = ny;
     if (backend == PSFMC_BACKEND_FUSED) {
         c->nblk = row_tiles;
-        c->rows3 = rows3;
+        c->rows3_fwd = rows3_fwd; c->rows3_inv = rows3_inv;
         // the power-of-two row kernels run without row guards: whole workgroups of rows only;
         // any other ny takes the guarded code path of the same shape (layout groups of 4 rows)
-        c->row_fast = !rows3 && rs.plain && ny % (rs.rg * rs.fast_waves) == 0;
+        c->row_fast = !rows3_fwd && !rows3_inv && rs.plain && ny % (rs.rg * rs.fast_waves) == 0;
         c->rg_log2 = c->row_fast ? rs.fast_rg_log2 : 2;
         c->nyp = t_col_len(ny, c->rg_log2);
         RowShape cs{};
         RC_TRY(row_shape_for(ny, &cs));
-        c->plain_shape = !rows3 && rs.plain && cs.plain;
+        c->plain_shape = !rows3_fwd && !rows3_inv && rs.plain && cs.plain;
         c->cols_grid = prop.multiProcessorCount * 2;
         c->chunk = fused_pass_walkers(c);
         // measured (gpurun_out/stag*_quick.txt, same-box A/B): 64^2 +2.7 %, 128^2 +1.7 %, 256^2 +4.6 %
@@ -1471,7 +1482,7 @@ extern "C" double psfmc_get_option(const psfmc_ctx* cc, const char* key) {
         if (!strcmp(key, name)) { prof_collect(c); return (double)c->prof_n[i]; }
     }
     if (!strcmp(key, "row_group")) return 1 << c->rg_log2;
-    if (!strcmp(key, "rows3")) return c->rows3 ? 1.0 : 0.0;
+    if (!strcmp(key, "rows3")) return (c->rows3_fwd ? 1.0 : 0.0) + (c->rows3_inv ? 2.0 : 0.0);   // bit 0 forward, bit 1 inverse
     if (!strcmp(key, "column_engine")) {       // the column kernel this context launches NOW: 0 k_cols, 1 k_cols3, 2 k_cols3g
         if (c->backend != PSFMC_BACKEND_FUSED) return NAN;
         int code = 0;

@@ -33,25 +33,42 @@ constexpr int kRows3RgLog2 = 2;
 
 // the row shape of a side: {R2, R3}, R1 = nx / (R2 R3); {0, 0} = the side has no three-stage row kernels
 #ifndef PSFMC_ROWS3_EXTRA
-#define PSFMC_ROWS3_EXTRA 0         /* 1: also build the row kernels of the candidate sides below (tools/rows3_probe.hip) */
+#define PSFMC_ROWS3_EXTRA 0         /* 1: also build the candidates below (tools/rows3_probe.hip; PSFMC_ROWS3=1 in the environment selects them) */
 #endif
+// Which sides have these kernels, and which take them by default, is by measurement (tools/rows3_probe.hip on an
+// MI355X, gpurun_out/r4_rows3_probe*.txt, same prep records, pass-sized batches, us per launch two-stage ->
+// three-stage):
+//   inverse   676: 48.2 -> 40.9   728: 53.9 -> 38.4   780: 52.7 -> 43.0   784: 57.6 -> 41.6   840: 55.8 -> 37.5
+//             900: 63.3 -> 42.3   (their two-stage kernels hold 26 ... 30 complex registers per lane: one wave per
+//             SIMD, or two with 72 ... 128 bytes of scratch); 630 / 650 / 700: 35.7 -> 40.7, 38.9 -> 44.1, 50.4 -> 48.8
+//             (two waves without much scratch: no gain); 512 / 1024: 32.1 -> 40.2, 33.8 -> 42.4 (SLOWER)
+//   forward   728: 62.9 -> 61.6   840: 64.8 -> 63.0   900: 71.2 -> 72.6   (even) and SLOWER everywhere else
+//             (630: 42.4 -> 58.7 ... 1024: 72.4 -> 94.5, 512: 46.5 -> 64.9): a wave's stores are 16-byte pieces of
+//             lines where the two-stage wave's are 32 ... 64 bytes, its store phase takes twice as long (26 vs 13.7 us
+//             at 1024^2 / 6 walkers, measured by compiling the phases out), and the table traffic per pixel doubles.
+// So: inverse kernels for the six sides above, both kernels for the sides above 1024 (nothing else reaches them).
 constexpr Fft3gPick rows3_pick(int n) {
     switch (n) {
         // sides above 1024: the only row kernels there are (the two-stage shapes end at P = T = 32)
         case 1152: case 1280: case 1536: case 2048: return {8, 8};
-#if PSFMC_ROWS3_EXTRA
-        case 512: case 1024: return {8, 8};
-        // sides whose two-stage row shape holds 25 ... 30 complex registers per lane at one wave per SIMD
-        case 650: return {5, 10};
+        // sides whose two-stage row shape holds 26 ... 30 complex registers per lane
         case 676: case 780: return {4, 13};
         case 728: case 784: case 840: return {4, 14};
         case 900: return {4, 15};
-        case 700: return {5, 10};
+#if PSFMC_ROWS3_EXTRA
+        case 512: case 1024: return {8, 8};
+        case 650: case 700: return {5, 10};
         case 630: return {7, 9};
 #endif
         default: return {0, 0};
     }
 }
+constexpr bool rows3_only_side(int n) { return n > 1024; }
+// the inverse kernel is the default where it measured faster; the forward kernel only where there is no other
+constexpr bool rows3_inv_default(int n) {
+    return rows3_only_side(n) || n == 676 || n == 728 || n == 780 || n == 784 || n == 840 || n == 900;
+}
+constexpr bool rows3_fwd_built(int n) { return rows3_pick(n).r2 > 0 && (rows3_only_side(n) || PSFMC_ROWS3_EXTRA); }
 template <int NX> struct Rows3 {
     using S = Fft3gShape<NX, rows3_pick(NX).r2, rows3_pick(NX).r3>;
     static constexpr bool kBuilt = S::kBuilt;
@@ -75,6 +92,10 @@ template <class S, bool INVERSE> constexpr int rows3_min_waves() {
 }
 #ifndef PSFMC_ROWS3_RASTER_GROUP
 #define PSFMC_ROWS3_RASTER_GROUP 1
+#endif
+#ifndef PSFMC_ROWS3_PREFETCH
+#define PSFMC_ROWS3_PREFETCH 0      /* the next component's parameters and tables in flight during this one's pixels
+                                       (measured: 840 -6 %, 900 0, 1024 +3 % kernel time; 15 registers) */
 #endif
 #ifndef PSFMC_DEBUG_ROWS3
 #define PSFMC_DEBUG_ROWS3 0          /* timing experiments: 1 = no store phase, 2 = no transform, 4 = no rasteriser */
@@ -151,8 +172,8 @@ k_rows3_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip, c
 #pragma unroll
             for (int k = 0; k < R1; ++k) r[k] = wprep[0] * (double)(t + k);
 #else
-            raster_row<R1, L, 0, WRAP, WRAP ? 1 : PSFMC_ROWS3_RASTER_GROUP>(wprep, n_ps, n_sersic, tl, iy, ps_only != 0,
-                                                                           wave_lds, r, wr, pow_mode);
+            raster_row<R1, L, 0, WRAP, WRAP ? 1 : PSFMC_ROWS3_RASTER_GROUP, PSFMC_ROWS3_PREFETCH != 0>(
+                wprep, n_ps, n_sersic, tl, iy, ps_only != 0, wave_lds, r, wr, pow_mode);
 #endif
             wave_lds_sync();
 #pragma unroll

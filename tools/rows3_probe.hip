@@ -27,7 +27,8 @@ template <int NX>
 static void run_side(int n_w, int n_sersic, int reps) {
     using S3 = typename Rows3<NX>::S;
     constexpr int NY = NX, NXH = NX / 2 + 1;
-    constexpr int rgl2_old = layout_rg_log2<NX, true>();
+    constexpr bool FAST = FftShape<NX>::kPlain;             // the unguarded power-of-two kernels, or the general ones
+    constexpr int rgl2_old = layout_rg_log2<NX, FAST>();
     const int n_ps = 1, plen = prep_len(n_ps, n_sersic);
     std::vector<double> hprep((size_t)n_w * plen, 0.0);
     srand(11);
@@ -61,7 +62,7 @@ static void run_side(int n_w, int n_sersic, int reps) {
     uint8_t* dbad;
     cd *dtw, *dT_old, *dT_new;
     FieldPx *dfield_old, *dfield_new;
-    const int nblk_old = NY / row_group<NX>();
+    const int nblk_old = (NY + row_group<NX>() - 1) / row_group<NX>();
     CK(hipMalloc(&dprep, hprep.size() * sizeof(double)));
     CK(hipMemcpy(dprep, hprep.data(), hprep.size() * sizeof(double), hipMemcpyHostToDevice));
     CK(hipMalloc(&dtw, NX * sizeof(cd)));
@@ -83,15 +84,15 @@ static void run_side(int n_w, int n_sersic, int reps) {
     hipLaunchKernelGGL((k_pack_field3<NX>), dim3(256), dim3(256), 0, 0, dsci, dvar, dbad, dfield_new, NY);
     CK(hipDeviceSynchronize());
 
-    constexpr size_t lds_old = fused_row_lds_bytes<NX, true>(), lds_new = rows3_lds_bytes<S3>();
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows_fwd<NX, false, cd, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_old));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows_inv<NX, cd, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_old));
+    constexpr size_t lds_old = fused_row_lds_bytes<NX, FAST>(), lds_new = rows3_lds_bytes<S3>();
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows_fwd<NX, false, cd, FAST, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_old));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows_inv<NX, cd, FAST, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_old));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows3_fwd<NX, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_new));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rows3_inv<NX, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_new));
-    constexpr int waves_old = row_waves<NX, true>();
+    constexpr int waves_old = row_waves<NX, FAST>();
     const WrapDesc wr{0, 0, 0, 0, 0, 0};
     auto fwd_old = [&]() {
-        hipLaunchKernelGGL((k_rows_fwd<NX, false, cd, true, false>), dim3(nblk_old / waves_old, n_w), dim3(64 * waves_old), lds_old, 0,
+        hipLaunchKernelGGL((k_rows_fwd<NX, false, cd, FAST, false>), dim3((nblk_old + waves_old - 1) / waves_old, n_w), dim3(64 * waves_old), lds_old, 0,
                            dprep, (const uint8_t*)nullptr, dtw, dT_old, n_ps, n_sersic, NY, 0, (const double*)nullptr,
                            (const double*)nullptr, (double*)nullptr, wr, kPowTabsBuilt);
     };
@@ -101,7 +102,7 @@ static void run_side(int n_w, int n_sersic, int reps) {
                            (const double*)nullptr, (double*)nullptr, wr, kPowTabsBuilt);
     };
     auto inv_old = [&]() {
-        hipLaunchKernelGGL((k_rows_inv<NX, cd, true, false>), dim3(nblk_old / waves_old, n_w), dim3(64 * waves_old), lds_old, 0,
+        hipLaunchKernelGGL((k_rows_inv<NX, cd, FAST, false>), dim3((nblk_old + waves_old - 1) / waves_old, n_w), dim3(64 * waves_old), lds_old, 0,
                            dT_old, (const uint8_t*)nullptr, dtw, dfield_old, dpart_old, NY, dprep, plen, (double*)nullptr,
                            (double*)nullptr, 0, 0u);
     };
