@@ -186,7 +186,7 @@ def column_kernel_name(eng, n):
     library that does not report it."""
     code = eng.get_option('column_engine')
     if code == code:
-        return {0: 'k_cols', 1: 'k_cols3', 2: 'k_cols3g'}[int(code)]
+        return {0: 'k_cols', 1: 'k_cols3', 2: 'k_cols3g', 3: 'k_cols3f'}[int(code)]
     from psfmc_amd.engine import column_engine
     return column_engine(n)[0]
 

@@ -673,10 +673,13 @@ __device__ __forceinline__ void load_twiddles3(cd (&w1)[fft3_w1_regs<N>()], cd (
 
 // `w1_lds` (R1 = 16): the workgroup's shared stage-1 table [k1][t] = W_N^(t k1) in LDS,
 // or nullptr to re-read the global table.
+// `w2_lds` (optional): the stage-2 twiddles [k2][n3] = W_N^(R1 n3 k2) from a 64-entry LDS table instead of the
+// eight per-lane registers w2 (32 VGPRs: what keeps the R1 = 16 column kernel from a third wave per SIMD).
 template <int N, int SIGN>
 __device__ __forceinline__ void fft_wave3(cd (&v)[Fft3Shape<N>::R1], const cd (&w1)[fft3_w1_regs<N>()],
                                           const cd (&w2)[8], const cd* __restrict__ table, int t,
-                                          double* __restrict__ lds, const cd* __restrict__ w1_lds = nullptr) {
+                                          double* __restrict__ lds, const cd* __restrict__ w1_lds = nullptr,
+                                          const cd* __restrict__ w2_lds = nullptr) {
     constexpr int R1 = Fft3Shape<N>::R1, NB = R1 / 8, S1 = 72, S2 = R1 + 1;
     const int n3 = t & 7, g = t >> 3;
     // stage 1
@@ -710,7 +713,10 @@ __device__ __forceinline__ void fft_wave3(cd (&v)[Fft3Shape<N>::R1], const cd (&
     for (int i = 0; i < NB; ++i) {
         Dft<8, SIGN>::run(z[i]);
 #pragma unroll
-        for (int k2 = 1; k2 < 8; ++k2) z[i][k2] = cmul(z[i][k2], SIGN < 0 ? w2[k2] : cconj(w2[k2]));
+        for (int k2 = 1; k2 < 8; ++k2) {
+            const cd wk = w2_lds ? w2_lds[k2 * 8 + n3] : w2[k2];
+            z[i][k2] = cmul(z[i][k2], SIGN < 0 ? wk : cconj(wk));
+        }
     }
     // exchange 2 + stage 3: E2[(k2*8 + n3)][k1], k1 = g + 8 i
     cd y[NB][8];

@@ -648,9 +648,14 @@ k_cols(TS* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restric
 // (psfmc_fft.h fft_wave3): one wave per column, 4 waves per workgroup, persistent.
 // ---------------------------------------------------------------------------
 // the waves' exchange regions, then (R1 = 16) the shared stage-1 twiddle table [16][64]
+#ifndef PSFMC_COLS3_W2_LDS
+#define PSFMC_COLS3_W2_LDS 0        /* R1 = 16: the stage-2 twiddles from a 64-entry LDS table (32 registers back) */
+#endif
+template <int NY> constexpr bool cols3_w2_lds() { return PSFMC_COLS3_W2_LDS && Fft3Shape<NY>::R1 > 8; }
 template <int NY> constexpr size_t fused_col3_lds_bytes() {
     return (size_t)(kColThreads / 64) * fft3_lds_doubles<NY>() * sizeof(double) +
-           (Fft3Shape<NY>::R1 > 8 ? (size_t)Fft3Shape<NY>::R1 * 64 * sizeof(cd) : 0);
+           (Fft3Shape<NY>::R1 > 8 ? (size_t)Fft3Shape<NY>::R1 * 64 * sizeof(cd) : 0) +
+           (cols3_w2_lds<NY>() ? 64 * sizeof(cd) : 0);
 }
 
 #ifndef PSFMC_COLS3_BAR
@@ -673,11 +678,23 @@ k_cols3(TS* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restri
     const int t = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double* lds = smem + (size_t)wave * fft3_lds_doubles<NY>();
     cd w1[fft3_w1_regs<NY>()], w2[8];
-    load_twiddles3<NY>(w1, w2, twy, t);
     const cd* w1s = nullptr;
+    const cd* w2s = nullptr;
+    if constexpr (cols3_w2_lds<NY>()) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w2[k] = cd{1.0, 0.0};
+        w1[0] = cd{1.0, 0.0};
+    } else {
+        load_twiddles3<NY>(w1, w2, twy, t);
+    }
     if constexpr (R1 > 8) {
         cd* tab = reinterpret_cast<cd*>(smem + (size_t)WPB * fft3_lds_doubles<NY>());
         for (int i = threadIdx.x; i < R1 * 64; i += kColThreads) tab[i] = twy[(i & 63) * (i >> 6)];
+        if constexpr (cols3_w2_lds<NY>()) {
+            cd* tab2 = tab + R1 * 64;                      // [k2][n3] = W_N^(R1 n3 k2)
+            if (threadIdx.x < 64) tab2[threadIdx.x] = twy[R1 * (threadIdx.x & 7) * (threadIdx.x >> 3)];
+            w2s = tab2;
+        }
         __syncthreads();                                   // once, before any wave can leave
         w1s = tab;
     }
@@ -697,7 +714,7 @@ k_cols3(TS* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restri
 #pragma unroll
         for (int a = 0; a < R1; ++a) v[a] = load_stream(base + 128 * a);
         if (skipped) continue;
-        fft_wave3<NY, -1>(v, w1, w2, twy, t, lds, w1s);
+        fft_wave3<NY, -1>(v, w1, w2, twy, t, lds, w1s, w2s);
         if constexpr (CONVOLVE) {
             // keep the kernel-spectrum loads (and the next column's) out of the transform's
             // register budget: occupancy, not load hoisting, hides their latency here
@@ -711,7 +728,7 @@ k_cols3(TS* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restri
 #if PSFMC_COLS3_BAR & 2
             __builtin_amdgcn_sched_barrier(0);
 #endif
-            fft_wave3<NY, +1>(v, w1, w2, twy, t, lds, w1s);
+            fft_wave3<NY, +1>(v, w1, w2, twy, t, lds, w1s, w2s);
 #if PSFMC_COLS3_BAR & 4
             __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -808,6 +825,79 @@ k_cols3g(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restr
                     for (int k3 = 0; k3 < R3; ++k3) base[row_off(fft3g_index<S>(t, q, k3))] = o[q][k3];
                 }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// cols3f (round 4): the column kernel of ny = 8 m x 64 (512, 1024, 1536, 2048) on the general three-stage engine
+// run FORWARD both ways.  With R2 = R3 = 8 and R1 a multiple of 8 the forward transform's output register (q, k3)
+// holds X[t + 64 (q + NB3 k3)] -- the engine's own INPUT layout with a = q + NB3 k3 -- so the inverse transform is
+// the same engine with conjugated twiddles (no mirrored engine, no second twiddle table: R1 KB + N doubles per wave
+// of LDS, which is what lets two workgroups share a CU at 1536), and the kernel is written for a third wave per
+// SIMD at R1 = 16.
+// ---------------------------------------------------------------------------
+template <class S> constexpr bool cols3f_shape() { return S::kBuilt && S::R2 == 8 && S::R3 == 8 && S::R1 % 8 == 0; }
+template <class S> constexpr size_t fused_col3f_lds_bytes() {
+    return ((size_t)(kColThreads / 64) * fft3g_lds_doubles<S>() + (size_t)S::R1 * 64 * 2) * sizeof(double);
+}
+#ifndef PSFMC_COLS3F_WAVES16
+#define PSFMC_COLS3F_WAVES16 3
+#endif
+template <class S> constexpr int cols3f_min_waves() { return S::R1 <= 8 ? 4 : S::R1 <= 16 ? PSFMC_COLS3F_WAVES16 : S::R1 <= 24 ? 2 : 1; }
+
+template <int NY, bool CONVOLVE, class S = Fft3gShape<NY>>
+__global__ void __launch_bounds__(kColThreads, (cols3f_min_waves<S>()))
+k_cols3f(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restrict__ prep,
+         const uint8_t* __restrict__ skip, const cd* __restrict__ twy, int plen, int nxh, int n_w, int rg_log2) {
+    static_assert(cols3f_shape<S>(), "ny = 8 m x 8 x 8");
+    constexpr int R1 = S::R1, NB3 = S::NB3, WPB = kColThreads / 64;
+    static_assert(NB3 * 8 == R1, "registers");
+    extern __shared__ __align__(16) double smem[];
+#if PSFMC_COLS_PRIO
+    __builtin_amdgcn_s_setprio(PSFMC_COLS_PRIO);
+#endif
+    const int t = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* lds = smem + (size_t)wave * fft3g_lds_doubles<S>();
+    cd* tab = reinterpret_cast<cd*>(smem + (size_t)WPB * fft3g_lds_doubles<S>());
+    for (int i = threadIdx.x; i < R1 * 64; i += kColThreads) tab[i] = twy[(i & 63) * (i >> 6)];
+    __syncthreads();                                   // once, before any wave can leave
+    cd w2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w2[k] = twy[R1 * (t & 7) * k];
+    const int rg_mask = (1 << rg_log2) - 1;
+    const int off_t = 2 * t - (t & rg_mask);           // element offset of row t; row 64 a + t adds 128 a (64 a multiple of the row group)
+    const int n_cols = n_w * 2 * nxh;
+    const int nyp = t_col_len(NY, rg_log2);
+    const GroupRange gr = xcd_group_range((n_cols + WPB - 1) / WPB);
+    for (int grp = gr.first; grp < gr.end; grp += gr.step) {
+        const int col = grp * WPB + wave;
+        if (col >= n_cols) continue;                     // wave-uniform
+        const int pr = col >> 1, c = col & 1;           // kx * n_w + walker, component
+        const int kx = pr / n_w, w = pr - kx * n_w;
+        const bool skipped = skip && skip[w];            // wave-uniform; tested once the column's loads are issued
+        cd* base = Tbuf + ((size_t)w * nxh + kx) * 2 * nyp + (c << rg_log2) + off_t;
+        cd v[R1];
+#pragma unroll
+        for (int a = 0; a < R1; ++a) v[a] = load_stream(base + 128 * a);
+        if (skipped) continue;
+        cd o[NB3][8];
+        fft_wave3g<S, -1>(v, o, w2, t, lds, tab);        // o[q][k3] = X[t + 64 (q + NB3 k3)]
+        if constexpr (CONVOLVE) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int psf = (int)prep[(size_t)w * plen + kPrepPsfIdx];
+            const cd* k = Kt + (((size_t)psf * nxh + kx) * 2 + c) * NY + t;
+#pragma unroll
+            for (int q = 0; q < NB3; ++q)
+#pragma unroll
+                for (int k3 = 0; k3 < 8; ++k3) v[q + NB3 * k3] = cmul(o[q][k3], k[64 * (q + NB3 * k3)]);
+            __builtin_amdgcn_sched_barrier(0);
+            fft_wave3g<S, +1>(v, o, w2, t, lds, tab);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int q = 0; q < NB3; ++q)
+#pragma unroll
+            for (int k3 = 0; k3 < 8; ++k3) base[128 * (q + NB3 * k3)] = o[q][k3];
     }
 }
 

@@ -359,7 +359,7 @@ struct psfmc_ctx {
     bool rows3_fwd = false, rows3_inv = false;
     long long speculated_runs = 0;   // psfmc_stretch_run calls that took the whole-iteration route
     int speculate = -1;       // device sampler: ensembles of up to 2 x this many walkers run ONE pipeline pass per iteration (0 = never, -1 = the default rule)
-    int cols3 = 1;            // column kernel on the wave-wide three-stage engines: 0 never, 1 k_cols3 at 512 / 1024 and k_cols3g at the sides of fft3g_pick, 2 k_cols3g at 512 / 1024 as well
+    int cols3 = 1;            // column kernel on the wave-wide three-stage engines: 0 never, 1 the defaults (k_cols3f at 512 / 1536 / 2048, k_cols3 at 1024, k_cols3g at the other sides of fft3g_pick), 2 k_cols3g at those four as well, 3 round 3's k_cols3 at 512 / 1024, 4 k_cols3f at 1024 too
     bool use_graph = false;   // psfmc_stretch_run replays a captured iteration (set_option "graph"; measured: no gain,
                               // the iteration is kernel-time- not launch-bound)
     long long graph_launches = 0;
@@ -579,8 +579,31 @@ static int launch_cols(psfmc_ctx* c, void* Tvoid, int n_w, const double* prep, c
   } else {
     TS* Tbuf = static_cast<TS*>(Tvoid);
     const int n_cols = n_w * 2 * c->nxh;
+    if constexpr (cols3f_shape<Fft3gShape<NY>>() && sizeof(TS) == sizeof(cd)) {
+        // ny = 8 m x 64 (512, 1024, 1536, 2048): the general three-stage engine run forward both ways (round 4).
+        // In the flow (same box, whole step): 512^2 +1.6 %, 1536^2 +18 %, 2048^2 +2 %; at 1024 its third wave per
+        // SIMD measured SLOWER than k_cols3 (57.5 vs 52.7 us per 6-walker pass, step -0.8 %: 6 MB of columns in
+        // flight per XCD against a 4-MiB L2 that also has to hold the kernel-spectrum columns), so 1024 keeps
+        // k_cols3 unless cols3 = 4 asks for this one
+        if ((c->cols3 == 1 && NY != 1024) || c->cols3 == 4) {
+            using S3 = Fft3gShape<NY>;
+            constexpr size_t lds3 = fused_col3f_lds_bytes<S3>();
+            static thread_local int attr3f_device = -1;
+            if (attr3f_device != c->device) {
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cols3f<NY, CONVOLVE>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+                attr3f_device = c->device;
+            }
+            const int per_block = kColThreads / 64;
+            const int blocks = (n_cols + per_block - 1) / per_block;
+            const int grid3 = blocks < 4 * c->cols_grid ? blocks : 4 * c->cols_grid;
+            hipLaunchKernelGGL((k_cols3f<NY, CONVOLVE>), dim3(grid3), dim3(kColThreads), lds3, st, Tbuf, c->d_Kt, prep, skip,
+                               c->d_twy, c->plen, c->nxh, n_w, c->rg_log2);
+            return PSFMC_OK;
+        }
+    }
     if constexpr (NY == 512 || NY == 1024) {          // long power-of-two columns: wave-wide three-stage engine
-        if (c->cols3 == 1 || (c->cols3 && sizeof(TS) != sizeof(cd))) {
+        if (c->cols3 == 3 || (c->cols3 == 1 && NY == 1024) || (c->cols3 && sizeof(TS) != sizeof(cd))) {
             constexpr size_t lds3 = fused_col3_lds_bytes<NY>();
             const int per_block = kColThreads / 64;
             const int blocks = (n_cols + per_block - 1) / per_block;
@@ -627,10 +650,13 @@ static int launch_cols(psfmc_ctx* c, void* Tvoid, int n_w, const double* prep, c
   }
 }
 
-// which column kernel launch_cols takes for this context: 0 k_cols, 1 k_cols3, 2 k_cols3g (the same conditions)
+// which column kernel launch_cols takes for this context: 0 k_cols, 1 k_cols3, 2 k_cols3g, 3 k_cols3f (the same conditions)
 template <int NY> static int col_engine_code(const psfmc_ctx* c) {
+    if constexpr (cols3f_shape<Fft3gShape<NY>>()) {
+        if (((c->cols3 == 1 && NY != 1024) || c->cols3 == 4) && !c->t_f32) return 3;
+    }
     if constexpr (NY == 512 || NY == 1024) {
-        if (c->cols3 == 1 || (c->cols3 && c->t_f32)) return 1;
+        if (c->cols3 == 3 || (c->cols3 == 1 && NY == 1024) || (c->cols3 && c->t_f32)) return 1;
     }
     if constexpr (cols3g_side<NY>()) {
         if (!c->t_f32 && c->cols3 && cols3g_layout_ok<Fft3gShape<NY>>(c->rg_log2)) return 2;
@@ -930,7 +956,13 @@ static int alloc_work(psfmc_ctx* c) {
 // 24, 16 at 1024^2 8 % slower than 6 (gpurun_out r2i sweep).
 static int fused_pass_walkers(const psfmc_ctx* c) {
     const double per_walker = 2.0 * c->nxh * c->nyp * (c->t_f32 ? 8.0 : 16.0);
-    const int fit = (int)(112.0 * 1048576.0 / per_walker);
+    // Up to 1024^2: 112 MiB per pass, two passes in flight (rounds 1-3, swept per size).  Above, the kernel spectra
+    // and the packed field pixels -- each the size of one walker's T -- are a third of the Infinity Cache and count:
+    // two passes + the two shared arrays inside 224 MiB (round 4, same box: 1536^2 2 walkers per pass 21.1 k
+    // evals/s, 3: 18.2 k, 4: 17.3 k; 2048^2 1: 7.86 k, 2: 7.60 k; 1152^2 4: 28.4 k, 6: 25.4 k)
+    const double t64 = 2.0 * c->nxh * c->nyp * 16.0;
+    const int fit = t64 <= 17.0e6 ? (int)(112.0 * 1048576.0 / per_walker)
+                                  : (int)((224.0 * 1048576.0 - 2.0 * t64) / (2.0 * per_walker));
     int chunk = fit >= 64 ? ((fit + 4) & ~7) : fit >= 16 ? (fit & ~7) : fit >= 4 ? (fit & ~1) : fit;
     // (sides above 1024: 2 walkers per pass at 1536^2, ONE at 2048^2 -- 67 MB of T each, two passes in flight)
     return chunk < 1 ? 1 : chunk;
@@ -1483,7 +1515,7 @@ extern "C" double psfmc_get_option(const psfmc_ctx* cc, const char* key) {
     }
     if (!strcmp(key, "row_group")) return 1 << c->rg_log2;
     if (!strcmp(key, "rows3")) return (c->rows3_fwd ? 1.0 : 0.0) + (c->rows3_inv ? 2.0 : 0.0);   // bit 0 forward, bit 1 inverse
-    if (!strcmp(key, "column_engine")) {       // the column kernel this context launches NOW: 0 k_cols, 1 k_cols3, 2 k_cols3g
+    if (!strcmp(key, "column_engine")) {       // the column kernel this context launches NOW: 0 k_cols, 1 k_cols3, 2 k_cols3g, 3 k_cols3f
         if (c->backend != PSFMC_BACKEND_FUSED) return NAN;
         int code = 0;
         SizeCall a;

@@ -48,11 +48,14 @@ for _sides, _shape in (((264, 308, 352, 484), (4, 11)), ((384, 528, 576), (4, 12
 
 def column_engine(ny):
     """Which column kernel the fused back end launches for transform side `ny` (psfmc_hip.hip
-    launch_cols): 'k_cols3' (512, 1024: the power-of-two wave-wide three-stage engine), 'k_cols3g' (the
+    launch_cols): 'k_cols3f' (512, 1536, 2048: the general three-stage engine run forward both ways), 'k_cols3'
+    (1024: round 3's power-of-two three-stage kernel), 'k_cols3g' (the
     sides psfmc_fft.h fft3g_pick lists: ny = R1 * R2 * R3 on R2 * R3 <= 64 lanes) or 'k_cols' (the
     two-stage engine).  Returns (kernel name, (R1, R2, R3) or None)."""
-    if ny in (512, 1024):
+    if ny == 1024:
         return 'k_cols3', None
+    if ny in (512, 1536, 2048):
+        return 'k_cols3f', (ny // 64, 8, 8)
     if ny in _COLS3G_SHAPES:
         r2, r3 = _COLS3G_SHAPES[ny]
         return 'k_cols3g', (ny // (r2 * r3), r2, r3)

@@ -112,12 +112,13 @@ def test_many_fields_each_with_its_own_context():
 
 def test_auto_backend_keeps_unbuilt_sides_on_the_fused_kernels():
     """backend='auto': a side outside the built list (170 = 2 * 5 * 17) runs on the fused kernels embedded in
-    the next built side (round 2: the hipFFT back end), like a built one (140); a side too large to embed
-    with its 64-pixel PSF (1000 + 63 > 1024) still goes to hipFFT.  All against the oracle."""
+    the next built side (round 2: the hipFFT back end), like a built one (140); so does 1000 with its 64-pixel
+    PSF since round 4 (embedded in 1152); only a side too large to embed (1986 + 63 > 2048) still goes to hipFFT
+    (not run here: its oracle alone takes a minute).  All against the oracle."""
     import psfmc_oracle as orc
     from psfmc_amd import engine
-    assert not engine.fused_supports(1000, 1000, (64, 64))
-    for side, want_backend in ((170, 'fused'), (140, 'fused')):
+    assert engine.fused_supports(1000, 1000, (64, 64)) and not engine.fused_supports(1986, 1986, (64, 64))
+    for side, want_backend in ((170, 'fused'), (140, 'fused'), (1000, 'fused')):
         model, fld = make_model(side, 1, 'auto', max_walkers=8)
         assert model._backend == want_backend
         theta = synth_field.draw_walkers(side, 1, 4, seed=3, near_truth=fld['truth'])
@@ -224,7 +225,7 @@ def test_unbuilt_even_sizes_on_both_back_ends():
     got = model.log_likelihood_batch(np.zeros((2, 0)))
     assert abs(got[0] - want) <= 1e-11 * abs(want)
     model.close()
-    big = np.zeros((64, 1010), dtype=np.float32)
+    big = np.zeros((64, 2040), dtype=np.float32)                 # 2040 + 21 - 1 > 2048, the largest built side
     with pytest.raises(engine.NativeError) as err:
         cfg = Configuration(big, big + 400.0, psf, pivm, mag_zeropoint=24.0)
         MultiComponentModel([cfg, Sky(adu=0.01)], backend='fused', max_walkers=4).log_likelihood_batch(np.zeros((1, 0)))

@@ -38,14 +38,27 @@ static void run_one(size_t t_budget_bytes) {
     CK(hipGetDeviceProperties(&prop, 0));
     const int n_cols = n_w * 2 * nxh;
     auto launch = [&]() {
-        if constexpr (R2 > 0) {
+        if constexpr (R2 == -2) {                  // X(n, -2, 0): k_cols3f<n> (512, 1024, 1536, 2048)
+            using S = Fft3gShape<N, 8, 8>;
+            constexpr size_t lds = fused_col3f_lds_bytes<S>();
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cols3f<N, true, S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            const int blocks = (n_cols + 3) / 4, cap = 8 * prop.multiProcessorCount;
+            hipLaunchKernelGGL((k_cols3f<N, true, S>), dim3(blocks < cap ? blocks : cap), dim3(kColThreads), lds, 0, dT, dK, dprep,
+                               (const uint8_t*)nullptr, dtw, plen, nxh, n_w, rg_log2);
+        } else if constexpr (R2 < 0) {             // X(n, -1, 0): k_cols3<n> (512, 1024)
+            constexpr size_t lds = fused_col3_lds_bytes<N>();
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cols3<N, true, cd>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            const int blocks = (n_cols + 3) / 4, cap = 8 * prop.multiProcessorCount;
+            hipLaunchKernelGGL((k_cols3<N, true, cd>), dim3(blocks < cap ? blocks : cap), dim3(kColThreads), lds, 0, dT, dK, dprep,
+                               (const uint8_t*)nullptr, dtw, plen, nxh, n_w, rg_log2);
+        } else if constexpr (R2 > 0) {
             using S = Fft3gShape<N, R2, R3>;
             constexpr size_t lds = fused_col3g_lds_bytes<S>();
             CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cols3g<N, true, S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             const int blocks = (n_cols + 3) / 4, cap = 8 * prop.multiProcessorCount;
             hipLaunchKernelGGL((k_cols3g<N, true, S>), dim3(blocks < cap ? blocks : cap), dim3(kColThreads), lds, 0, dT, dK, dprep,
                                (const uint8_t*)nullptr, dtw, plen, nxh, n_w, rg_log2);
-        } else {
+        } else if constexpr (two_stage_side(N)) {
             constexpr size_t lds = fused_col_lds_bytes<N>();
             CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cols<N, true, cd>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             const int groups = (n_cols + col_ffts_per_block<N>() - 1) / col_ffts_per_block<N>(), cap = 2 * prop.multiProcessorCount;
@@ -95,10 +108,16 @@ static void run_one(size_t t_budget_bytes) {
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / reps, gbs = 2.0 * per_w * n_w * sizeof(cd) / (us * 1e-6) / 1e9;
-    if (R2 > 0)
+    if (R2 == -2)
+        printf("N %4d   k_cols3f                          walkers %4d  %7.1f us  %6.0f GB/s   max err %.2e of %.2e %s\n", N, n_w, us, gbs,
+               worst, scale, worst < 1e-9 * scale ? "ok" : "WRONG");
+    else if (R2 < 0)
+        printf("N %4d   k_cols3 (waves %d, w2 in LDS %d)  walkers %4d  %7.1f us  %6.0f GB/s   max err %.2e of %.2e %s\n", N, PSFMC_COLS3_WAVES,
+               PSFMC_COLS3_W2_LDS, n_w, us, gbs, worst, scale, worst < 1e-9 * scale ? "ok" : "WRONG");
+    else if (R2 > 0)
         printf("N %4d = %2d x (%2d x %2d)  walkers %4d  %7.1f us  %6.0f GB/s   max err %.2e of %.2e %s\n", N, N / (R2 * R3 ? R2 * R3 : 1), R2, R3,
                n_w, us, gbs, worst, scale, worst < 1e-9 * scale ? "ok" : "WRONG");
-    else
+    else if constexpr (two_stage_side(N))
         printf("N %4d   two-stage %2d x %2d    walkers %4d  %7.1f us  %6.0f GB/s   max err %.2e of %.2e %s\n", N, FftShape<N>::P, FftShape<N>::T,
                n_w, us, gbs, worst, scale, worst < 1e-9 * scale ? "ok" : "WRONG");
     fflush(stdout);

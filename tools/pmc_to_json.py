@@ -41,8 +41,9 @@ wr = {c: optional('wrreq', 'TCC_EA0_WRREQ' + c + '_sum') for c in ('', '_64B')}
 valu = optional('sq2', 'SQ_INSTS_VALU')          # vector wave-instructions per launch
 table = {}
 for k in sorted(set(fetch) | set(write)):
-    if not any(s in k for s in ('k_rows_fwd<%d, false' % side, 'k_cols<%d, true' % side,
-                                'k_cols3<%d, true' % side, 'k_rows_inv<%d' % side)):
+    if not any(s in k for s in ('k_rows_fwd<%d, false' % side, 'k_cols<%d, true' % side, 'k_cols3<%d, true' % side,
+                                'k_cols3g<%d, true' % side, 'k_cols3f<%d, true' % side, 'k_rows_inv<%d' % side,
+                                'k_rows3_fwd<%d, false' % side, 'k_rows3_inv<%d' % side)):
         continue
     f_kib, w_kib = fetch.get(k, 0.0), write.get(k, 0.0)
     table[k] = {'FETCH_SIZE_KiB_per_launch': f_kib, 'WRITE_SIZE_KiB_per_launch': w_kib,
