@@ -638,7 +638,7 @@ def timed_calls(call, sync, min_s=1.0, decide=None):
     call()
     sync()
     one = max((time.perf_counter() - t0) / 2, 1e-6)
-    n = max(3, int(np.ceil(min_s / one)))
+    n = max(3, int(np.ceil(1.3 * min_s / one)))        # (the sized pair includes a synchronisation the loop does not)
     if decide is not None:
         n = decide(n)
     t0 = time.perf_counter()
@@ -824,7 +824,11 @@ def multi_gpu_extras(args, torch, dist, world, rank, local, dev, gloo):
         pass
     if world > 1:
         dist.barrier()
-    n_iter = decide(512 if world == 1 else 128)
+    t0 = time.perf_counter()
+    for _ in sampler.sample(p0, iterations=64):
+        pass
+    per_iter = max((time.perf_counter() - t0) / 64, 1e-6)
+    n_iter = decide(32 * int(np.ceil(1.2 / per_iter / 32)))          # >= 1 s of iterations, rank 0's count for all
     t0 = time.perf_counter()
     for _ in sampler.sample(p0, iterations=n_iter):
         pass

@@ -179,10 +179,12 @@ def test_field_set_shares_batches_between_fields():
         m.close()
 
 
-@pytest.mark.parametrize('side,n_sersic', [(1024, 2), (200, 1), (64, 1)])
+@pytest.mark.parametrize('side,n_sersic', [(1024, 2), (200, 1), (64, 1), (784, 1), (1152, 1)])
 def test_field_set_other_shapes(side, n_sersic):
     """Two fields in one context at nx = 1024 (the inverse row kernel's own multi-field instantiation),
-    a general shape and the smallest one: bit-identical to the fields' own contexts."""
+    a general shape and the smallest one; round 4: a side whose inverse row kernel is the three-stage one beside
+    a two-stage forward kernel (784) and a side above 1024 (both three-stage): bit-identical to the fields' own
+    contexts."""
     from test_gpu_fullsize import make_model
     from psfmc_amd import FieldSet
     own = [make_model(side, n_sersic, 'fused', max_walkers=8, seed=s) for s in (3, 4)]
