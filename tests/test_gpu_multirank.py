@@ -41,6 +41,15 @@ model = helpers.build_model('synth256', case, work, backend='fused', max_walkers
 sharded = ShardedLogPosterior(model)
 lnp = sharded(case['params'])
 np.save(os.path.join(out, 'lnp%d.npy' % rank), lnp)
+# (a') the same with the vectors resident on the GPU (what `bench.py --gpus N` times): device tensor in, the
+# all-gathered device tensor out; a block larger than the context's max_walkers goes through in slices
+theta_dev = torch.from_numpy(np.ascontiguousarray(case['params'])).to('cuda:0')
+lnp_dev = sharded.evaluate_device(theta_dev)
+big = torch.from_numpy(np.ascontiguousarray(np.tile(case['params'], (5, 1)))).to('cuda:0')     # 325 walkers: blocks > 128
+lnp_big = sharded.evaluate_device(big)
+torch.cuda.synchronize()
+np.save(os.path.join(out, 'lnpdev%d.npy' % rank), lnp_dev.cpu().numpy())
+np.save(os.path.join(out, 'lnpbig%d.npy' % rank), lnp_big.cpu().numpy())
 # (b) the device-resident sampler, half-steps sharded, images accumulated per rank
 p0 = synth_field.draw_walkers(256, 1, __NWALK__, seed=77, near_truth=case['params'][-1])
 samp = DeviceEnsembleSampler(__NWALK__, model, group=True, block=3, accumulate=True)
@@ -96,6 +105,9 @@ def test_ranks_reproduce_one_rank(tmp_path, world, N_WALK):
     single.mkdir()
     model = helpers.build_model('synth256', case, single, backend='fused', max_walkers=128)
     assert np.array_equal(model.log_posterior_batch(case['params']), l0)      # bitwise: batch independent
+    for r in range(world):
+        assert np.array_equal(np.load(out / ('lnpdev%d.npy' % r)), l0), r          # (a') device-resident route
+        assert np.array_equal(np.load(out / ('lnpbig%d.npy' % r)), np.tile(l0, 5)), r
     # (b) the two-rank chain is the one-rank chain
     p0 = synth_field.draw_walkers(256, 1, N_WALK, seed=77, near_truth=case['params'][-1])
     samp = DeviceEnsembleSampler(N_WALK, model, block=3, accumulate=True)
