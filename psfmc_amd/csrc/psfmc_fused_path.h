@@ -66,6 +66,9 @@ constexpr int kInvRemapMaxWalkers = 24;
 #ifndef PSFMC_DEBUG_FWD
 #define PSFMC_DEBUG_FWD 0            /* timing experiments on k_rows_fwd: 1 = no store phase, 2 = no transform */
 #endif
+#ifndef PSFMC_FWD_PRIO_STAGGER
+#define PSFMC_FWD_PRIO_STAGGER 0      /* n > 0: forward row workgroups take issue priority (linear id / n) & 3 */
+#endif
 #ifndef PSFMC_COLS_PREFETCH
 #define PSFMC_COLS_PREFETCH 1         /* register double-buffering of the column loads */
 #endif
@@ -277,6 +280,16 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
     constexpr int RGL2 = layout_rg_log2<NX, FAST>(), RGL = 1 << RGL2;       // rows per layout group
     extern __shared__ __align__(16) double smem[];
     const int w = blockIdx.y;
+#if PSFMC_FWD_PRIO_STAGGER
+    // experiment: the workgroups that share a CU get different instruction-issue priorities, so that the waves of a
+    // SIMD finish -- and store -- at different times instead of all together
+    switch (((blockIdx.y * gridDim.x + blockIdx.x) / PSFMC_FWD_PRIO_STAGGER) & 3) {      // (the operand is an immediate)
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        case 3: __builtin_amdgcn_s_setprio(3); break;
+        default: break;
+    }
+#endif
     // the skip flag is a (wave-uniform) byte behind a vector load: tested only after the loads that
     // do not depend on it have been issued, so that its latency is not a serial step of every wave
     const bool skipped = skip && skip[w];

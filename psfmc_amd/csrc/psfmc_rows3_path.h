@@ -143,6 +143,14 @@ k_rows3_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip, c
     extern __shared__ __align__(16) double smem[];
     const int w = blockIdx.y;
     if (skip && skip[w]) return;                                      // (workgroup-uniform)
+#if PSFMC_FWD_PRIO_STAGGER
+    switch (((blockIdx.y * gridDim.x + blockIdx.x) / PSFMC_FWD_PRIO_STAGGER) & 3) {      // (the operand is an immediate)
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        case 3: __builtin_amdgcn_s_setprio(3); break;
+        default: break;
+    }
+#endif
     const int t = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     cd* tab = reinterpret_cast<cd*>(smem + (size_t)kRows3Waves * rows3_wave_lds_doubles<S>());
     rows3_fill_table<S>(tab, twx);

@@ -9,6 +9,12 @@
 //      exchange would give): 32 lines per instruction, 32 bytes each (from neighbouring lanes)
 //   3  four rows per wave, lanes t, t + 16, t + 32, t + 48 = the four rows of a group (nx = 512's pattern): 64 bytes
 //   4  plain contiguous stores (the write sweep)
+//   5  one row per wave, a lane's two elements ADJACENT ([kx][y][c]) but written by two instructions (16 bytes each):
+//      does anything merge the two half-sector writes of consecutive instructions?
+//   6  the column kernel's side of such a layout: a wave per (kx, c) column, 64 lanes = 64 consecutive y, elements 32
+//      bytes apart (the other component's wave fills the gaps) -- against 7, today's 64-byte runs (4 rows of one c)
+//   8  one row per wave, TODAY's layout, a lane pair shares a line: lane 2j writes (c = 0, r), lane 2j + 1 writes
+//      (c = 1, r) of the SAME kx in one instruction (16 bytes each, 64 bytes apart): 32 lines per instruction
 // Build: hipcc -O3 --offload-arch=gfx950 tools/store_pattern_probe.hip -o build/probe/store_pattern_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -35,6 +41,39 @@ __global__ void __launch_bounds__(256) k_store(double2* __restrict__ T, int N, i
     const int f = lane / LANES, t = lane % LANES;
     const int y = r0 + f;
     const size_t row_el = (size_t)((y >> 2) * 8 + (y & 3));     // c = 0 element of row y inside a kx column
+    if (MODE == 5) {
+        const size_t row2 = (size_t)y * 2;
+        for (int e = 0; e * 64 < nxh; ++e) {
+            const int kx = t + 64 * e;
+            if (kx < nxh) {
+                double2* o = base + kx * kstride + row2;
+                o[0] = val;
+                o[1] = val;
+            }
+        }
+        return;
+    }
+    if (MODE == 6 || MODE == 7) {
+        // column waves: wave id -> (kx, c); lane -> y = lane + 64 a
+        const int col = (blockIdx.x * 4 + wave);
+        if (col >= 2 * nxh) return;
+        const int kx = col >> 1, c = col & 1;
+        double2* cb = base + kx * kstride;
+        for (int a = 0; a * 64 < N; ++a) {
+            const int yy = lane + 64 * a;
+            const size_t el = MODE == 6 ? (size_t)yy * 2 + c : (size_t)((yy >> 2) * 8 + c * 4 + (yy & 3));
+            cb[el] = val;
+        }
+        return;
+    }
+    if (MODE == 8) {
+        for (int e = 0; e * 64 < nxh; ++e) {
+            const int kx_a = (t & ~1) + 64 * e, kx_b = (t | 1) + 64 * e;
+            if (kx_a < nxh) base[kx_a * kstride + row_el + 4 * (t & 1)] = val;
+            if (kx_b < nxh) base[kx_b * kstride + row_el + 4 * (t & 1)] = val;
+        }
+        return;
+    }
     if (MODE == 2) {
         // adjacent lanes write adjacent pieces: layout [kx][y][c]
         const size_t row2 = (size_t)y * 2;
@@ -57,7 +96,7 @@ __global__ void __launch_bounds__(256) k_store(double2* __restrict__ T, int N, i
 
 template <int MODE> static void run(double2* T, int N, int n_w, const char* what) {
     constexpr int ROWS = MODE == 1 ? 2 : MODE == 3 ? 4 : 1;
-    const dim3 grid(MODE == 4 ? 2048 / n_w + 1 : (N / ROWS + 3) / 4, n_w);
+    const dim3 grid(MODE == 4 ? 2048 / n_w + 1 : (MODE == 6 || MODE == 7) ? (2 * (N / 2 + 1) + 3) / 4 : (N / ROWS + 3) / 4, n_w);
     for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k_store<MODE>), grid, dim3(256), 0, 0, T, N, n_w);
     hipEvent_t a, b;
     CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -84,6 +123,10 @@ int main() {
         run<2>(T, N, n_w, "one row per wave: 32 bytes from neighbouring lanes");
         run<3>(T, N, n_w, "four rows per wave: 64 bytes from lanes 16 apart");
         run<4>(T, N, n_w, "contiguous");
+        run<5>(T, N, n_w, "one row per wave: 2 x 16 bytes of one sector, two instructions");
+        run<6>(T, N, n_w, "column waves: 16 bytes every 32 (layout [kx][y][c])");
+        run<7>(T, N, n_w, "column waves: 64-byte runs (today's layout)");
+        run<8>(T, N, n_w, "one row per wave: a lane pair writes c = 0 and c = 1 of one kx");
         CK(hipFree(T));
     }
     return 0;
