@@ -204,6 +204,17 @@ def test_general_sides_match_oracle(shape):
                 e_orc = float(np.abs(ref[fin].astype(np.longdouble) - exact[fin]).max())
                 e_gpu = float(np.abs(dev[kind][0][fin].astype(np.longdouble) - exact[fin]).max())
                 assert e_gpu <= 4.0 * e_orc + 1e-11 * scale, (shape, e_gpu / scale, e_orc / scale)
+        if max(shape) > 1024:
+            # sides above 1024: the posterior-image sums too (k_raster_sums with one row per wave, the forward row
+            # kernel's from-image form and the inverse kernel's image outputs of the three-stage family)
+            model.accumulate_samples(theta[:2])
+            post = model.collect_posterior_images()
+            for kind, ref in imgs.items():
+                fin = np.isfinite(ref)
+                scale = max(np.abs(ref[fin]).max(), 1e-300)
+                peak = np.nanmax(np.abs(imgs['raw_model']))
+                tol = 5e-9 * max(1.0, (peak / 2e3) ** 2) if kind == 'composite_ivm' else 1e-11
+                assert np.abs(post[kind][fin] - ref[fin]).max() <= tol * scale, (shape, kind, 'posterior')
     else:
         assert got[0] == -np.inf
     # the device-computed PSF spectra of this shape against numpy
