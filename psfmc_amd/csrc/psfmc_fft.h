@@ -95,6 +95,14 @@ PSFMC_FFT_SHAPE(128, 16, 8)
 PSFMC_FFT_SHAPE(256, 16, 16)
 PSFMC_FFT_SHAPE(512, 32, 16)
 PSFMC_FFT_SHAPE(1024, 32, 32)
+// Round 4, a survey of the shapes that leave many lanes idle (tools/side_costs.py with the alternative shape against
+// this table, same box; profiles/r4_shape_survey*_{base,alt}.jsonl): where the COLUMNS of a side run on the three-stage
+// engine anyway (fft3g_pick) the two-stage shape only serves the row kernels, and more lanes beat fewer registers --
+// 250: 10 x 25 (50 lanes) -> 25 x 10 (60): +10 % whole step; 264: 12 x 22 (44) -> 22 x 12 (60): +19 %; 286: 13 x 22 -> 22 x 13:
+// +19 %; 312: 13 x 24 -> 24 x 13: +15 %; 330: 15 x 22 -> 22 x 15: +9 %; 350: 14 x 25 -> 25 x 14: +9 %; 352: 16 x 22 -> 22 x 16: +17 %;
+// 416: 16 x 26 -> 26 x 16: +15 %.  Measured and left alone: 384, 390, 448, 480, 504, 576, 600, 672 (-8 ... +3 %), every small
+// side tried (110 ... 288: -1 ... -44 %: their two-stage COLUMN kernel pays for the registers) and the R = 40 shapes of 440,
+// 500, 520, 560 (-13 ... -14 %).
 // sides with factors 3 and 5 (any even side of this list runs on the fused kernels).  The
 // shapes keep R = max(P, ceil(P/T) T) small -- registers, hence waves per SIMD, are what the
 // memory-bound column kernel lives on -- at the price of a few idle lanes (T = 10, 15, 20, 30
@@ -109,7 +117,7 @@ PSFMC_FFT_SHAPE(180, 12, 15)
 PSFMC_FFT_SHAPE(192, 12, 16)
 PSFMC_FFT_SHAPE(200, 20, 10)
 PSFMC_FFT_SHAPE(240, 15, 16)
-PSFMC_FFT_SHAPE(250, 10, 25)
+PSFMC_FFT_SHAPE(250, 25, 10)
 PSFMC_FFT_SHAPE(288, 16, 18)
 PSFMC_FFT_SHAPE(300, 15, 20)
 PSFMC_FFT_SHAPE(320, 16, 20)
@@ -140,7 +148,7 @@ PSFMC_FFT_SHAPE(252, 14, 18)
 PSFMC_FFT_SHAPE(280, 14, 20)
 PSFMC_FFT_SHAPE(294, 14, 21)
 PSFMC_FFT_SHAPE(336, 16, 21)
-PSFMC_FFT_SHAPE(350, 14, 25)
+PSFMC_FFT_SHAPE(350, 25, 14)
 PSFMC_FFT_SHAPE(392, 14, 28)
 PSFMC_FFT_SHAPE(420, 20, 21)
 PSFMC_FFT_SHAPE(448, 16, 28)
@@ -163,15 +171,15 @@ PSFMC_FFT_SHAPE(176, 11, 16)
 PSFMC_FFT_SHAPE(208, 13, 16)
 PSFMC_FFT_SHAPE(220, 11, 20)
 PSFMC_FFT_SHAPE(260, 13, 20)
-PSFMC_FFT_SHAPE(264, 12, 22)
-PSFMC_FFT_SHAPE(286, 13, 22)
+PSFMC_FFT_SHAPE(264, 22, 12)
+PSFMC_FFT_SHAPE(286, 22, 13)
 PSFMC_FFT_SHAPE(308, 11, 28)
-PSFMC_FFT_SHAPE(312, 13, 24)
-PSFMC_FFT_SHAPE(330, 15, 22)
-PSFMC_FFT_SHAPE(352, 16, 22)
+PSFMC_FFT_SHAPE(312, 24, 13)
+PSFMC_FFT_SHAPE(330, 22, 15)
+PSFMC_FFT_SHAPE(352, 22, 16)
 PSFMC_FFT_SHAPE(364, 13, 28)
 PSFMC_FFT_SHAPE(390, 15, 26)
-PSFMC_FFT_SHAPE(416, 16, 26)
+PSFMC_FFT_SHAPE(416, 26, 16)
 PSFMC_FFT_SHAPE(440, 20, 22)
 PSFMC_FFT_SHAPE(484, 22, 22)
 PSFMC_FFT_SHAPE(520, 20, 26)

@@ -42,6 +42,11 @@ constexpr int kRows3RgLog2 = 2;
 //             900: 63.3 -> 42.3   (their two-stage kernels hold 26 ... 30 complex registers per lane: one wave per
 //             SIMD, or two with 72 ... 128 bytes of scratch); 630 / 650 / 700: 35.7 -> 40.7, 38.9 -> 44.1, 50.4 -> 48.8
 //             (two waves without much scratch: no gain); 512 / 1024: 32.1 -> 40.2, 33.8 -> 42.4 (SLOWER)
+//             second survey (profiles/r4_rows3_probe_survey.txt: every side with a three-stage column shape, two Sersic
+//             components): the inverse kernel alone gains 8 ... 28 % at 308, 330, 364, 384, 392, 440, 484, 500, 520, 560,
+//             572, 600, 660, 720, 832 -- but IN THE STEP (one component, tools/side_costs.py, default against PSFMC_ROWS3=0:
+//             profiles/r4_inv3_more_sides_*.jsonl) only 720 gains (+3.6 %); the others move -4.5 ... +1.0 %: a kernel that
+//             is faster alone but leaner in registers changes how the two lanes' kernels share the chip.  720 taken.
 //   forward   728: 62.9 -> 61.6   840: 64.8 -> 63.0   900: 71.2 -> 72.6   (even) and SLOWER everywhere else
 //             (630: 42.4 -> 58.7 ... 1024: 72.4 -> 94.5, 512: 46.5 -> 64.9): a wave's stores are 16-byte pieces of
 //             lines where the two-stage wave's are 32 ... 64 bytes, its store phase takes twice as long (26 vs 13.7 us
@@ -55,18 +60,25 @@ constexpr Fft3gPick rows3_pick(int n) {
         case 676: case 780: return {4, 13};
         case 728: case 784: case 840: return {4, 14};
         case 900: return {4, 15};
+        // second survey (every side with a three-stage column shape): the one more side whose whole step gains
+        case 720: return fft3g_pick(n);
 #if PSFMC_ROWS3_EXTRA
         case 512: case 1024: return {8, 8};
         case 650: case 700: return {5, 10};
         case 630: return {7, 9};
 #endif
+#if PSFMC_ROWS3_EXTRA > 1
+        default: return n > 256 ? fft3g_pick(n) : Fft3gPick{0, 0};      // (survey builds: every side with a three-stage shape)
+#else
         default: return {0, 0};
+#endif
     }
 }
 constexpr bool rows3_only_side(int n) { return n > 1024; }
 // the inverse kernel is the default where it measured faster; the forward kernel only where there is no other
 constexpr bool rows3_inv_default(int n) {
-    return rows3_only_side(n) || n == 676 || n == 728 || n == 780 || n == 784 || n == 840 || n == 900;
+    return rows3_pick(n).r2 > 0 && n != 512 && n != 1024 && n != 630 && n != 650 && n != 700 &&
+           (PSFMC_ROWS3_EXTRA < 2 || rows3_only_side(n));
 }
 constexpr bool rows3_fwd_built(int n) { return rows3_pick(n).r2 > 0 && (rows3_only_side(n) || PSFMC_ROWS3_EXTRA); }
 template <int NX> struct Rows3 {
