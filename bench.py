@@ -828,7 +828,7 @@ def multi_gpu_extras(args, torch, dist, world, rank, local, dev, gloo):
     for _ in sampler.sample(p0, iterations=64):
         pass
     per_iter = max((time.perf_counter() - t0) / 64, 1e-6)
-    n_iter = decide(32 * int(np.ceil(1.2 / per_iter / 32)))          # >= 1 s of iterations, rank 0's count for all
+    n_iter = decide(32 * int(np.ceil(1.5 / per_iter / 32)))          # >= 1 s of iterations, rank 0's count for all
     t0 = time.perf_counter()
     for _ in sampler.sample(p0, iterations=n_iter):
         pass

@@ -769,7 +769,7 @@ template <int NY> constexpr bool cols3g_side() { return Fft3gShape<NY>::kBuilt &
 
 // (sides above 1024 hold 18 ... 32 complex registers per lane in each of the two layouts: one wave per SIMD)
 template <int NY, bool CONVOLVE, class S = Fft3gShape<NY>>
-__global__ void __launch_bounds__(kColThreads, (S::R1 > 16 ? 1 : 2))
+__global__ void __launch_bounds__(kColThreads, (S::R1 > 16 ? 1 : 2))      // (1152 / 1280 at two waves: 140 ... 152 bytes of scratch)
 k_cols3g(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restrict__ prep,
          const uint8_t* __restrict__ skip, const cd* __restrict__ twy, int plen, int nxh, int n_w, int rg_log2) {
     constexpr int R1 = S::R1, R2 = S::R2, R3 = S::R3, L = S::L, NB3 = S::NB3, WPB = kColThreads / 64;
