@@ -36,7 +36,7 @@ constexpr int kRows3RgLog2 = 2;
 #define PSFMC_ROWS3_EXTRA 0         /* 1: also build the candidates below (tools/rows3_probe.hip; PSFMC_ROWS3=1 in the environment selects them) */
 #endif
 // Which sides have these kernels, and which take them by default, is by measurement (tools/rows3_probe.hip on an
-// MI355X, gpurun_out/r4_rows3_probe*.txt, same prep records, pass-sized batches, us per launch two-stage ->
+// MI355X, profiles/r4_rows3_probe_*.txt, same prep records, pass-sized batches, us per launch two-stage ->
 // three-stage):
 //   inverse   676: 48.2 -> 40.9   728: 53.9 -> 38.4   780: 52.7 -> 43.0   784: 57.6 -> 41.6   840: 55.8 -> 37.5
 //             900: 63.3 -> 42.3   (their two-stage kernels hold 26 ... 30 complex registers per lane: one wave per
@@ -51,7 +51,8 @@ constexpr int kRows3RgLog2 = 2;
 //             (630: 42.4 -> 58.7 ... 1024: 72.4 -> 94.5, 512: 46.5 -> 64.9): a wave's stores are 16-byte pieces of
 //             lines where the two-stage wave's are 32 ... 64 bytes, its store phase takes twice as long (26 vs 13.7 us
 //             at 1024^2 / 6 walkers, measured by compiling the phases out), and the table traffic per pixel doubles.
-// So: inverse kernels for the six sides above, both kernels for the sides above 1024 (nothing else reaches them).
+// So: the inverse kernel for the six sides above and 720, both kernels for the sides above 1024 (nothing else
+// reaches them).
 constexpr Fft3gPick rows3_pick(int n) {
     switch (n) {
         // sides above 1024: the only row kernels there are (the two-stage shapes end at P = T = 32)
@@ -77,8 +78,7 @@ constexpr Fft3gPick rows3_pick(int n) {
 constexpr bool rows3_only_side(int n) { return n > 1024; }
 // the inverse kernel is the default where it measured faster; the forward kernel only where there is no other
 constexpr bool rows3_inv_default(int n) {
-    return rows3_pick(n).r2 > 0 && n != 512 && n != 1024 && n != 630 && n != 650 && n != 700 &&
-           (PSFMC_ROWS3_EXTRA < 2 || rows3_only_side(n));
+    return rows3_only_side(n) || n == 676 || n == 720 || n == 728 || n == 780 || n == 784 || n == 840 || n == 900;
 }
 constexpr bool rows3_fwd_built(int n) { return rows3_pick(n).r2 > 0 && (rows3_only_side(n) || PSFMC_ROWS3_EXTRA); }
 template <int NX> struct Rows3 {
