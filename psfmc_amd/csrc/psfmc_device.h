@@ -395,6 +395,9 @@ __device__ __forceinline__ double fast_pow_tab(double x, const PowPoly& q, const
     return __builtin_fma(eb, d, eb);
 }
 
+#ifndef PSFMC_RASTER_RCP_PAIRS
+#define PSFMC_RASTER_RCP_PAIRS 0
+#endif
 // 2^y for finite |y| (any magnitude: ldexp saturates); no inf handling.
 __device__ __forceinline__ double fast_exp2_poly(double r);
 __device__ __forceinline__ double fast_exp2_noclamp(double y) {
@@ -634,10 +637,31 @@ __device__ __forceinline__ void raster_row(const double* __restrict__ prep, int 
             each([&](int j) { yy[j] -= nn[j]; sb[j] = __builtin_fma(kExp2Deg11[11], yy[j], kExp2Deg11[10]); });
 #pragma unroll
             for (int i = 9; i >= 0; --i) each([&](int j) { sb[j] = __builtin_fma(sb[j], yy[j], kExp2Deg11[i]); });
+#if PSFMC_RASTER_RCP_PAIRS
+            // experiment: ONE reciprocal per PAIR of pixels -- 1 / (a b), then 1 / a = b / (a b): v_rcp_f64 issues for
+            // four instructions, so a pair costs mul + rcp (4) + Newton (2) + 2 mul = 9 slots instead of 12
+            if constexpr (kG % 2 == 0) {
+                each([&](int j) { sb[j] = __builtin_amdgcn_ldexp(sb[j], (int)nn[j]); tt[j] *= gk; });
+#pragma unroll
+                for (int j = 0; j < kG; j += 2)
+                    if (g * kG + j + 1 < P) {
+                        const double ab = F.d2[j] * F.d2[j + 1];
+                        double rr2 = __builtin_amdgcn_rcp(ab);
+                        rr2 = __builtin_fma(rr2, __builtin_fma(-ab, rr2, 1.0), rr2);
+                        rc[j] = rr2 * F.d2[j + 1];
+                        rc[j + 1] = rr2 * F.d2[j];
+                    } else if (g * kG + j < P) {
+                        rc[j] = __builtin_amdgcn_rcp(F.d2[j]);
+                        rc[j] = __builtin_fma(rc[j], __builtin_fma(-F.d2[j], rc[j], 1.0), rc[j]);
+                    }
+            } else
+#endif
+            {
             each([&](int j) { sb[j] = __builtin_amdgcn_ldexp(sb[j], (int)nn[j]); rc[j] = __builtin_amdgcn_rcp(F.d2[j]); });
             // 1 / d2 with one Newton step (fast_rcp1); g^2 q / 12 = (gk t)^2 / rho2 * rho2 / d2: the elliptical
             // radius cancels
             each([&](int j) { rc[j] = __builtin_fma(rc[j], __builtin_fma(-F.d2[j], rc[j], 1.0), rc[j]); tt[j] *= gk; });
+            }
             each([&](int j) { tt[j] *= tt[j]; sb[j] *= sbeff; });
             each([&](int j) { r[g * kG + j] = __builtin_fma(sb[j], __builtin_fma(tt[j], rc[j], 1.0), r[g * kG + j]); });
         };

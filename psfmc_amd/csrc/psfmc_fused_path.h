@@ -84,7 +84,10 @@ template <int NX> constexpr int row_group() { return FftShape<NX>::TPW; }       
 #define PSFMC_RASTER_GROUP 4
 #endif
 #ifndef PSFMC_RASTER_GROUP_PLAIN
-#define PSFMC_RASTER_GROUP_PLAIN 1    /* the 512 / 1024 kernels; 2 (236 registers, no spills) measured +1.0 % / 0 % whole step: not taken */
+#define PSFMC_RASTER_GROUP_PLAIN 2    /* the 512 / 1024 kernels: two pixels per group (236 registers, no spills).  Round 4, same box, three
+                                         alternating runs (profiles/r4_g2_step_ab.txt): kernel alone 66.7 -> 62.7 us at 1024^2, 44.3 -> 42.5 at
+                                         512^2; whole step +0.7 % / +1.2 % (51.82 -> 52.17 k, 279.0 -> 282.2 k evals/s): small, consistent, taken
+                                         (round 3 read the same numbers as noise) */
 #endif
 template <int NX> constexpr int raster_group() {
     if (FftShape<NX>::kPlain && NX >= 512) return PSFMC_RASTER_GROUP_PLAIN;

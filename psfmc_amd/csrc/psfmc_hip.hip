@@ -351,6 +351,15 @@ struct psfmc_ctx {
     int n_streams = 2;
     int stagger = 0;          // the second lane starts one forward-row kernel late (run_pipeline); set per shape
     hipEvent_t ev_stagger[kMaxStreams] = {nullptr, nullptr, nullptr, nullptr};
+    // "exclusive" kernels (set_option "exclusive", bit 0 forward rows, bit 1 columns, bit 2 inverse rows): a kernel of
+    // that kind of pass i + 1 (the other lane) waits for the same kind of pass i, so that the two lanes never run two
+    // like kernels side by side -- a VALU-bound forward kernel then always meets the other lane's memory-bound ones.
+    // Measured (round 4, profiles/r4_exclusive.txt): SLOWER in every combination, 1024^2 50.3 k -> 43.7 ... 46.4 k
+    // evals/s, 512^2 268 k -> 249 ... 266 k: the lanes spend half their time like against like by themselves
+    // (profiles/r4_lane_timeline_*.txt: forward + forward alone 32 % of the wall time at 1024^2) and that is the
+    // better state -- two forward launches side by side are three whole rounds of row waves.  Off.
+    int exclusive = 0;
+    hipEvent_t ev_excl[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
     bool t_f32 = false;       // T stored as complex64 (set_option "storage_f32"); arithmetic stays fp64
     bool plain_shape = false; // both sides power-of-two shapes (what storage_f32 is built for)
     bool row_fast = false;    // nx a power-of-two shape and ny a whole number of its row workgroups
@@ -1104,6 +1113,8 @@ static int ctx_init(psfmc_ctx* c, const double* sci, const double* obs_var, cons
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     for (int i = 0; i < psfmc_ctx::kMaxStreams; ++i) HIP_TRY(hipEventCreateWithFlags(&c->ev_stagger[i], hipEventDisableTiming));
+    for (int k = 0; k < 3; ++k)
+        for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreateWithFlags(&c->ev_excl[k][i], hipEventDisableTiming));
     for (int i = 1; i < psfmc_ctx::kMaxStreams; ++i) {
         HIP_TRY(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
@@ -1415,6 +1426,9 @@ extern "C" int psfmc_ctx_destroy(psfmc_ctx* c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     for (int i = 0; i < psfmc_ctx::kMaxStreams; ++i)
         if (c->ev_stagger[i]) (void)hipEventDestroy(c->ev_stagger[i]);
+    for (int k = 0; k < 3; ++k)
+        for (int i = 0; i < 2; ++i)
+            if (c->ev_excl[k][i]) (void)hipEventDestroy(c->ev_excl[k][i]);
     delete c;
     return PSFMC_OK;
 }
@@ -1460,6 +1474,10 @@ extern "C" int psfmc_set_option(psfmc_ctx* c, const char* key, double value) {
     }
     if (!strcmp(key, "stagger")) {
         c->stagger = (int)value;
+        return PSFMC_OK;
+    }
+    if (!strcmp(key, "exclusive")) {
+        c->exclusive = (int)value & 7;
         return PSFMC_OK;
     }
     if (!strcmp(key, "linear_accumulation")) {
@@ -1536,6 +1554,7 @@ extern "C" double psfmc_get_option(const psfmc_ctx* cc, const char* key) {
     if (!strcmp(key, "cols_grid")) return c->cols_grid;
     if (!strcmp(key, "streams")) return c->n_streams;
     if (!strcmp(key, "stagger")) return c->stagger;
+    if (!strcmp(key, "exclusive")) return c->exclusive;
     if (!strcmp(key, "linear_accumulation")) return c->linear_acc ? 1.0 : 0.0;
     return NAN;
 }
@@ -1623,6 +1642,28 @@ static int run_pipeline(psfmc_ctx* c, int W, const uint8_t* d_skip, hipStream_t 
                 HIP_TRY(hipEventRecord(c->ev_stagger[pass], s));
                 HIP_TRY(hipStreamWaitEvent(c->side[pass + 1], c->ev_stagger[pass], 0));
                 RC_TRY(fused_cols(c, n, Tbuf, prep, skip, s));
+            } else if (c->exclusive && lanes == 2) {
+                // kind k of this pass starts only when kind k of the previous pass (the other lane) has finished
+                auto gate = [&](int k) -> int {
+                    if ((c->exclusive >> k) & 1) {
+                        if (pass > 0) HIP_TRY(hipStreamWaitEvent(s, c->ev_excl[k][(pass - 1) & 1], 0));
+                    }
+                    return PSFMC_OK;
+                };
+                auto done = [&](int k) -> int {
+                    if ((c->exclusive >> k) & 1) HIP_TRY(hipEventRecord(c->ev_excl[k][pass & 1], s));
+                    return PSFMC_OK;
+                };
+                RC_TRY(gate(0));
+                RC_TRY(fused_rows_fwd(c, n, Tbuf, prep, skip, 0, nullptr, s));
+                RC_TRY(done(0));
+                RC_TRY(gate(1));
+                RC_TRY(fused_cols(c, n, Tbuf, prep, skip, s));
+                RC_TRY(done(1));
+                RC_TRY(gate(2));
+                RC_TRY(fused_inverse(c, n, Tbuf, prep, skip, partial, nullptr, nullptr, s));
+                RC_TRY(done(2));
+                continue;
             } else {
                 RC_TRY(fused_forward(c, n, Tbuf, prep, skip, 0, nullptr, s));
             }

@@ -13,7 +13,7 @@ for r in rows:
     name = r['Kernel_Name'].split('psfmc::')[1].split('<')[0].split('(')[0]
     ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Queue_Id'], name))
 ev.sort()
-pipe = [e for e in ev if e[3] in ('k_rows_fwd', 'k_cols', 'k_cols3', 'k_rows_inv')]
+pipe = [e for e in ev if e[3] in ('k_rows_fwd', 'k_cols', 'k_cols3', 'k_cols3g', 'k_cols3f', 'k_rows_inv', 'k_rows3_fwd', 'k_rows3_inv')]
 # batches are separated by k_theta_prep
 starts = [e[0] for e in ev if e[3] == 'k_theta_prep']
 if len(starts) < 4:
