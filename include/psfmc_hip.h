@@ -334,9 +334,13 @@ int psfmc_get_spectra(psfmc_ctx* ctx, double* psf_spec, double* var_spec);
  * complex64 while every operation stays fp64 -- half the memory traffic; the log-posterior is
  * then good to ~1e-7 relative, the class of the reference's own float32 raw-model accumulator
  * (psfMC/models.py:249), not an fp64 result.  Power-of-two sides, fused back end only.
- * "cols3" (0 / 1 / 2, default 1): which column kernel runs -- 0 the two-stage engine everywhere, 1 the wave-wide
- * three-stage engines where they measured faster (k_cols3 at 512 / 1024, k_cols3g at the sides of
- * psfmc_fft.h fft3g_pick), 2 k_cols3g at 512 / 1024 as well; results agree to rounding.
+ * "cols3" (0 ... 4, default 1): which column kernel runs -- 0 the two-stage engine wherever a side has one, 1 the
+ * wave-wide three-stage engines where they measured faster (round 4: k_cols3f at 512 / 1536 / 2048, k_cols3 at
+ * 1024, k_cols3g at the other sides of psfmc_fft.h fft3g_pick), 2 k_cols3g at those four as well, 3 round 3's
+ * k_cols3 at 512 too, 4 k_cols3f at 1024 too; results agree to rounding.  Sides above 1024 have only the
+ * three-stage kernels.
+ * "exclusive" (bits 0 / 1 / 2 = forward rows / columns / inverse rows, default 0): chain the two passes in flight so
+ * that two kernels of that kind never run side by side (measurement knob; slower in every combination).
  * "speculate" (device sampler, psfmc_stretch_run): ensembles of up to 2 n walkers run ONE pipeline pass per
  * iteration -- the first half's proposals and both candidate proposals of every second-half walker (partner
  * moved / partner stayed) -- instead of two half-steps; the chain is the same bit for bit.  0 never, n > 0 that
@@ -345,7 +349,11 @@ int psfmc_get_spectra(psfmc_ctx* ctx, double* psf_spec, double* var_spec);
  * transforms of more than 256 pixels per row --, 0: log2 + exp2 per pixel; a property of the transform shape),
  * "transform_ny" / "transform_nx" (the transform shape: the image's own, or the built sides an
  * image of unbuilt sides is embedded in), "speculated_runs", "graph_launches", "row_group",
- * "partials_per_walker". */
+ * "partials_per_walker", "column_engine" (the column kernel this context launches now: 0 k_cols, 1 k_cols3, 2
+ * k_cols3g, 3 k_cols3f), "rows3" (bit 0 / bit 1: the forward / inverse row kernel is the one-row-per-wave
+ * three-stage one of csrc/psfmc_rows3_path.h -- both above 1024, the inverse one at seven general sides; the
+ * environment variable PSFMC_ROWS3 = 1 / 0, read at context creation, forces every built one / none: A/B runs).
+ */
 int psfmc_set_option(psfmc_ctx* ctx, const char* key, double value);
 double psfmc_get_option(const psfmc_ctx* ctx, const char* key);
 
