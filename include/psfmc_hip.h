@@ -335,10 +335,9 @@ int psfmc_get_spectra(psfmc_ctx* ctx, double* psf_spec, double* var_spec);
  * then good to ~1e-7 relative, the class of the reference's own float32 raw-model accumulator
  * (psfMC/models.py:249), not an fp64 result.  Power-of-two sides, fused back end only.
  * "cols3" (0 ... 4, default 1): which column kernel runs -- 0 the two-stage engine wherever a side has one, 1 the
- * wave-wide three-stage engines where they measured faster (round 4: k_cols3f at 512 / 1536 / 2048, k_cols3 at
- * 1024, k_cols3g at the other sides of psfmc_fft.h fft3g_pick), 2 k_cols3g at those four as well, 3 round 3's
- * k_cols3 at 512 too, 4 k_cols3f at 1024 too; results agree to rounding.  Sides above 1024 have only the
- * three-stage kernels.
+ * wave-wide three-stage engines where they measured faster (round 4: k_cols3f at 512 / 1024 / 1536 / 2048, k_cols3g
+ * at the other sides of psfmc_fft.h fft3g_pick), 2 k_cols3g at those four as well, 3 round 3's k_cols3 at 512 and
+ * 1024, 4 the same as 1; results agree to rounding.  Sides above 1024 have only the three-stage kernels.
  * "exclusive" (bits 0 / 1 / 2 = forward rows / columns / inverse rows, default 0): chain the two passes in flight so
  * that two kernels of that kind never run side by side (measurement knob; slower in every combination).
  * "speculate" (device sampler, psfmc_stretch_run): ensembles of up to 2 n walkers run ONE pipeline pass per

@@ -856,10 +856,25 @@ template <class S> constexpr bool cols3f_shape() { return S::kBuilt && S::R2 == 
 template <class S> constexpr size_t fused_col3f_lds_bytes() {
     return ((size_t)(kColThreads / 64) * fft3g_lds_doubles<S>() + (size_t)S::R1 * 64 * 2) * sizeof(double);
 }
+// The load pipeline (the next column of a wave loaded into a second register set while the current one goes through its
+// inverse transform and its stores, as in k_cols) is decided per side by the WHOLE STEP, not by the kernel alone, which it
+// makes faster everywhere (512: 38.5 -> 36.5 us, 1024: 49.7 -> 47.4, 1536: 62 -> 56, 2048: 70 -> 55): step 512^2 -1.0 %,
+// 1024^2 +0.5 % (and then +0.5 % over k_cols3<1024>), 1536^2 -7 % (the second set costs the second workgroup of a CU),
+// 2048^2 +5.4 % (one wave per SIMD either way).  profiles/r4_cols3f_prefetch.txt, r4_cols3f_prefetch_step_ab.txt.
+// PSFMC_COLS3F_PREFETCH: -1 per side (1024, 2048), 0 nowhere, 1 everywhere.
+#ifndef PSFMC_COLS3F_PREFETCH
+#define PSFMC_COLS3F_PREFETCH -1
+#endif
 #ifndef PSFMC_COLS3F_WAVES16
 #define PSFMC_COLS3F_WAVES16 3
 #endif
-template <class S> constexpr int cols3f_min_waves() { return S::R1 <= 8 ? 4 : S::R1 <= 16 ? PSFMC_COLS3F_WAVES16 : S::R1 <= 24 ? 2 : 1; }
+template <class S> constexpr bool cols3f_prefetch() {
+    return PSFMC_COLS3F_PREFETCH < 0 ? (S::R1 == 16 || S::R1 == 32) : PSFMC_COLS3F_PREFETCH != 0;
+}
+template <class S> constexpr int cols3f_min_waves() {
+    if (cols3f_prefetch<S>()) return S::R1 <= 8 ? 3 : S::R1 <= 16 ? 2 : 1;       // (a second register set for the next column)
+    return S::R1 <= 8 ? 4 : S::R1 <= 16 ? PSFMC_COLS3F_WAVES16 : S::R1 <= 24 ? 2 : 1;
+}
 
 template <int NY, bool CONVOLVE, class S = Fft3gShape<NY>>
 __global__ void __launch_bounds__(kColThreads, (cols3f_min_waves<S>()))
@@ -885,6 +900,63 @@ k_cols3f(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restr
     const int n_cols = n_w * 2 * nxh;
     const int nyp = t_col_len(NY, rg_log2);
     const GroupRange gr = xcd_group_range((n_cols + WPB - 1) / WPB);
+    // cols3f_prefetch: the next column of this wave is loaded into a second register set while the current one
+    // goes through its inverse transform and its stores (k_cols' load pipeline)
+    auto locate = [&](int grp, int& w, int& kx, int& c, bool& live) -> cd* {
+        int col = grp * WPB + wave;
+        live = col < n_cols;
+        col = live ? col : n_cols - 1;
+        c = col & 1;
+        const int pr = col >> 1;
+        kx = pr / n_w;
+        w = pr - kx * n_w;
+        if (live && skip && skip[w]) live = false;
+        return Tbuf + ((size_t)w * nxh + kx) * 2 * nyp + (c << rg_log2) + off_t;
+    };
+    if constexpr (cols3f_prefetch<S>() && CONVOLVE) {
+        cd nxt[R1];
+        int w_n, kx_n, c_n;
+        bool live_n = false;
+        cd* base_n = Tbuf;
+        if (gr.first < gr.end) {
+            base_n = locate(gr.first, w_n, kx_n, c_n, live_n);
+#pragma unroll
+            for (int a = 0; a < R1; ++a) nxt[a] = load_stream(base_n + 128 * a);
+        }
+        for (int grp = gr.first; grp < gr.end; grp += gr.step) {
+            cd v[R1];
+#pragma unroll
+            for (int a = 0; a < R1; ++a) v[a] = nxt[a];
+            cd* base = base_n;
+            const int w = w_n, kx = kx_n, c = c_n;
+            const bool live = live_n;
+            cd o[NB3][8];
+            fft_wave3g<S, -1>(v, o, w2, t, lds, tab);
+            __builtin_amdgcn_sched_barrier(0);
+            const int psf = live ? (int)prep[(size_t)w * plen + kPrepPsfIdx] : 0;
+            const cd* k = Kt + (((size_t)psf * nxh + kx) * 2 + c) * NY + t;
+#pragma unroll
+            for (int q = 0; q < NB3; ++q)
+#pragma unroll
+                for (int k3 = 0; k3 < 8; ++k3) v[q + NB3 * k3] = cmul(o[q][k3], k[64 * (q + NB3 * k3)]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (grp + gr.step < gr.end) {
+                base_n = locate(grp + gr.step, w_n, kx_n, c_n, live_n);
+#pragma unroll
+                for (int a = 0; a < R1; ++a) nxt[a] = load_stream(base_n + 128 * a);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            fft_wave3g<S, +1>(v, o, w2, t, lds, tab);
+            __builtin_amdgcn_sched_barrier(0);
+            if (live) {
+#pragma unroll
+                for (int q = 0; q < NB3; ++q)
+#pragma unroll
+                    for (int k3 = 0; k3 < 8; ++k3) base[128 * (q + NB3 * k3)] = o[q][k3];
+            }
+        }
+        return;
+    }
     for (int grp = gr.first; grp < gr.end; grp += gr.step) {
         const int col = grp * WPB + wave;
         if (col >= n_cols) continue;                     // wave-uniform

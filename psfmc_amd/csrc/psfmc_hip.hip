@@ -590,11 +590,12 @@ static int launch_cols(psfmc_ctx* c, void* Tvoid, int n_w, const double* prep, c
     const int n_cols = n_w * 2 * c->nxh;
     if constexpr (cols3f_shape<Fft3gShape<NY>>() && sizeof(TS) == sizeof(cd)) {
         // ny = 8 m x 64 (512, 1024, 1536, 2048): the general three-stage engine run forward both ways (round 4).
-        // In the flow (same box, whole step): 512^2 +1.6 %, 1536^2 +18 %, 2048^2 +2 %; at 1024 its third wave per
-        // SIMD measured SLOWER than k_cols3 (57.5 vs 52.7 us per 6-walker pass, step -0.8 %: 6 MB of columns in
-        // flight per XCD against a 4-MiB L2 that also has to hold the kernel-spectrum columns), so 1024 keeps
-        // k_cols3 unless cols3 = 4 asks for this one
-        if ((c->cols3 == 1 && NY != 1024) || c->cols3 == 4) {
+        // In the flow (same box, whole step): 512^2 +1.6 %, 1536^2 +18 %, 2048^2 +2 % (+5.4 % more with its load
+        // pipeline, cols3f_prefetch); at 1024 its third wave per SIMD measured SLOWER than k_cols3 (57.5 vs 52.7 us
+        // per 6-walker pass, step -0.8 %: 6 MB of columns in flight per XCD against a 4-MiB L2 that also has to hold
+        // the kernel-spectrum columns), with the load pipeline at two waves per SIMD it is the faster one (51.4 vs
+        // 52.6 us in the flow, step +0.5 %).  cols3 = 3 asks for k_cols3 at 512 / 1024
+        if (c->cols3 == 1 || c->cols3 == 4) {
             using S3 = Fft3gShape<NY>;
             constexpr size_t lds3 = fused_col3f_lds_bytes<S3>();
             static thread_local int attr3f_device = -1;
@@ -612,7 +613,7 @@ static int launch_cols(psfmc_ctx* c, void* Tvoid, int n_w, const double* prep, c
         }
     }
     if constexpr (NY == 512 || NY == 1024) {          // long power-of-two columns: wave-wide three-stage engine
-        if (c->cols3 == 3 || (c->cols3 == 1 && NY == 1024) || (c->cols3 && sizeof(TS) != sizeof(cd))) {
+        if (c->cols3 == 3 || (c->cols3 && sizeof(TS) != sizeof(cd))) {
             constexpr size_t lds3 = fused_col3_lds_bytes<NY>();
             const int per_block = kColThreads / 64;
             const int blocks = (n_cols + per_block - 1) / per_block;
@@ -662,10 +663,10 @@ static int launch_cols(psfmc_ctx* c, void* Tvoid, int n_w, const double* prep, c
 // which column kernel launch_cols takes for this context: 0 k_cols, 1 k_cols3, 2 k_cols3g, 3 k_cols3f (the same conditions)
 template <int NY> static int col_engine_code(const psfmc_ctx* c) {
     if constexpr (cols3f_shape<Fft3gShape<NY>>()) {
-        if (((c->cols3 == 1 && NY != 1024) || c->cols3 == 4) && !c->t_f32) return 3;
+        if ((c->cols3 == 1 || c->cols3 == 4) && !c->t_f32) return 3;
     }
     if constexpr (NY == 512 || NY == 1024) {
-        if (c->cols3 == 3 || (c->cols3 == 1 && NY == 1024) || (c->cols3 && c->t_f32)) return 1;
+        if (c->cols3 == 3 || (c->cols3 && c->t_f32)) return 1;
     }
     if constexpr (cols3g_side<NY>()) {
         if (!c->t_f32 && c->cols3 && cols3g_layout_ok<Fft3gShape<NY>>(c->rg_log2)) return 2;

@@ -48,13 +48,11 @@ for _sides, _shape in (((264, 308, 352, 484), (4, 11)), ((384, 528, 576), (4, 12
 
 def column_engine(ny):
     """Which column kernel the fused back end launches for transform side `ny` (psfmc_hip.hip
-    launch_cols): 'k_cols3f' (512, 1536, 2048: the general three-stage engine run forward both ways), 'k_cols3'
-    (1024: round 3's power-of-two three-stage kernel), 'k_cols3g' (the
+    launch_cols): 'k_cols3f' (512, 1024, 1536, 2048: the general three-stage engine run forward both ways; round 3's
+    power-of-two kernel 'k_cols3' remains behind option cols3 = 3 and for storage='f32'), 'k_cols3g' (the
     sides psfmc_fft.h fft3g_pick lists: ny = R1 * R2 * R3 on R2 * R3 <= 64 lanes) or 'k_cols' (the
     two-stage engine).  Returns (kernel name, (R1, R2, R3) or None)."""
-    if ny == 1024:
-        return 'k_cols3', None
-    if ny in (512, 1536, 2048):
+    if ny in (512, 1024, 1536, 2048):
         return 'k_cols3f', (ny // 64, 8, 8)
     if ny in _COLS3G_SHAPES:
         r2, r3 = _COLS3G_SHAPES[ny]

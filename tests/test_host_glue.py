@@ -242,9 +242,7 @@ def test_side_tables_agree_between_python_and_the_kernels():
     assert picks and set(picks) <= set(engine.FUSED_SIDES)
     for n in engine.FUSED_SIDES:
         name, shape = engine.column_engine(n)
-        if n == 1024:
-            assert name == 'k_cols3' and picks[n] == (8, 8)
-        elif n in (512, 1536, 2048):
+        if n in (512, 1024, 1536, 2048):
             assert name == 'k_cols3f' and picks[n] == (8, 8) and shape == (n // 64, 8, 8)
         elif n in picks:
             r2, r3 = picks[n]
