@@ -463,6 +463,45 @@ class Watchdog(object):
         os._exit(4)
 
 
+class Salvage(object):
+    """Deadline around the side figures of a multi-rank run (collectives the timed region did not use): when they
+    overrun, rank 0 prints the headline line it already holds -- with the overrun named under `multi_gpu` -- and
+    every rank leaves with code 0, so that a hang in a side figure cannot cost the measured headline."""
+
+    def __init__(self, rank, seconds):
+        import threading
+        self.rank, self.seconds, self.line = rank, seconds, None
+        self._timer = threading.Timer(seconds, self._expired)
+        self._timer.daemon = True
+
+    def arm(self, line):
+        self.line = line
+        self._timer.start()
+
+    def _expired(self):
+        if self.rank == 0 and self.line is not None:
+            self.line['multi_gpu'] = {'error': 'timeout', 'limit_s': self.seconds,
+                                      'note': 'the side figures of the sharded paths did not finish; the headline '
+                                              'above was measured before they started'}
+            print(json.dumps(self.line), flush=True)
+        os._exit(0)
+
+    def done(self):
+        self._timer.cancel()
+
+
+def guarded(name, fn, *a, **kw):
+    """A side figure must not cost the headline: an exception becomes an `error` entry under its key (and a line
+    on stderr)."""
+    try:
+        return fn(*a, **kw)
+    except Exception as exc:               # noqa: BLE001 -- whatever it was, name it and go on
+        import traceback
+        traceback.print_exc()
+        sys.stderr.write('bench.py: side figure %s failed: %r\n' % (name, exc))
+        return {'error': type(exc).__name__, 'message': str(exc)[:400]}
+
+
 def spawn_ranks(args, argv):
     """`bench.py --gpus N` outside a torch.distributed launch: start the N ranks as a child
     process (this process has not touched the GPU), relay the output, return its exit code."""
@@ -912,6 +951,9 @@ def main():
     ap.add_argument('--no-multi', action='store_true', help="skip the sharded paths' side figures (multi_gpu)")
     ap.add_argument('--config4-walkers', type=int, default=2048, help='walkers of the strong-scaled config 4')
     ap.add_argument('--config5-fields', type=int, default=64, help='fields of config 5, dealt to the ranks')
+    ap.add_argument('--extras-timeout', type=float, default=420.0,
+                    help='N > 1: seconds the multi_gpu side figures may take before rank 0 prints the headline line '
+                         'without them and every rank leaves')
     args = ap.parse_args()
     if args.cpu_worker >= 0:
         return cpu_worker(args)
@@ -1047,17 +1089,7 @@ def main():
     kernels = []
     if rank == 0 and args.backend == 'fused':
         kernels = kernel_profile(eng, args, one_batch, torch, dev, max(2, min(args.steps, 5)))
-    # the sharded paths' side figures: every rank takes part (rank 0 comes from its profile pass)
-    multi = None
-    if world > 1:
-        stream_cm.__exit__(None, None, None)
-        dist.barrier()
-    if not args.no_multi and not args.no_extras and args.backend == 'fused':
-        t0 = time.perf_counter()
-        multi = multi_gpu_extras(args, torch, dist, world, rank, local, dev, gloo)
-        if multi is not None:
-            multi['wall_s'] = time.perf_counter() - t0
-
+    line = None
     if rank == 0:
         evals_per_step = args.walkers * args.batches
         total_evals = evals_per_step * world * args.steps
@@ -1125,6 +1157,24 @@ def main():
             line['kernels'] = kernels
         else:
             line['roofline'] = step_roof
+    # the sharded paths' side figures: every rank takes part (rank 0 comes from its profile pass).  With N > 1 they
+    # run under a deadline that prints the headline line as it stands if they hang
+    multi = None
+    if world > 1:
+        stream_cm.__exit__(None, None, None)
+        dist.barrier()
+    if not args.no_multi and not args.no_extras and args.backend == 'fused':
+        t0 = time.perf_counter()
+        salvage = None
+        if world > 1:
+            salvage = Salvage(rank, args.extras_timeout)
+            salvage.arm(line)
+        multi = guarded('multi_gpu', multi_gpu_extras, args, torch, dist, world, rank, local, dev, gloo)
+        if salvage is not None:
+            salvage.done()
+        if multi is not None:
+            multi['wall_s'] = time.perf_counter() - t0
+    if rank == 0:
         if world == 1 and not args.no_extras:
             # side figures: likelihood only from pre-derived rows (round 1's headline), the
             # Python entry point with host vectors, small ensembles
@@ -1192,10 +1242,10 @@ def main():
             line['multi_gpu'] = multi
         if world == 1 and not args.no_configs and not args.no_extras and args.backend == 'fused':
             t0 = time.perf_counter()
-            line['configs'] = other_configs(args, torch, dev, local)
+            line['configs'] = guarded('configs', other_configs, args, torch, dev, local)
             line['configs']['wall_s'] = time.perf_counter() - t0
         if world == 1 and not args.no_example:
-            ex = example_model_rate()
+            ex = guarded('example_model_256_walkers', example_model_rate)
             if ex:
                 line['example_model_256_walkers'] = ex
         if not args.no_cpu and world == 1:      # CPU baseline: rank 0 at N = 1 only
@@ -1217,6 +1267,11 @@ def main():
             assert np.array_equal(np.isfinite(got), fin), 'GPU and oracle disagree on finiteness'
             line['check_vs_cpu_rel'] = float(np.max(np.abs(got[fin] - ref[fin]) / np.abs(ref[fin])))
         print(json.dumps(line))
+    if world > 1 and isinstance(multi, dict) and 'error' in multi:
+        # a side figure failed on this rank: the other ranks may sit in one of its collectives until their own
+        # deadline; the line is out, leave without another collective
+        sys.stdout.flush()
+        os._exit(0)
     model.close()
     if world > 1:
         dist.barrier()
