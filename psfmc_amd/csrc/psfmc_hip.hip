@@ -751,13 +751,13 @@ template <int NX> static int pack_field(psfmc_ctx* c, int f) {
 // per-side constants of the row kernels the context will launch (rows3: the three-stage family)
 template <int NX> static RowShape row_shape_of(bool rows3) {
     if constexpr (rows3_side<NX>()) {
-        if (rows3 || !two_stage_side(NX)) return RowShape{1, kRows3Waves, kRows3RgLog2, Rows3<NX>::S::R1, false};
+        if (rows3 || !two_stage_side(NX)) return RowShape{1, kRows3Waves, rows3_rg_log2(NX), Rows3<NX>::S::R1, false};
     }
     if constexpr (two_stage_side(NX))
         return RowShape{row_group<NX>(), row_waves<NX, true>(), layout_rg_log2<NX, true>(), FftShape<NX>::R,
                         FftShape<NX>::kPlain};
     else
-        return RowShape{1, kRows3Waves, kRows3RgLog2, 0, false};
+        return RowShape{1, kRows3Waves, rows3_rg_log2(NX), 0, false};
 }
 // bit 0: a two-stage family exists; bit 1: the three-stage inverse kernel is built; bit 2: the forward one;
 // bit 3: the three-stage inverse kernel is the default
@@ -1344,7 +1344,7 @@ static int ctx_create_impl(psfmc_ctx** out, int device, int ny, int nx, int n_fi
         // the power-of-two row kernels run without row guards: whole workgroups of rows only;
         // any other ny takes the guarded code path of the same shape (layout groups of 4 rows)
         c->row_fast = !rows3_fwd && !rows3_inv && rs.plain && ny % (rs.rg * rs.fast_waves) == 0;
-        c->rg_log2 = c->row_fast ? rs.fast_rg_log2 : 2;
+        c->rg_log2 = c->row_fast ? rs.fast_rg_log2 : (rows3_fwd || rows3_inv) ? rows3_rg_log2(nx) : 2;   // (rows3: 2; 0 above 1024)
         c->nyp = t_col_len(ny, c->rg_log2);
         RowShape cs{};
         RC_TRY(row_shape_for(ny, &cs));

@@ -27,9 +27,20 @@
 
 namespace psfmc {
 
-constexpr int kRows3Waves = 4;                        // = rows of a layout group
+constexpr int kRows3Waves = 4;                        // rows of a workgroup (= one layout group of the general sides)
 constexpr int kRows3Threads = 64 * kRows3Waves;
-constexpr int kRows3RgLog2 = 2;
+// Layout groups.  The sides that also have two-stage row kernels share their guarded layout: groups of 4 rows,
+// [kx][yg][c][r].  The sides above 1024 have no other row kernels and take groups of ONE row, [kx][y][c]: the two
+// components of a (kx, y) are then 32 adjacent bytes, and a lane PAIR (kx even / odd) trades one value so that every
+// store (load) instruction moves whole 32-byte sectors -- one lane the c = 0 half, its neighbour the c = 1 half --
+// instead of 16-byte pieces of two sectors 64 bytes apart: the memory system charges per sector touched, 2.6 TB/s for
+// 16-byte pieces against 5.1 TB/s for 32-byte ones (tools/store_pattern_probe.hip, profiles/r4_store_pattern_probe.txt;
+// the column kernels then see 16 bytes every 32: 5.4 against 6.4 TB/s there).  PSFMC_ROWS3_BIG_RG_LOG2 = 2 builds the
+// old form for comparison.
+#ifndef PSFMC_ROWS3_BIG_RG_LOG2
+#define PSFMC_ROWS3_BIG_RG_LOG2 0
+#endif
+constexpr int rows3_rg_log2(int n) { return n > 1024 ? PSFMC_ROWS3_BIG_RG_LOG2 : 2; }
 
 // the row shape of a side: {R2, R3}, R1 = nx / (R2 R3); {0, 0} = the side has no three-stage row kernels
 #ifndef PSFMC_ROWS3_EXTRA
@@ -133,6 +144,21 @@ __global__ void k_pack_field3(const double* __restrict__ sci, const double* __re
     }
 }
 
+// the value of the neighbouring lane (lane ^ 1): DPP quad_perm [1, 0, 3, 2] on the two halves of a double
+__device__ __forceinline__ double swap_adjacent_lanes(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    int lo = (int)b, hi = (int)(b >> 32);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+// a lane pair's trade: the even lane gives `from_even` and the odd lane `from_odd`; each gets the other's
+__device__ __forceinline__ cd pair_trade(bool odd, cd from_even, cd from_odd) {
+    const double sx = odd ? from_odd.x : from_even.x, sy = odd ? from_odd.y : from_even.y;
+    return cd{swap_adjacent_lanes(sx), swap_adjacent_lanes(sy)};
+}
+__device__ __forceinline__ cd pick(bool second, cd a, cd b) { return cd{second ? b.x : a.x, second ? b.y : a.y}; }
+
 // the workgroup's stage-1 twiddle table [k1][lane] = W_N^(lane k1) (zero for the lanes past L)
 template <class S>
 __device__ __forceinline__ void rows3_fill_table(cd* __restrict__ tab, const cd* __restrict__ twx) {
@@ -151,7 +177,9 @@ k_rows3_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip, c
             const double* __restrict__ img_scale, double* __restrict__ raw_out, WrapDesc wr, int pow_mode) {
     static_assert(pow_tabs_side(NX), "the three-stage row kernels rasterise with the power tables");
     constexpr int R1 = S::R1, R2 = S::R2, R3 = S::R3, L = S::L, NB3 = S::NB3;
-    constexpr int NXH = NX / 2 + 1, RGL = 1 << kRows3RgLog2;
+    constexpr int RGL2 = rows3_rg_log2(NX), NXH = NX / 2 + 1, RGL = 1 << RGL2;
+    constexpr bool kPair = RGL2 == 0 && L == 64;                      // lane pairs store whole sectors (see rows3_rg_log2)
+    static_assert(!kPair || (R1 * R2) % 2 == 0, "lane pairs hold outputs together");
     extern __shared__ __align__(16) double smem[];
     const int w = blockIdx.y;
     if (skip && skip[w]) return;                                      // (workgroup-uniform)
@@ -167,7 +195,7 @@ k_rows3_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip, c
     cd* tab = reinterpret_cast<cd*>(smem + (size_t)kRows3Waves * rows3_wave_lds_doubles<S>());
     rows3_fill_table<S>(tab, twx);
     double* wave_lds = smem + (size_t)wave * rows3_wave_lds_doubles<S>();
-    const int iy = blockIdx.x * RGL + wave;
+    const int iy = blockIdx.x * kRows3Waves + wave;
     const bool row_in = iy < ny;                                      // wave-uniform
     const bool lane_in = L == 64 || t < L;
     const int tl = lane_in ? t : 0;
@@ -241,10 +269,38 @@ k_rows3_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip, c
             if (fft3g_valid<S>(t, q) && 2 * k > NX) ubuf[NX - k] = o[q][k3];
         }
     wave_lds_sync();
-    const int nyp = t_col_len(ny, kRows3RgLog2);
+    const int nyp = t_col_len(ny, RGL2);
     cd* wbase = Tbuf + (size_t)w * 2 * NXH * nyp;                     // wave-uniform
     const unsigned kstride = 2u * (unsigned)nyp * kCd;                // bytes between kx columns
-    const unsigned off_row = (unsigned)t_elem(iy, 0, kRows3RgLog2) * kCd;
+    const unsigned off_row = (unsigned)t_elem(iy, 0, RGL2) * kCd;
+    if constexpr (kPair) {
+        // lanes 2j / 2j + 1 hold kx = k_e / k_e + 1.  The even lane hands H[k_e] over and takes G[k_e + 1]: the first
+        // instruction then writes (k_e; c = 0, c = 1) from the pair, the second (k_e + 1; c = 0, c = 1) -- 32
+        // adjacent bytes each, the component = the lane's parity
+        const bool odd = (t & 1) != 0;
+        const unsigned off_pair = off_row + (odd ? kCd : 0u);
+#pragma unroll
+        for (int q = 0; q < NB3; ++q)
+#pragma unroll
+            for (int k3 = 0; k3 < R3; ++k3) {
+                const int k = fft3g_index<S>(t, q, k3);
+                if (2 * (k - t) <= NX) {                              // (folds) lane 0 of this register is in the lower half
+                    // (R1 R2 is even: the two lanes of a pair hold an output or not together)
+                    const bool held = fft3g_valid<S>(t, q), low = held && 2 * k <= NX;
+                    const cd zk = o[q][k3];
+                    const bool self = k == 0 || 2 * k == NX;
+                    cd zm = ubuf[(self || !low) ? 1 : k];
+                    if (self) zm = zk;
+                    const cd g = cd{zk.x + zm.x, zk.y - zm.y}, h = cd{zk.y + zm.y, zm.x - zk.x};
+                    const cd got = pair_trade(odd, h, g);
+                    const cd first = pick(odd, g, got), second = pick(odd, got, h);
+                    const int ke = k & ~1, ko = k | 1;
+                    if (held && 2 * ke <= NX) *at_bytes(wbase, off_pair + (unsigned)ke * kstride) = first;
+                    if (held && 2 * ko <= NX) *at_bytes(wbase, off_pair + (unsigned)ko * kstride) = second;
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < NB3; ++q)
 #pragma unroll
@@ -273,7 +329,8 @@ k_rows3_inv(const cd* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const
             const double* __restrict__ prep, int plen, double* __restrict__ conv_out, double* __restrict__ var_out,
             int n_psf_field, unsigned field_stride) {
     constexpr int R1 = S::R1, R2 = S::R2, R3 = S::R3, L = S::L, NB3 = S::NB3, NSLOT = NB3 * R3;
-    constexpr int NXH = NX / 2 + 1, RGL = 1 << kRows3RgLog2;
+    constexpr int RGL2 = rows3_rg_log2(NX), NXH = NX / 2 + 1, RGL = 1 << RGL2;
+    constexpr bool kPair = RGL2 == 0 && L == 64;                      // lane pairs load whole sectors (see rows3_rg_log2)
     extern __shared__ __align__(16) double smem[];
     int w = blockIdx.y, bx = blockIdx.x;
     {   // which workgroup takes which (row group, walker): k_rows_inv's order (eight consecutive row groups, one
@@ -301,11 +358,11 @@ k_rows3_inv(const cd* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const
     cd* tab = reinterpret_cast<cd*>(smem + (size_t)kRows3Waves * rows3_wave_lds_doubles<S>());
     rows3_fill_table<S>(tab, twx);
     double* wave_lds = smem + (size_t)wave * rows3_wave_lds_doubles<S>();
-    const int iy = bx * RGL + wave;
+    const int iy = bx * kRows3Waves + wave;
     const bool row_in = iy < ny;                                      // wave-uniform
     const bool lane_in = L == 64 || t < L;
     const int tl = lane_in ? t : 0;
-    const int nyp = t_col_len(ny, kRows3RgLog2);
+    const int nyp = t_col_len(ny, RGL2);
     const cd* wbase = Tbuf + (size_t)w * 2 * NXH * nyp;               // wave-uniform
     const unsigned kstride = 2u * (unsigned)nyp * kCd;
     // Y[k], k = L a + t:  k <= NX/2: G[k] + i H[k];  else conj(G[NX-k]) + i conj(H[NX-k]).  Every (G, H) pair is
@@ -314,11 +371,28 @@ k_rows3_inv(const cd* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const
     cd* mbuf = reinterpret_cast<cd*>(wave_lds);
     cd v[R1];
     if (row_in) {
-        const unsigned off_row = (unsigned)t_elem(iy, 0, kRows3RgLog2) * kCd;
+        const unsigned off_row = (unsigned)t_elem(iy, 0, RGL2) * kCd;
+        const bool odd = (t & 1) != 0;
+        const unsigned off_pair = off_row + (odd ? kCd : 0u);
 #pragma unroll
         for (int a = 0; a < R1; ++a) {
             const int k = L * a + tl;
             v[a] = cd{0.0, 0.0};
+            if constexpr (kPair) {
+                // the pair's two instructions fetch (k_e; c = 0, c = 1) and (k_e + 1; c = 0, c = 1), the component =
+                // the lane's parity; the even lane then takes H[k_e] and hands G[k_e + 1] over
+                if (2 * L * a <= NX) {
+                    const int ke = k & ~1, ko = k | 1;
+                    cd first = cd{0.0, 0.0}, second = cd{0.0, 0.0};
+                    if (2 * ke <= NX) first = load_stream(at_bytes(wbase, off_pair + (unsigned)ke * kstride));
+                    if (2 * ko <= NX) second = load_stream(at_bytes(wbase, off_pair + (unsigned)ko * kstride));
+                    const cd got = pair_trade(odd, second, first);
+                    const cd g = pick(odd, first, got), h = pick(odd, got, second);
+                    const bool low = 2 * k <= NX;
+                    if (low) v[a] = cd{g.x - h.y, g.y + h.x};
+                    if (low && k > 0 && 2 * k < NX) mbuf[k] = cd{g.x + h.y, h.x - g.y};
+                }
+            } else
             if (2 * L * a <= NX) {                                    // (folds) some lane of this register is in the lower half
                 const bool low = lane_in && 2 * k <= NX;
                 cd g = cd{0.0, 0.0}, h = cd{0.0, 0.0};

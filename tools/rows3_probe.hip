@@ -56,7 +56,7 @@ static void run_side(int n_w, int n_sersic, int reps) {
     std::vector<uint8_t> bad((size_t)NY * NX, 0);
     for (size_t i = 0; i < sci.size(); ++i) { sci[i] = urand(); var[i] = 0.5 + urand(); bad[i] = urand() < 0.001; }
 
-    const int nyp_old = t_col_len(NY, rgl2_old), nyp_new = t_col_len(NY, kRows3RgLog2);
+    const int nyp_old = t_col_len(NY, rgl2_old), nyp_new = t_col_len(NY, rows3_rg_log2(NX));
     const size_t per_old = (size_t)2 * NXH * nyp_old, per_new = (size_t)2 * NXH * nyp_new;
     double *dprep, *dsci, *dvar, *dpart_old, *dpart_new;
     uint8_t* dbad;
@@ -125,7 +125,7 @@ static void run_side(int n_w, int n_sersic, int reps) {
             for (int y = 0; y < NY; ++y)
                 for (int c = 0; c < 2; ++c) {
                     const cd p = a[per_old * w + (size_t)kx * 2 * nyp_old + el(y, c, rgl2_old)];
-                    const cd q = b[per_new * w + (size_t)kx * 2 * nyp_new + el(y, c, kRows3RgLog2)];
+                    const cd q = b[per_new * w + (size_t)kx * 2 * nyp_new + el(y, c, rows3_rg_log2(NX))];
                     worst = fmax(worst, fmax(fabs(p.x - q.x), fabs(p.y - q.y)));
                     scale = fmax(scale, fmax(fabs(p.x), fabs(p.y)));
                 }
