@@ -801,6 +801,7 @@ constexpr Fft3gPick fft3g_pick(int n) {
 }
 template <int N, int R2_ = fft3g_pick(N).r2, int R3_ = fft3g_pick(N).r3> struct Fft3gShape {
     static constexpr bool kBuilt = R2_ > 0;
+    static constexpr int kN = N;
     static constexpr int R2 = kBuilt ? R2_ : 1, R3 = kBuilt ? R3_ : 1, L = R2 * R3, R1 = kBuilt ? N / L : 1;
     static_assert(!kBuilt || (R1 * L == N && L <= 64 && R1 <= 32 && R1 >= 4), "N = R1 R2 R3");
     static constexpr int NB2 = (R1 + R2 - 1) / R2, NB3 = (R1 * R2 + 63) / 64;
@@ -818,18 +819,36 @@ template <class S> __device__ __forceinline__ int fft3g_index(int t, int q, int 
 
 // `w1_lds`: the workgroup's stage-1 twiddle table [k1][t] = W_N^(t k1) in LDS (row stride 64);
 // w2[k2] = W_N^(R1 n3 k2).  Lanes t >= L carry no input; they work in stage 3 only.
-template <class S, int SIGN>
+// HALF1: the table holds k1 < R1 / 2 only and `w1h` = W_N^(t R1 / 2) is the lane's factor for the other half,
+// W_N^(t (k1 + R1 / 2)) = W_N^(t k1) w1h -- R1 / 2 more complex multiplies per transform for half the table's LDS
+// (what lets eight row waves of 2048 share a CU, psfmc_rows3_path.h).
+template <class S, int SIGN, bool HALF1 = false>
 __device__ __forceinline__ void fft_wave3g(cd (&v)[S::R1], cd (&o)[S::NB3][S::R3], const cd (&w2)[S::R2], int t,
-                                           double* __restrict__ lds, const cd* __restrict__ w1_lds) {
+                                           double* __restrict__ lds, const cd* __restrict__ w1_lds,
+                                           cd w1h = cd{1.0, 0.0}) {
     constexpr int R1 = S::R1, R2 = S::R2, R3 = S::R3, L = S::L, NB2 = S::NB2, NB3 = S::NB3, S1 = S::S1, S2 = S::S2;
     const bool lane_in = L == 64 || t < L;
     const int tl = lane_in ? t : 0;
     const int n3 = tl % R3, g = tl / R3;
     Dft<R1, SIGN>::run(v);
+    if constexpr (HALF1) {
+        static_assert(R1 % 2 == 0, "half table");
+        constexpr int H = R1 / 2;
+        const cd wh = SIGN < 0 ? w1h : cconj(w1h);
+        v[H] = cmul(v[H], wh);
+#pragma unroll
+        for (int k = 1; k < H; ++k) {
+            const cd w0 = w1_lds[k * 64 + t];
+            const cd wk = SIGN < 0 ? w0 : cconj(w0);
+            v[k] = cmul(v[k], wk);
+            v[k + H] = cmul(v[k + H], cmul(wk, wh));
+        }
+    } else {
 #pragma unroll
     for (int k = 1; k < R1; ++k) {
         const cd wk = w1_lds[k * 64 + t];
         v[k] = cmul(v[k], SIGN < 0 ? wk : cconj(wk));
+    }
     }
     cd z[NB2][R2];
     int k1s[NB2];

@@ -463,8 +463,8 @@ static int launch_rows3_fwd_kernel(psfmc_ctx* c, int n, const double* prep, cons
     }
     if (!FROM_IMAGE && !c->prep_tabs_valid)
         return fail(PSFMC_EINVAL, "internal: forward rows launched on prep records without a power-table decision");
-    hipLaunchKernelGGL((k_rows3_fwd<NX, FROM_IMAGE, WRAP>), dim3((c->ny + kRows3Waves - 1) / kRows3Waves, n),
-                       dim3(kRows3Threads), lds, st, prep, skip, c->d_twx, Tbuf, c->n_ps, c->n_sersic, c->ny, ps_only, img,
+    hipLaunchKernelGGL((k_rows3_fwd<NX, FROM_IMAGE, WRAP>), dim3((c->ny + rows3_waves(NX) - 1) / rows3_waves(NX), n),
+                       dim3(rows3_threads(NX)), lds, st, prep, skip, c->d_twx, Tbuf, c->n_ps, c->n_sersic, c->ny, ps_only, img,
                        img_scale, raw_out, c->wrap, c->prep_tabs_built ? kPowTabsBuilt : kPowTabsInWave);
     return PSFMC_OK;
 }
@@ -494,7 +494,7 @@ static int launch_rows3_inv_kernel(psfmc_ctx* c, int n, const cd* Tbuf, const do
             attr_device = c->device;
         }
     }
-    hipLaunchKernelGGL((k_rows3_inv<NX, MULTI>), dim3((c->ny + kRows3Waves - 1) / kRows3Waves, n), dim3(kRows3Threads), lds,
+    hipLaunchKernelGGL((k_rows3_inv<NX, MULTI>), dim3((c->ny + rows3_waves(NX) - 1) / rows3_waves(NX), n), dim3(rows3_threads(NX)), lds,
                        st, Tbuf, skip, c->d_twx, c->d_field, partial, c->ny, prep, c->plen, conv_out, var_out,
                        c->n_fields > 1 ? c->n_psf_field : 0, (unsigned)c->field_len);
     return PSFMC_OK;
@@ -751,13 +751,13 @@ template <int NX> static int pack_field(psfmc_ctx* c, int f) {
 // per-side constants of the row kernels the context will launch (rows3: the three-stage family)
 template <int NX> static RowShape row_shape_of(bool rows3) {
     if constexpr (rows3_side<NX>()) {
-        if (rows3 || !two_stage_side(NX)) return RowShape{1, kRows3Waves, rows3_rg_log2(NX), Rows3<NX>::S::R1, false};
+        if (rows3 || !two_stage_side(NX)) return RowShape{1, rows3_waves(NX), rows3_rg_log2(NX), Rows3<NX>::S::R1, false};
     }
     if constexpr (two_stage_side(NX))
         return RowShape{row_group<NX>(), row_waves<NX, true>(), layout_rg_log2<NX, true>(), FftShape<NX>::R,
                         FftShape<NX>::kPlain};
     else
-        return RowShape{1, kRows3Waves, rows3_rg_log2(NX), 0, false};
+        return RowShape{1, rows3_waves(NX), rows3_rg_log2(NX), 0, false};
 }
 // bit 0: a two-stage family exists; bit 1: the three-stage inverse kernel is built; bit 2: the forward one;
 // bit 3: the three-stage inverse kernel is the default

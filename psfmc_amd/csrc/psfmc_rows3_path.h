@@ -27,8 +27,19 @@
 
 namespace psfmc {
 
-constexpr int kRows3Waves = 4;                        // rows of a workgroup (= one layout group of the general sides)
-constexpr int kRows3Threads = 64 * kRows3Waves;
+// Rows (= waves) of a workgroup: 4 = one layout group of the general sides.  At nx = 2048 a wave's exchange region is
+// 18 KB and the stage-1 table the workgroup shares 32 KB: four waves = 104 KB = ONE workgroup and one wave per SIMD on
+// a CU.  EIGHT waves around HALF the table (psfmc_fft.h fft_wave3g HALF1: the other half is the lane's one factor
+// times the first) are exactly the CU's 160 KB: two waves per SIMD, and the 2048 rows of a walker are one whole round
+// of the chip's 256 CUs (PSFMC_ROWS3_WAVES_2048: 4 / 6 / 7 with the whole table for comparison; the layout above 1024
+// has no row groups to respect).
+#ifndef PSFMC_ROWS3_WAVES_2048
+#define PSFMC_ROWS3_WAVES_2048 8
+#endif
+constexpr int rows3_waves(int n) { return n == 2048 ? PSFMC_ROWS3_WAVES_2048 : 4; }
+constexpr int rows3_threads(int n) { return 64 * rows3_waves(n); }
+constexpr bool rows3_half_table(int n) { return n == 2048 && rows3_waves(n) == 8; }
+template <class S> constexpr int rows3_table_rows() { return rows3_half_table(S::kN) ? S::R1 / 2 : S::R1; }
 // Layout groups.  The sides that also have two-stage row kernels share their guarded layout: groups of 4 rows,
 // [kx][yg][c][r].  The sides above 1024 have no other row kernels and take groups of ONE row, [kx][y][c]: the two
 // components of a (kx, y) are then 32 adjacent bytes, and a lane PAIR (kx even / odd) trades one value so that every
@@ -105,13 +116,14 @@ template <class S> constexpr size_t rows3_wave_lds_doubles() {
     return fft > ras ? fft : ras;
 }
 template <class S> constexpr size_t rows3_lds_bytes() {
-    return ((size_t)kRows3Waves * rows3_wave_lds_doubles<S>() + (size_t)S::R1 * 64 * 2) * sizeof(double);
+    return ((size_t)rows3_waves(S::kN) * rows3_wave_lds_doubles<S>() + (size_t)rows3_table_rows<S>() * 64 * 2) * sizeof(double);
 }
 #ifndef PSFMC_ROWS3_WAVES16
 #define PSFMC_ROWS3_WAVES16 3       /* waves per SIMD the kernels with 9 ... 16 complex registers per lane are compiled for */
 #endif
+template <class S> constexpr bool rows3_lds_fits() { return rows3_lds_bytes<S>() <= 160 * 1024; }
 template <class S, bool INVERSE> constexpr int rows3_min_waves() {
-    return S::R1 <= 8 ? 4 : S::R1 <= 16 ? PSFMC_ROWS3_WAVES16 : S::R1 <= 24 ? 2 : 1;
+    return S::R1 <= 8 ? 4 : S::R1 <= 16 ? PSFMC_ROWS3_WAVES16 : (S::R1 <= 24 || rows3_waves(S::kN) > 4) ? 2 : 1;
 }
 #ifndef PSFMC_ROWS3_RASTER_GROUP
 #define PSFMC_ROWS3_RASTER_GROUP 1
@@ -162,7 +174,7 @@ __device__ __forceinline__ cd pick(bool second, cd a, cd b) { return cd{second ?
 // the workgroup's stage-1 twiddle table [k1][lane] = W_N^(lane k1) (zero for the lanes past L)
 template <class S>
 __device__ __forceinline__ void rows3_fill_table(cd* __restrict__ tab, const cd* __restrict__ twx) {
-    for (int i = threadIdx.x; i < S::R1 * 64; i += kRows3Threads)
+    for (int i = threadIdx.x; i < rows3_table_rows<S>() * 64; i += rows3_threads(S::kN))
         tab[i] = (i & 63) < S::L ? twx[(i & 63) * (i >> 6)] : cd{0.0, 0.0};
 }
 
@@ -171,13 +183,15 @@ __device__ __forceinline__ void rows3_fill_table(cd* __restrict__ tab, const cd*
 // Arguments as k_rows_fwd.
 // ---------------------------------------------------------------------------
 template <int NX, bool FROM_IMAGE, bool WRAP = false, class S = typename Rows3<NX>::S>
-__global__ void __launch_bounds__(kRows3Threads, (rows3_min_waves<S, false>()))
+__global__ void __launch_bounds__((rows3_threads(NX)), (rows3_min_waves<S, false>()))
 k_rows3_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip, const cd* __restrict__ twx,
             cd* __restrict__ Tbuf, int n_ps, int n_sersic, int ny, int ps_only, const double* __restrict__ img,
             const double* __restrict__ img_scale, double* __restrict__ raw_out, WrapDesc wr, int pow_mode) {
     static_assert(pow_tabs_side(NX), "the three-stage row kernels rasterise with the power tables");
+    static_assert(rows3_lds_fits<S>(), "a workgroup's LDS");
     constexpr int R1 = S::R1, R2 = S::R2, R3 = S::R3, L = S::L, NB3 = S::NB3;
     constexpr int RGL2 = rows3_rg_log2(NX), NXH = NX / 2 + 1, RGL = 1 << RGL2;
+    constexpr int WAVES = rows3_waves(NX);
     constexpr bool kPair = RGL2 == 0 && L == 64;                      // lane pairs store whole sectors (see rows3_rg_log2)
     static_assert(!kPair || (R1 * R2) % 2 == 0, "lane pairs hold outputs together");
     extern __shared__ __align__(16) double smem[];
@@ -192,10 +206,10 @@ k_rows3_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip, c
     }
 #endif
     const int t = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    cd* tab = reinterpret_cast<cd*>(smem + (size_t)kRows3Waves * rows3_wave_lds_doubles<S>());
+    cd* tab = reinterpret_cast<cd*>(smem + (size_t)WAVES * rows3_wave_lds_doubles<S>());
     rows3_fill_table<S>(tab, twx);
     double* wave_lds = smem + (size_t)wave * rows3_wave_lds_doubles<S>();
-    const int iy = blockIdx.x * kRows3Waves + wave;
+    const int iy = blockIdx.x * WAVES + wave;
     const bool row_in = iy < ny;                                      // wave-uniform
     const bool lane_in = L == 64 || t < L;
     const int tl = lane_in ? t : 0;
@@ -245,7 +259,7 @@ k_rows3_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip, c
 #pragma unroll
         for (int k3 = 0; k3 < R3; ++k3) o[q][k3] = v[(q * R3 + k3) % R1];
 #else
-    fft_wave3g<S, -1>(v, o, w2, t, wave_lds, tab);                    // o[q][k3] = Z[(t + 64 q) + R1 R2 k3]
+    fft_wave3g<S, -1, rows3_half_table(NX)>(v, o, w2, t, wave_lds, tab, twx[(R1 / 2) * tl]);   // o[q][k3] = Z[(t + 64 q) + R1 R2 k3]
 #endif
 #if PSFMC_DEBUG_ROWS3 & 1
     {
@@ -323,13 +337,14 @@ k_rows3_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip, c
 // Arguments as k_rows_inv.
 // ---------------------------------------------------------------------------
 template <int NX, bool MULTI = false, class S = typename Rows3<NX>::S>
-__global__ void __launch_bounds__(kRows3Threads, (rows3_min_waves<S, true>()))
+__global__ void __launch_bounds__((rows3_threads(NX)), (rows3_min_waves<S, true>()))
 k_rows3_inv(const cd* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const cd* __restrict__ twx,
             const FieldPx* __restrict__ field, double* __restrict__ partial, int ny,
             const double* __restrict__ prep, int plen, double* __restrict__ conv_out, double* __restrict__ var_out,
             int n_psf_field, unsigned field_stride) {
     constexpr int R1 = S::R1, R2 = S::R2, R3 = S::R3, L = S::L, NB3 = S::NB3, NSLOT = NB3 * R3;
     constexpr int RGL2 = rows3_rg_log2(NX), NXH = NX / 2 + 1, RGL = 1 << RGL2;
+    constexpr int WAVES = rows3_waves(NX);
     constexpr bool kPair = RGL2 == 0 && L == 64;                      // lane pairs load whole sectors (see rows3_rg_log2)
     extern __shared__ __align__(16) double smem[];
     int w = blockIdx.y, bx = blockIdx.x;
@@ -355,10 +370,10 @@ k_rows3_inv(const cd* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const
     }
     if (skip && skip[w]) return;                                      // (workgroup-uniform)
     const int t = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    cd* tab = reinterpret_cast<cd*>(smem + (size_t)kRows3Waves * rows3_wave_lds_doubles<S>());
+    cd* tab = reinterpret_cast<cd*>(smem + (size_t)WAVES * rows3_wave_lds_doubles<S>());
     rows3_fill_table<S>(tab, twx);
     double* wave_lds = smem + (size_t)wave * rows3_wave_lds_doubles<S>();
-    const int iy = bx * kRows3Waves + wave;
+    const int iy = bx * WAVES + wave;
     const bool row_in = iy < ny;                                      // wave-uniform
     const bool lane_in = L == 64 || t < L;
     const int tl = lane_in ? t : 0;
@@ -421,7 +436,7 @@ k_rows3_inv(const cd* __restrict__ Tbuf, const uint8_t* __restrict__ skip, const
 #pragma unroll
     for (int k = 0; k < R2; ++k) w2[k] = twx[R1 * (tl % R3) * k];
     cd o[NB3][R3];
-    fft_wave3g<S, +1>(v, o, w2, t, wave_lds, tab);                    // o[q][k3] = y[(t + 64 q) + R1 R2 k3]
+    fft_wave3g<S, +1, rows3_half_table(NX)>(v, o, w2, t, wave_lds, tab, twx[(R1 / 2) * tl]);   // o[q][k3] = y[(t + 64 q) + R1 R2 k3]
     // imaginary part is lambda * model variance (see build_prep)
     const double inv_lambda = prep[(size_t)w * plen + kPrepInvLambda];
     if (conv_out) {

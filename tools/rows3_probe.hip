@@ -97,7 +97,7 @@ static void run_side(int n_w, int n_sersic, int reps) {
                            (const double*)nullptr, (double*)nullptr, wr, kPowTabsBuilt);
     };
     auto fwd_new = [&]() {
-        hipLaunchKernelGGL((k_rows3_fwd<NX, false, false>), dim3((NY + 3) / 4, n_w), dim3(kRows3Threads), lds_new, 0, dprep,
+        hipLaunchKernelGGL((k_rows3_fwd<NX, false, false>), dim3((NY + rows3_waves(NX) - 1) / rows3_waves(NX), n_w), dim3(rows3_threads(NX)), lds_new, 0, dprep,
                            (const uint8_t*)nullptr, dtw, dT_new, n_ps, n_sersic, NY, 0, (const double*)nullptr,
                            (const double*)nullptr, (double*)nullptr, wr, kPowTabsBuilt);
     };
@@ -107,7 +107,7 @@ static void run_side(int n_w, int n_sersic, int reps) {
                            (double*)nullptr, 0, 0u);
     };
     auto inv_new = [&]() {
-        hipLaunchKernelGGL((k_rows3_inv<NX, false>), dim3((NY + 3) / 4, n_w), dim3(kRows3Threads), lds_new, 0, dT_new,
+        hipLaunchKernelGGL((k_rows3_inv<NX, false>), dim3((NY + rows3_waves(NX) - 1) / rows3_waves(NX), n_w), dim3(rows3_threads(NX)), lds_new, 0, dT_new,
                            (const uint8_t*)nullptr, dtw, dfield_new, dpart_new, NY, dprep, plen, (double*)nullptr,
                            (double*)nullptr, 0, 0u);
     };
