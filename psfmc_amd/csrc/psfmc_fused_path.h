@@ -446,6 +446,12 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
 // every group exactly once).
 // ---------------------------------------------------------------------------
 struct GroupRange { int first, end, step; };
+// (the divisions of xcd_group_range run on the vector unit and leave wave-uniform values in vector registers, and with
+// them every address derived from a group number: this moves them back to scalar registers)
+__device__ __forceinline__ GroupRange scalar_range(GroupRange g) {
+    return GroupRange{__builtin_amdgcn_readfirstlane(g.first), __builtin_amdgcn_readfirstlane(g.end),
+                      __builtin_amdgcn_readfirstlane(g.step)};
+}
 __device__ __forceinline__ GroupRange xcd_group_range(int n_groups) {
     const int nb = (int)gridDim.x, b = (int)blockIdx.x;
     const int nx = nb >= 8 ? 8 : 1;
@@ -767,6 +773,9 @@ template <class S> constexpr size_t fused_col3g_lds_bytes() {
            sizeof(double);
 }
 // the row-group size the kernel's affine addressing allows for a side (see in_off)
+#ifndef PSFMC_COLS3G_SCALAR_BASE
+#define PSFMC_COLS3G_SCALAR_BASE 1
+#endif
 template <class S> constexpr bool cols3g_layout_ok(int rg_log2) { return S::L % 4 != 0 || S::L % (1 << rg_log2) == 0; }
 template <int NY> constexpr bool cols3g_side() { return Fft3gShape<NY>::kBuilt && NY > PSFMC_COLS3G_MIN; }
 
@@ -780,7 +789,8 @@ k_cols3g(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restr
 #if PSFMC_COLS_PRIO
     __builtin_amdgcn_s_setprio(PSFMC_COLS_PRIO);
 #endif
-    const int t = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = threadIdx.x & 63;
+    const int wave = PSFMC_COLS3G_SCALAR_BASE ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (int)(threadIdx.x >> 6);
     const bool lane_in = L == 64 || t < L;
     const int tl = lane_in ? t : 0;
     double* lds = smem + (size_t)wave * fft3g_lds_doubles<S>();
@@ -800,19 +810,28 @@ k_cols3g(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restr
     const int off_t = row_off(tl);
     const int n_cols = n_w * 2 * nxh;
     const int nyp = t_col_len(NY, rg_log2);
-    const GroupRange gr = xcd_group_range((n_cols + WPB - 1) / WPB);
+    // PSFMC_COLS3G_SCALAR_BASE: a column's addresses as a scalar base + a 32-bit lane offset (see k_cols3f)
+    const GroupRange gr0 = xcd_group_range((n_cols + WPB - 1) / WPB);
+    const GroupRange gr = PSFMC_COLS3G_SCALAR_BASE ? scalar_range(gr0) : gr0;
     for (int grp = gr.first; grp < gr.end; grp += gr.step) {
         const int col = grp * WPB + wave;
         if (col >= n_cols) continue;                     // wave-uniform
         const int pr = col >> 1, c = col & 1;           // kx * n_w + walker, component
-        const int kx = pr / n_w, w = pr - kx * n_w;
+        const int kx = PSFMC_COLS3G_SCALAR_BASE ? __builtin_amdgcn_readfirstlane(pr / n_w) : pr / n_w, w = pr - kx * n_w;
         const bool skipped = skip && skip[w];            // wave-uniform; tested once the column's loads are issued
         cd* base = Tbuf + ((size_t)w * nxh + kx) * 2 * nyp + (c << rg_log2);
         // L a + t: with L a multiple of the row group (host-checked, cols3g_layout_ok) the offset is affine in a
         auto in_off = [&](int a) -> int { return kAffine ? off_t + 2 * L * a : row_off(L * a + tl); };
+        unsigned ob = (unsigned)off_t * kCd;
+        if (PSFMC_COLS3G_SCALAR_BASE && kAffine) asm volatile("" : "+v"(ob));
         cd v[R1];
+        if constexpr (PSFMC_COLS3G_SCALAR_BASE && kAffine) {
 #pragma unroll
-        for (int a = 0; a < R1; ++a) v[a] = load_stream(base + in_off(a));
+            for (int a = 0; a < R1; ++a) v[a] = load_stream(at_bytes(base, ob + (unsigned)(2 * L * a) * kCd));
+        } else {
+#pragma unroll
+            for (int a = 0; a < R1; ++a) v[a] = load_stream(base + in_off(a));
+        }
         if (skipped) continue;
         cd o[NB3][R3];
         fft_wave3g<S, -1>(v, o, w2, t, lds, tab);
@@ -830,8 +849,15 @@ k_cols3g(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restr
             fft_wave3g_inv<S>(o, v, t, lds, tab, tab_b);
             __builtin_amdgcn_sched_barrier(0);
             if (lane_in) {
+                if constexpr (PSFMC_COLS3G_SCALAR_BASE && kAffine) {
+                    unsigned os = (unsigned)off_t * kCd;
+                    asm volatile("" : "+v"(os));
 #pragma unroll
-                for (int a = 0; a < R1; ++a) base[in_off(a)] = v[a];
+                    for (int a = 0; a < R1; ++a) *at_bytes(base, os + (unsigned)(2 * L * a) * kCd) = v[a];
+                } else {
+#pragma unroll
+                    for (int a = 0; a < R1; ++a) base[in_off(a)] = v[a];
+                }
             }
         } else {
 #pragma unroll
@@ -853,9 +879,20 @@ k_cols3g(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restr
 // SIMD at R1 = 16.
 // ---------------------------------------------------------------------------
 template <class S> constexpr bool cols3f_shape() { return S::kBuilt && S::R2 == 8 && S::R3 == 8 && S::R1 % 8 == 0; }
-template <class S> constexpr size_t fused_col3f_lds_bytes() {
-    return ((size_t)(kColThreads / 64) * fft3g_lds_doubles<S>() + (size_t)S::R1 * 64 * 2) * sizeof(double);
+// ny = 2048: a wave's exchange region is 18 KB and the stage-1 table 32 KB -- four waves are ONE workgroup and one wave
+// per SIMD on a CU.  Eight waves around HALF the table (fft_wave3g HALF1) are exactly the CU's 160 KB: two waves per
+// SIMD at <= 256 registers, without the load pipeline (PSFMC_COLS3F_WAVES_2048 = 4: the old form, with it).
+#ifndef PSFMC_COLS3F_WAVES_2048
+#define PSFMC_COLS3F_WAVES_2048 8
+#endif
+template <class S> constexpr int cols3f_waves() { return S::R1 == 32 ? PSFMC_COLS3F_WAVES_2048 : kColThreads / 64; }
+template <class S> constexpr int cols3f_threads() { return 64 * cols3f_waves<S>(); }
+template <class S> constexpr bool cols3f_half_table() { return cols3f_waves<S>() == 8; }
+template <class S> constexpr int cols3f_table_rows() { return cols3f_half_table<S>() ? S::R1 / 2 : S::R1; }
+template <class S> constexpr size_t fused_col3f_lds_used() {
+    return ((size_t)cols3f_waves<S>() * fft3g_lds_doubles<S>() + (size_t)cols3f_table_rows<S>() * 64 * 2) * sizeof(double);
 }
+template <class S> constexpr size_t fused_col3f_lds_bytes() { return fused_col3f_lds_used<S>(); }
 // The load pipeline (the next column of a wave loaded into a second register set while the current one goes through its
 // inverse transform and its stores, as in k_cols) is decided per side by the WHOLE STEP, not by the kernel alone, which it
 // makes faster everywhere (512: 38.5 -> 36.5 us, 1024: 49.7 -> 47.4, 1536: 62 -> 56, 2048: 70 -> 55): step 512^2 -1.0 %,
@@ -869,37 +906,57 @@ template <class S> constexpr size_t fused_col3f_lds_bytes() {
 #define PSFMC_COLS3F_WAVES16 3
 #endif
 template <class S> constexpr bool cols3f_prefetch() {
-    return PSFMC_COLS3F_PREFETCH < 0 ? (S::R1 == 16 || S::R1 == 32) : PSFMC_COLS3F_PREFETCH != 0;
+    return PSFMC_COLS3F_PREFETCH < 0 ? (S::R1 == 16 || (S::R1 == 32 && !cols3f_half_table<S>())) : PSFMC_COLS3F_PREFETCH != 0;
 }
 template <class S> constexpr int cols3f_min_waves() {
     if (cols3f_prefetch<S>()) return S::R1 <= 8 ? 3 : S::R1 <= 16 ? 2 : 1;       // (a second register set for the next column)
-    return S::R1 <= 8 ? 4 : S::R1 <= 16 ? PSFMC_COLS3F_WAVES16 : S::R1 <= 24 ? 2 : 1;
+    return S::R1 <= 8 ? 4 : S::R1 <= 16 ? PSFMC_COLS3F_WAVES16 : (S::R1 <= 24 || cols3f_half_table<S>()) ? 2 : 1;
 }
 
 template <int NY, bool CONVOLVE, class S = Fft3gShape<NY>>
-__global__ void __launch_bounds__(kColThreads, (cols3f_min_waves<S>()))
+__global__ void __launch_bounds__((cols3f_threads<S>()), (cols3f_min_waves<S>()))
 k_cols3f(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restrict__ prep,
          const uint8_t* __restrict__ skip, const cd* __restrict__ twy, int plen, int nxh, int n_w, int rg_log2) {
     static_assert(cols3f_shape<S>(), "ny = 8 m x 8 x 8");
-    constexpr int R1 = S::R1, NB3 = S::NB3, WPB = kColThreads / 64;
+    constexpr int R1 = S::R1, NB3 = S::NB3, WPB = cols3f_waves<S>();
+    constexpr bool HALF = cols3f_half_table<S>();
     static_assert(NB3 * 8 == R1, "registers");
+    static_assert(fused_col3f_lds_bytes<S>() <= 160 * 1024, "a workgroup's LDS");
     extern __shared__ __align__(16) double smem[];
 #if PSFMC_COLS_PRIO
     __builtin_amdgcn_s_setprio(PSFMC_COLS_PRIO);
 #endif
-    const int t = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     double* lds = smem + (size_t)wave * fft3g_lds_doubles<S>();
     cd* tab = reinterpret_cast<cd*>(smem + (size_t)WPB * fft3g_lds_doubles<S>());
-    for (int i = threadIdx.x; i < R1 * 64; i += kColThreads) tab[i] = twy[(i & 63) * (i >> 6)];
+    for (int i = threadIdx.x; i < cols3f_table_rows<S>() * 64; i += cols3f_threads<S>()) tab[i] = twy[(i & 63) * (i >> 6)];
     __syncthreads();                                   // once, before any wave can leave
     cd w2[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) w2[k] = twy[R1 * (t & 7) * k];
+    const cd w1h = twy[(R1 / 2) * t];                  // (HALF: the lane's factor for the table's other half)
     const int rg_mask = (1 << rg_log2) - 1;
-    const int off_t = 2 * t - (t & rg_mask);           // element offset of row t; row 64 a + t adds 128 a (64 a multiple of the row group)
+    // A column's addresses are a wave-uniform base (scalar registers; row 64 a adds 128 a elements: 64 a is a multiple
+    // of the row group) plus ONE per-lane byte offset -- written as base + lane they cost a 64-bit vector address
+    // pair per element (k_cols3f<2048> at two waves per SIMD: 124 bytes of scratch; none this way)
+    // (ny = 512 keeps base + lane pointers: eight elements per column, and the scalar form measured 42 -> 45 us there)
+    constexpr bool kScalar = R1 > 8;
+    const int off_t = 2 * t - (t & rg_mask);
+    const unsigned off_b = (unsigned)off_t * kCd, kt_b = (unsigned)t * kCd;
+    auto t_at = [&](cd* base, unsigned ob, int a) -> cd* {       // element of row 64 a + t of the column at `base`
+        if constexpr (kScalar) return at_bytes(base, ob + 128u * kCd * a);
+        else return base + off_t + 128 * a;
+    };
+    auto k_at = [&](const cd* k, unsigned kb, int a) -> const cd* {
+        if constexpr (kScalar) return at_bytes(k, kb + 64u * kCd * a);
+        else return k + t + 64 * a;
+    };
+    // (`ob` / `kb` below: the lane offsets made opaque INSIDE the loop body -- hoisted out of the loop as 64-bit values
+    // the instruction selector no longer sees "scalar base + 32-bit lane offset" and falls back to a vector address pair
+    // per element)
     const int n_cols = n_w * 2 * nxh;
     const int nyp = t_col_len(NY, rg_log2);
-    const GroupRange gr = xcd_group_range((n_cols + WPB - 1) / WPB);
+    const GroupRange gr = scalar_range(xcd_group_range((n_cols + WPB - 1) / WPB));
     // cols3f_prefetch: the next column of this wave is loaded into a second register set while the current one
     // goes through its inverse transform and its stores (k_cols' load pipeline)
     auto locate = [&](int grp, int& w, int& kx, int& c, bool& live) -> cd* {
@@ -908,10 +965,10 @@ k_cols3f(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restr
         col = live ? col : n_cols - 1;
         c = col & 1;
         const int pr = col >> 1;
-        kx = pr / n_w;
+        kx = __builtin_amdgcn_readfirstlane(pr / n_w);   // (the division runs on the vector unit: back to a scalar register)
         w = pr - kx * n_w;
         if (live && skip && skip[w]) live = false;
-        return Tbuf + ((size_t)w * nxh + kx) * 2 * nyp + (c << rg_log2) + off_t;
+        return Tbuf + ((size_t)w * nxh + kx) * 2 * nyp + (c << rg_log2);        // (wave-uniform, in scalar registers)
     };
     if constexpr (cols3f_prefetch<S>() && CONVOLVE) {
         cd nxt[R1];
@@ -920,10 +977,13 @@ k_cols3f(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restr
         cd* base_n = Tbuf;
         if (gr.first < gr.end) {
             base_n = locate(gr.first, w_n, kx_n, c_n, live_n);
+            const unsigned ob = off_b;
 #pragma unroll
-            for (int a = 0; a < R1; ++a) nxt[a] = load_stream(base_n + 128 * a);
+            for (int a = 0; a < R1; ++a) nxt[a] = load_stream(t_at(base_n, ob, a));
         }
         for (int grp = gr.first; grp < gr.end; grp += gr.step) {
+            unsigned ob = off_b, kb = kt_b;
+            if constexpr (kScalar) asm volatile("" : "+v"(ob), "+v"(kb));
             cd v[R1];
 #pragma unroll
             for (int a = 0; a < R1; ++a) v[a] = nxt[a];
@@ -931,28 +991,30 @@ k_cols3f(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restr
             const int w = w_n, kx = kx_n, c = c_n;
             const bool live = live_n;
             cd o[NB3][8];
-            fft_wave3g<S, -1>(v, o, w2, t, lds, tab);
+            fft_wave3g<S, -1, HALF>(v, o, w2, t, lds, tab, w1h);
             __builtin_amdgcn_sched_barrier(0);
-            const int psf = live ? (int)prep[(size_t)w * plen + kPrepPsfIdx] : 0;
-            const cd* k = Kt + (((size_t)psf * nxh + kx) * 2 + c) * NY + t;
+            const int psf = __builtin_amdgcn_readfirstlane(live ? (int)prep[(size_t)w * plen + kPrepPsfIdx] : 0);
+            const cd* k = Kt + (((size_t)psf * nxh + kx) * 2 + c) * NY;
 #pragma unroll
             for (int q = 0; q < NB3; ++q)
 #pragma unroll
-                for (int k3 = 0; k3 < 8; ++k3) v[q + NB3 * k3] = cmul(o[q][k3], k[64 * (q + NB3 * k3)]);
+                for (int k3 = 0; k3 < 8; ++k3) v[q + NB3 * k3] = cmul(o[q][k3], *k_at(k, kb, q + NB3 * k3));
             __builtin_amdgcn_sched_barrier(0);
             if (grp + gr.step < gr.end) {
                 base_n = locate(grp + gr.step, w_n, kx_n, c_n, live_n);
 #pragma unroll
-                for (int a = 0; a < R1; ++a) nxt[a] = load_stream(base_n + 128 * a);
+                for (int a = 0; a < R1; ++a) nxt[a] = load_stream(t_at(base_n, ob, a));
             }
             __builtin_amdgcn_sched_barrier(0);
-            fft_wave3g<S, +1>(v, o, w2, t, lds, tab);
+            fft_wave3g<S, +1, HALF>(v, o, w2, t, lds, tab, w1h);
             __builtin_amdgcn_sched_barrier(0);
             if (live) {
+                unsigned os = off_b;                     // (formed again: 32 offsets kept from the loads would sit in
+                if constexpr (kScalar) asm volatile("" : "+v"(os));   //  registers through both transforms)
 #pragma unroll
                 for (int q = 0; q < NB3; ++q)
 #pragma unroll
-                    for (int k3 = 0; k3 < 8; ++k3) base[128 * (q + NB3 * k3)] = o[q][k3];
+                    for (int k3 = 0; k3 < 8; ++k3) *t_at(base, os, q + NB3 * k3) = o[q][k3];
             }
         }
         return;
@@ -961,31 +1023,35 @@ k_cols3f(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restr
         const int col = grp * WPB + wave;
         if (col >= n_cols) continue;                     // wave-uniform
         const int pr = col >> 1, c = col & 1;           // kx * n_w + walker, component
-        const int kx = pr / n_w, w = pr - kx * n_w;
+        const int kx = __builtin_amdgcn_readfirstlane(pr / n_w), w = pr - kx * n_w;    // (the division runs on the vector unit)
         const bool skipped = skip && skip[w];            // wave-uniform; tested once the column's loads are issued
-        cd* base = Tbuf + ((size_t)w * nxh + kx) * 2 * nyp + (c << rg_log2) + off_t;
+        cd* base = Tbuf + ((size_t)w * nxh + kx) * 2 * nyp + (c << rg_log2);     // (wave-uniform, in scalar registers)
+        unsigned ob = off_b, kb = kt_b;
+        if constexpr (kScalar) asm volatile("" : "+v"(ob), "+v"(kb));
         cd v[R1];
 #pragma unroll
-        for (int a = 0; a < R1; ++a) v[a] = load_stream(base + 128 * a);
+        for (int a = 0; a < R1; ++a) v[a] = load_stream(t_at(base, ob, a));
         if (skipped) continue;
         cd o[NB3][8];
-        fft_wave3g<S, -1>(v, o, w2, t, lds, tab);        // o[q][k3] = X[t + 64 (q + NB3 k3)]
+        fft_wave3g<S, -1, HALF>(v, o, w2, t, lds, tab, w1h);        // o[q][k3] = X[t + 64 (q + NB3 k3)]
         if constexpr (CONVOLVE) {
             __builtin_amdgcn_sched_barrier(0);
-            const int psf = (int)prep[(size_t)w * plen + kPrepPsfIdx];
-            const cd* k = Kt + (((size_t)psf * nxh + kx) * 2 + c) * NY + t;
+            const int psf = __builtin_amdgcn_readfirstlane((int)prep[(size_t)w * plen + kPrepPsfIdx]);
+            const cd* k = Kt + (((size_t)psf * nxh + kx) * 2 + c) * NY;
 #pragma unroll
             for (int q = 0; q < NB3; ++q)
 #pragma unroll
-                for (int k3 = 0; k3 < 8; ++k3) v[q + NB3 * k3] = cmul(o[q][k3], k[64 * (q + NB3 * k3)]);
+                for (int k3 = 0; k3 < 8; ++k3) v[q + NB3 * k3] = cmul(o[q][k3], *k_at(k, kb, q + NB3 * k3));
             __builtin_amdgcn_sched_barrier(0);
-            fft_wave3g<S, +1>(v, o, w2, t, lds, tab);
+            fft_wave3g<S, +1, HALF>(v, o, w2, t, lds, tab, w1h);
             __builtin_amdgcn_sched_barrier(0);
         }
+        unsigned os = off_b;                             // (formed again: 32 offsets kept from the loads would sit in
+        if constexpr (kScalar) asm volatile("" : "+v"(os));   //  registers through both transforms)
 #pragma unroll
         for (int q = 0; q < NB3; ++q)
 #pragma unroll
-            for (int k3 = 0; k3 < 8; ++k3) base[128 * (q + NB3 * k3)] = o[q][k3];
+            for (int k3 = 0; k3 < 8; ++k3) *t_at(base, os, q + NB3 * k3) = o[q][k3];
     }
 }
 

@@ -9,13 +9,16 @@
 #include <cstdlib>
 #include <vector>
 using namespace psfmc;
+#ifndef NXH_LESS
+#define NXH_LESS 0   /* 1: one kx column fewer (what a packed DC + Nyquist column would leave): the tail-round experiment */
+#endif
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 template <int N, int R2, int R3>
 static void run_one(size_t t_budget_bytes) {
     constexpr int rg_log2 = 2;
-    const int nxh = N / 2 + 1, nyp = t_col_len(N, rg_log2), plen = 8;
+    const int nxh = N / 2 + 1 - NXH_LESS, nyp = t_col_len(N, rg_log2), plen = 8;
     const size_t per_w = (size_t)nxh * 2 * nyp;
     int n_w = (int)(t_budget_bytes / (per_w * sizeof(cd)));
     if (n_w < 1) n_w = 1;
@@ -42,8 +45,8 @@ static void run_one(size_t t_budget_bytes) {
             using S = Fft3gShape<N, 8, 8>;
             constexpr size_t lds = fused_col3f_lds_bytes<S>();
             CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cols3f<N, true, S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            const int blocks = (n_cols + 3) / 4, cap = 8 * prop.multiProcessorCount;
-            hipLaunchKernelGGL((k_cols3f<N, true, S>), dim3(blocks < cap ? blocks : cap), dim3(kColThreads), lds, 0, dT, dK, dprep,
+            const int wpb = cols3f_waves<S>(), blocks = (n_cols + wpb - 1) / wpb, cap = 8 * prop.multiProcessorCount;
+            hipLaunchKernelGGL((k_cols3f<N, true, S>), dim3(blocks < cap ? blocks : cap), dim3(cols3f_threads<S>()), lds, 0, dT, dK, dprep,
                                (const uint8_t*)nullptr, dtw, plen, nxh, n_w, rg_log2);
         } else if constexpr (R2 < 0) {             // X(n, -1, 0): k_cols3<n> (512, 1024)
             constexpr size_t lds = fused_col3_lds_bytes<N>();
