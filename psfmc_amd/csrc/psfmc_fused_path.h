@@ -768,23 +768,38 @@ k_cols3(TS* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restri
 // kernel spectrum is indexed by that k, and the inverse transform is the forward one's mirror image
 // (fft_wave3g_inv), which takes exactly that layout and returns the column in the layout it was loaded in.
 // ---------------------------------------------------------------------------
+// Waves per workgroup and per SIMD above 1024 (R1 = 18, 20: 1152, 1280).  Compiled for ONE wave per SIMD the kernel
+// holds 288 registers; bounded to two it spills 84 bytes per lane and is still the faster one where the LDS lets two
+// waves share a SIMD: 1152 (78 KB per four-wave workgroup, two per CU) 92 -> 68 us per 4-walker pass, step +16 %; at
+// 1280 four waves take 86 KB -- one workgroup per CU whatever the registers (80.5 us, no gain) -- so EIGHT waves share
+// the two tables there (132 KB).  profiles/r4_cols3g_2waves_1152.txt
+#ifndef PSFMC_COLS3G_R1_2WAVES
+#define PSFMC_COLS3G_R1_2WAVES 20     /* k_cols3g is compiled for two waves per SIMD up to this many registers per lane */
+#endif
+#ifndef PSFMC_COLS3G_WAVES_1280
+#define PSFMC_COLS3G_WAVES_1280 8
+#endif
+template <class S> constexpr int cols3g_waves() { return S::R1 == 20 && S::L == 64 ? PSFMC_COLS3G_WAVES_1280 : kColThreads / 64; }
+template <class S> constexpr int cols3g_threads() { return 64 * cols3g_waves<S>(); }
 template <class S> constexpr size_t fused_col3g_lds_bytes() {
-    return ((size_t)(kColThreads / 64) * fft3g_lds_doubles<S>() + (size_t)S::R1 * 64 * 2 + (size_t)S::R1 * S::L * 2) *
+    return ((size_t)cols3g_waves<S>() * fft3g_lds_doubles<S>() + (size_t)S::R1 * 64 * 2 + (size_t)S::R1 * S::L * 2) *
            sizeof(double);
 }
 // the row-group size the kernel's affine addressing allows for a side (see in_off)
+#ifndef PSFMC_COLS3G_KT_CHUNKS
+#define PSFMC_COLS3G_KT_CHUNKS 1      /* R1 > 16: the kernel-spectrum values of one output block in flight at a time (96 -> 84 bytes of scratch) */
+#endif
 #ifndef PSFMC_COLS3G_SCALAR_BASE
 #define PSFMC_COLS3G_SCALAR_BASE 1
 #endif
 template <class S> constexpr bool cols3g_layout_ok(int rg_log2) { return S::L % 4 != 0 || S::L % (1 << rg_log2) == 0; }
 template <int NY> constexpr bool cols3g_side() { return Fft3gShape<NY>::kBuilt && NY > PSFMC_COLS3G_MIN; }
 
-// (sides above 1024 hold 18 ... 32 complex registers per lane in each of the two layouts: one wave per SIMD)
 template <int NY, bool CONVOLVE, class S = Fft3gShape<NY>>
-__global__ void __launch_bounds__(kColThreads, (S::R1 > 16 ? 1 : 2))      // (1152 / 1280 at two waves: 140 ... 152 bytes of scratch)
+__global__ void __launch_bounds__((cols3g_threads<S>()), (S::R1 > PSFMC_COLS3G_R1_2WAVES ? 1 : 2))
 k_cols3g(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restrict__ prep,
          const uint8_t* __restrict__ skip, const cd* __restrict__ twy, int plen, int nxh, int n_w, int rg_log2) {
-    constexpr int R1 = S::R1, R2 = S::R2, R3 = S::R3, L = S::L, NB3 = S::NB3, WPB = kColThreads / 64;
+    constexpr int R1 = S::R1, R2 = S::R2, R3 = S::R3, L = S::L, NB3 = S::NB3, WPB = cols3g_waves<S>();
     extern __shared__ __align__(16) double smem[];
 #if PSFMC_COLS_PRIO
     __builtin_amdgcn_s_setprio(PSFMC_COLS_PRIO);
@@ -796,10 +811,10 @@ k_cols3g(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restr
     double* lds = smem + (size_t)wave * fft3g_lds_doubles<S>();
     cd* tab = reinterpret_cast<cd*>(smem + (size_t)WPB * fft3g_lds_doubles<S>());
     cd* tab_b = tab + R1 * 64;                         // the inverse transform's first twiddles [n3][c] = W_N^(n3 c)
-    for (int i = threadIdx.x; i < R1 * 64; i += kColThreads)
+    for (int i = threadIdx.x; i < R1 * 64; i += cols3g_threads<S>())
         tab[i] = (i & 63) < L ? twy[(i & 63) * (i >> 6)] : cd{0.0, 0.0};
     if constexpr (CONVOLVE)
-        for (int i = threadIdx.x; i < NY; i += kColThreads) tab_b[i] = twy[(i / (R1 * R2)) * (i % (R1 * R2))];
+        for (int i = threadIdx.x; i < NY; i += cols3g_threads<S>()) tab_b[i] = twy[(i / (R1 * R2)) * (i % (R1 * R2))];
     __syncthreads();                                   // once, before any wave can leave
     cd w2[R2];
 #pragma unroll
@@ -844,6 +859,7 @@ k_cols3g(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restr
                 const bool ok = fft3g_valid<S>(t, q);
 #pragma unroll
                 for (int k3 = 0; k3 < R3; ++k3) o[q][k3] = cmul(o[q][k3], k[ok ? fft3g_index<S>(t, q, k3) : 0]);
+                if constexpr (PSFMC_COLS3G_KT_CHUNKS && R1 > 16) __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_sched_barrier(0);
             fft_wave3g_inv<S>(o, v, t, lds, tab, tab_b);

@@ -632,10 +632,10 @@ static int launch_cols(psfmc_ctx* c, void* Tvoid, int n_w, const double* prep, c
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
                 attr3_device = c->device;
             }
-            const int per_block = kColThreads / 64;
+            const int per_block = cols3g_waves<Fft3gShape<NY>>();
             const int blocks = (n_cols + per_block - 1) / per_block;
             const int grid3 = blocks < 4 * c->cols_grid ? blocks : 4 * c->cols_grid;
-            hipLaunchKernelGGL((k_cols3g<NY, CONVOLVE>), dim3(grid3), dim3(kColThreads), lds3, st, Tbuf, c->d_Kt, prep,
+            hipLaunchKernelGGL((k_cols3g<NY, CONVOLVE>), dim3(grid3), dim3(cols3g_threads<Fft3gShape<NY>>()), lds3, st, Tbuf, c->d_Kt, prep,
                                skip, c->d_twy, c->plen, c->nxh, n_w, c->rg_log2);
             return PSFMC_OK;
         }

@@ -58,8 +58,8 @@ static void run_one(size_t t_budget_bytes) {
             using S = Fft3gShape<N, R2, R3>;
             constexpr size_t lds = fused_col3g_lds_bytes<S>();
             CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cols3g<N, true, S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            const int blocks = (n_cols + 3) / 4, cap = 8 * prop.multiProcessorCount;
-            hipLaunchKernelGGL((k_cols3g<N, true, S>), dim3(blocks < cap ? blocks : cap), dim3(kColThreads), lds, 0, dT, dK, dprep,
+            const int wpb = cols3g_waves<S>(), blocks = (n_cols + wpb - 1) / wpb, cap = 8 * prop.multiProcessorCount;
+            hipLaunchKernelGGL((k_cols3g<N, true, S>), dim3(blocks < cap ? blocks : cap), dim3(cols3g_threads<S>()), lds, 0, dT, dK, dprep,
                                (const uint8_t*)nullptr, dtw, plen, nxh, n_w, rg_log2);
         } else if constexpr (two_stage_side(N)) {
             constexpr size_t lds = fused_col_lds_bytes<N>();
