@@ -36,6 +36,8 @@ namespace psfmc {
 #ifndef PSFMC_ROWS3_WAVES_2048
 #define PSFMC_ROWS3_WAVES_2048 8
 #endif
+// (1152 / 1280 with six / five waves per workgroup and the kernels bounded to three waves per SIMD: the bound costs
+// scratch, inverse kernel 41 -> 73 us, step -32 %: profiles/r4_rows3_waves_1152.txt)
 constexpr int rows3_waves(int n) { return n == 2048 ? PSFMC_ROWS3_WAVES_2048 : 4; }
 constexpr int rows3_threads(int n) { return 64 * rows3_waves(n); }
 constexpr bool rows3_half_table(int n) { return n == 2048 && rows3_waves(n) == 8; }
