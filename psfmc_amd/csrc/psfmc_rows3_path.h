@@ -38,9 +38,24 @@ namespace psfmc {
 #endif
 // (1152 / 1280 with six / five waves per workgroup and the kernels bounded to three waves per SIMD: the bound costs
 // scratch, inverse kernel 41 -> 73 us, step -32 %: profiles/r4_rows3_waves_1152.txt)
-constexpr int rows3_waves(int n) { return n == 2048 ? PSFMC_ROWS3_WAVES_2048 : 4; }
+#ifndef PSFMC_ROWS3_WAVES_1280
+#define PSFMC_ROWS3_WAVES_1280 4
+#endif
+constexpr int rows3_waves(int n) { return n == 2048 ? PSFMC_ROWS3_WAVES_2048 : n == 1280 ? PSFMC_ROWS3_WAVES_1280 : 4; }
 constexpr int rows3_threads(int n) { return 64 * rows3_waves(n); }
-constexpr bool rows3_half_table(int n) { return n == 2048 && rows3_waves(n) == 8; }
+// nx = 1152: half the table takes a four-wave workgroup from 59.9 to 50.7 KB -- THREE workgroups per CU; the forward
+// kernel (166 registers) then runs three waves per SIMD: 41.6 -> 37.7 us, step +4 % (profiles/r4_rows3_half_1152.txt)
+#ifndef PSFMC_ROWS3_HALF_1152
+#define PSFMC_ROWS3_HALF_1152 1
+#endif
+// (nx = 1280: 56 KB with half the table is still two workgroups per CU; FIVE waves around it -- 67.6 KB, ten waves per
+// CU -- measured 37.5 -> 50 us forward, 36 -> 48 inverse, step -20 %: profiles/r4_rows3_half_1280.txt.  Left alone.)
+#ifndef PSFMC_ROWS3_HALF_1280
+#define PSFMC_ROWS3_HALF_1280 0
+#endif
+constexpr bool rows3_half_table(int n) {
+    return (n == 2048 && rows3_waves(n) == 8) || (PSFMC_ROWS3_HALF_1152 && n == 1152) || (PSFMC_ROWS3_HALF_1280 && n == 1280);
+}
 template <class S> constexpr int rows3_table_rows() { return rows3_half_table(S::kN) ? S::R1 / 2 : S::R1; }
 // Layout groups.  The sides that also have two-stage row kernels share their guarded layout: groups of 4 rows,
 // [kx][yg][c][r].  The sides above 1024 have no other row kernels and take groups of ONE row, [kx][y][c]: the two
