@@ -80,9 +80,11 @@ def pmc_table(args):
 
 
 def pmc_lookup(table, prefix):
-    for name, rec in table.items():
-        if name.startswith(prefix):
-            return rec['hbm_bytes_per_walker']
+    # (the one-row-per-wave row kernels of psfmc_rows3_path.h are named k_rows3_*)
+    for pre in (prefix, prefix.replace('k_rows_', 'k_rows3_')):
+        for name, rec in table.items():
+            if name.startswith(pre):
+                return rec['hbm_bytes_per_walker']
     return None
 
 

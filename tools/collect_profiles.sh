@@ -24,6 +24,7 @@ for N in $CONFIGS; do
     1024) ARGS="--size 1024 --sersic 4 --walkers 256"; CH=5.9535 ;;       # 256 / 43
     200)  ARGS="--size 200 --sersic 1 --walkers 4096"; CH=178.0870 ;;     # 4096 / 23
     300)  ARGS="--size 300 --sersic 1 --walkers 2048"; CH=78.7692 ;;      # 2048 / 26
+    2048) ARGS="--size 2048 --sersic 1 --walkers 64"; CH=1 ;;              # one walker per pass
     *)    ARGS="--size $N --sersic 1 --walkers 1024"; CH=0 ;;              # any other side: CH from the bench's own kernel pass (below)
   esac
   COMMON="$ARGS --no-cpu --no-example --no-extras"
@@ -55,6 +56,7 @@ for N in $CONFIGS; do
     1024) python3 bench.py --size 1024 --sersic 4 --walkers 256 --no-example --cpu-seconds 6 --cpu-procs 0 > $OUT/${TAG}_bench_1024.json 2>$OUT/${TAG}_bench_1024.err ;;
     200)  python3 bench.py --size 200 --sersic 1 --walkers 4096 --no-example --cpu-seconds 6 --cpu-procs 0 > $OUT/${TAG}_bench_200.json 2>$OUT/${TAG}_bench_200.err ;;
     300)  python3 bench.py --size 300 --sersic 1 --walkers 2048 --no-example --cpu-seconds 6 --cpu-procs 0 > $OUT/${TAG}_bench_300.json 2>$OUT/${TAG}_bench_300.err ;;
+    2048) python3 bench.py --size 2048 --sersic 1 --walkers 64 --no-example --cpu-seconds 6 --cpu-procs 0 > $OUT/${TAG}_bench_2048.json 2>$OUT/${TAG}_bench_2048.err ;;
     *)    python3 bench.py --size $N --sersic 1 --walkers 1024 --no-example --cpu-seconds 6 --cpu-procs 0 > $OUT/${TAG}_bench_$N.json 2>$OUT/${TAG}_bench_$N.err ;;
   esac
 done
