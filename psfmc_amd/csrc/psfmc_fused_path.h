@@ -66,6 +66,9 @@ constexpr int kInvRemapMaxWalkers = 24;
 #ifndef PSFMC_DEBUG_FWD
 #define PSFMC_DEBUG_FWD 0            /* timing experiments on k_rows_fwd: 1 = no store phase, 2 = no transform */
 #endif
+#ifndef PSFMC_FWD_STORE_BARRIER
+#define PSFMC_FWD_STORE_BARRIER 0
+#endif
 #ifndef PSFMC_FWD_PRIO_STAGGER
 #define PSFMC_FWD_PRIO_STAGGER 0      /* n > 0: forward row workgroups take issue priority (linear id / n) & 3 */
 #endif
@@ -375,6 +378,11 @@ k_rows_fwd(const double* __restrict__ prep, const uint8_t* __restrict__ skip,
     TS* wbase = Tbuf + (size_t)w * 2 * NXH * nyp;                    // wave-uniform
     constexpr unsigned kEl = sizeof(TS);                             // bytes of a T element
     const unsigned kstride = 2u * (unsigned)nyp * kEl;               // bytes between kx columns
+#if PSFMC_FWD_STORE_BARRIER
+    // experiment: the waves of a workgroup write the halves of the same 128-byte lines (two rows per wave at nx = 1024);
+    // started together again, the halves should meet in the L2 instead of going out as two partial writes
+    if constexpr (FAST && S::TPW == 2) __syncthreads();
+#endif
     if constexpr (FAST) {
         // Untangle.  Lane t holds Z[k], k = t + T e.  Z[NX - k] is held by lane
         // (T - t) % T at e' = P-1-e (t != 0) or P-e (t == 0), i.e. in the upper half of
