@@ -774,6 +774,9 @@ __device__ __forceinline__ void fft_wave3(cd (&v)[Fft3Shape<N>::R1], const cd (&
 // Its inverse is the mirror image below (fft_wave3g_inv), which takes exactly this output layout.
 // ---------------------------------------------------------------------------
 struct Fft3gPick { int r2, r3; };
+#ifndef PSFMC_COLS3G_ROUND4_SIDES
+#define PSFMC_COLS3G_ROUND4_SIDES 1
+#endif
 // The shape of a side, {0, 0} = none (its columns stay on the two-stage engine).  Empirical: every candidate
 // factorisation was timed against the two-stage kernel on an MI355X (tools/cols3g_shapes.hip;
 // profiles/r3_cols3g_shapes.txt).  What wins: R2 = 4 (stage 2 is then NB2 = R1 / 4 cheap radix-4 passes and stage 3
@@ -796,6 +799,19 @@ constexpr Fft3gPick fft3g_pick(int n) {
         case 512: case 640: case 704: case 768: case 832: case 960: case 1024: return {8, 8};
         // round 4: sides above 1024 -- no two-stage shape (P, T <= 32) reaches them; all 64 lanes, R1 = 18 ... 32
         case 1152: case 1280: case 1536: case 2048: return {8, 8};
+#if PSFMC_COLS3G_ROUND4_SIDES
+        // round 4, second survey (profiles/r4_cols3g_more_sides.txt): with the column's addresses on a scalar base the
+        // three-stage kernel also wins at sides with 5 ... 10 elements per lane, where round 3 measured it slower:
+        // kernel alone -5 ... -25 %, whole step (profiles/r4_cols3g_round4_sides_step.txt) 280 +2.2 %, 288 +1.6 %,
+        // 300 +2.9 %, 336 +5.0 %, 350 +3.3 %, 360 +0.6 %, 630 +2.7 %.  320 = 5 x (8 x 8) and 420 = 7 x (5 x 12) were
+        // faster alone (-3 %, -11 %) and slower in the step (-1.2 %, -1.7 %): not taken.
+        case 280: case 336: return {7, 8};
+        case 288: return {6, 8};
+        case 300: return {5, 12};
+        case 350: return {5, 10};
+        case 360: return {6, 10};
+        case 630: return {7, 9};
+#endif
         default: return {0, 0};
     }
 }

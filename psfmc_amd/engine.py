@@ -41,6 +41,9 @@ for _sides, _shape in (((264, 308, 352, 484), (4, 11)), ((384, 528, 576), (4, 12
                        ((392, 504, 560, 616, 672, 728, 784, 840, 896), (4, 14)), ((480, 900), (4, 15)),
                        ((448,), (4, 16)), ((330, 440), (5, 11)), ((250, 500), (5, 10)), ((294,), (7, 7)),
                        ((600, 660, 720), (5, 12)),
+                       # round 4, second survey (csrc/psfmc_fft.h fft3g_pick)
+                       ((280, 336), (7, 8)), ((288,), (6, 8)), ((300,), (5, 12)), ((350,), (5, 10)), ((360,), (6, 10)),
+                       ((630,), (7, 9)),
                        ((640, 704, 768, 832, 960, 1152, 1280, 1536, 2048), (8, 8))):
     for _n in _sides:
         _COLS3G_SHAPES[_n] = _shape
