@@ -116,7 +116,14 @@ constexpr Fft3gPick rows3_pick(int n) {
 }
 constexpr bool rows3_only_side(int n) { return n > 1024; }
 // the inverse kernel is the default where it measured faster; the forward kernel only where there is no other
+// (the sides whose two-stage row shapes round 4 re-surveyed for lanes now hold 24 ... 32 complex registers per lane:
+// the inverse kernel there, profiles/r4_inv3_reshaped_sides.txt -- faster alone at 330 and 350 only (9.5 -> 8.0, 8.9 -> 7.3
+// ps per pixel), slower at 264, 312, 352, 416, and the whole step -1 ... -14 % at all six.  Not taken.)
+#ifndef PSFMC_ROWS3_INV_MORE
+#define PSFMC_ROWS3_INV_MORE 0      /* survey builds (with PSFMC_ROWS3_EXTRA=2): the inverse kernel also at the sides listed below */
+#endif
 constexpr bool rows3_inv_default(int n) {
+    if (PSFMC_ROWS3_INV_MORE && (n == 250 || n == 264 || n == 312 || n == 330 || n == 350 || n == 352 || n == 416)) return true;
     return rows3_only_side(n) || n == 676 || n == 720 || n == 728 || n == 780 || n == 784 || n == 840 || n == 900;
 }
 constexpr bool rows3_fwd_built(int n) { return rows3_pick(n).r2 > 0 && (rows3_only_side(n) || PSFMC_ROWS3_EXTRA); }
