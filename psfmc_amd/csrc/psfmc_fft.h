@@ -100,7 +100,8 @@ PSFMC_FFT_SHAPE(1024, 32, 32)
 // engine anyway (fft3g_pick) the two-stage shape only serves the row kernels, and more lanes beat fewer registers --
 // 250: 10 x 25 (50 lanes) -> 25 x 10 (60): +10 % whole step; 264: 12 x 22 (44) -> 22 x 12 (60): +19 %; 286: 13 x 22 -> 22 x 13:
 // +19 %; 312: 13 x 24 -> 24 x 13: +15 %; 330: 15 x 22 -> 22 x 15: +9 %; 350: 14 x 25 -> 25 x 14: +9 %; 352: 16 x 22 -> 22 x 16: +17 %;
-// 416: 16 x 26 -> 26 x 16: +15 %.  Measured and left alone: 384, 390, 448, 480, 504, 576, 600, 672 (-8 ... +3 %), every small
+// 416: 16 x 26 -> 26 x 16: +15 %; 288 (once its columns had moved to the three-stage engine, late in round 4): 16 x 18 (54
+// lanes) -> 24 x 12 (60): +4.6 %, 18 x 16 (64 lanes, 32 registers): +0 % (profiles/r4_shape_288.txt).  Measured and left alone: 384, 390, 448, 480, 504, 576, 600, 672 (-8 ... +3 %), every small
 // side tried (110 ... 288: -1 ... -44 %: their two-stage COLUMN kernel pays for the registers) and the R = 40 shapes of 440,
 // 500, 520, 560 (-13 ... -14 %).
 // sides with factors 3 and 5 (any even side of this list runs on the fused kernels).  The
@@ -118,7 +119,7 @@ PSFMC_FFT_SHAPE(192, 12, 16)
 PSFMC_FFT_SHAPE(200, 20, 10)
 PSFMC_FFT_SHAPE(240, 15, 16)
 PSFMC_FFT_SHAPE(250, 25, 10)
-PSFMC_FFT_SHAPE(288, 16, 18)
+PSFMC_FFT_SHAPE(288, 24, 12)
 PSFMC_FFT_SHAPE(300, 15, 20)
 PSFMC_FFT_SHAPE(320, 16, 20)
 PSFMC_FFT_SHAPE(360, 18, 20)
