@@ -150,6 +150,9 @@ def general_shapes():
     # against two-stage, three-stage and power-of-two partners, and squares
     shapes += [(1152, 64), (96, 1152), (1280, 100), (128, 1280), (1536, 480), (250, 1536), (2048, 64), (84, 2048),
                (1152, 1152), (1280, 1536), (2048, 1152), (1536, 2048)]
+    # round 4, second column survey: the seven sides that moved to the three-stage column kernel, against row lengths of
+    # every layout (row groups of 8 -- where a side with 8 not dividing L falls back to the two-stage kernel --, 4, 2, 1)
+    shapes += [(300, 128), (336, 128), (288, 64), (630, 128), (360, 1024), (280, 512), (350, 256), (300, 1152), (336, 2048)]
     assert all(engine.fused_supports(ny, nx) for ny, nx in shapes)
     # the claim above, enforced: every built side runs as the column length AND as the row length
     assert {ny for ny, _ in shapes} >= set(engine.FUSED_SIDES), sorted(set(engine.FUSED_SIDES) - {ny for ny, _ in shapes})
