@@ -261,3 +261,34 @@ def test_samplers_agree_on_a_general_side_field():
     assert dev.naccepted.sum() > 0
     model.close()
     other.close()
+
+
+@pytest.mark.parametrize('n_side', [1152, 1000])
+def test_samplers_agree_above_1024(n_side):
+    """A side above 1024 (1152: built; 1000: embedded in 1152 with a wrap-around margin): the one-row-per-wave row
+    kernels with their lane-pair layout and the three-stage column kernel under BOTH samplers -- the device-resident
+    chain equals the host loop's bit for bit, the posterior images accumulated on the device equal the mean of the
+    chain's own sample images, and the log-posteriors agree with the hipFFT back end."""
+    from test_gpu_fullsize import make_model
+    from psfmc_amd.sampler import EnsembleSampler, DeviceEnsembleSampler
+    model, fld = make_model(n_side, 1, 'auto', max_walkers=24)
+    assert model._backend == 'fused' and model.engine.get_option('rows3') == 3
+    other, _ = make_model(n_side, 1, 'hipfft', max_walkers=24)
+    p0 = synth_field.draw_walkers(n_side, 1, 22, seed=5, near_truth=fld['truth'])
+    assert helpers.rel_err(model.log_posterior_batch(p0), other.log_posterior_batch(p0)) <= 1e-11
+    host = EnsembleSampler(22, model.num_params, batch_lnpostfn=model.log_posterior_batch)
+    dev = DeviceEnsembleSampler(22, model, block=2, accumulate=True)
+    for s in (host, dev):
+        s.random_state = np.random.RandomState(3).get_state()
+    list(host.sample(p0, iterations=4))
+    list(dev.sample(p0, iterations=4))
+    assert np.array_equal(dev.chain, host.chain) and np.array_equal(dev.naccepted, host.naccepted)
+    assert dev.naccepted.sum() > 0
+    post = model.collect_posterior_images()
+    flat = dev.chain.transpose(1, 0, 2).reshape(-1, model.num_params)          # every retained sample
+    imgs = model.sample_images(flat)
+    for kind in ('convolved_model', 'raw_model'):
+        want = imgs[kind].mean(axis=0)
+        assert np.abs(post[kind] - want).max() <= 1e-11 * np.abs(want).max(), (n_side, kind)
+    model.close()
+    other.close()
