@@ -800,6 +800,17 @@ template <class S> constexpr size_t fused_col3g_lds_bytes() {
 #ifndef PSFMC_COLS3G_SCALAR_BASE
 #define PSFMC_COLS3G_SCALAR_BASE 1
 #endif
+// (k_cols3f's load pipeline in this kernel, for the sides with at most PSFMC_COLS3G_PF_MAX_R1 elements per lane, measured
+// alone -- tools/cols3g_shapes.hip, profiles/r4_cols3g_prefetch_probe.txt: R1 = 5 ... 6 (250, 288, 300, 336) 3 ... 10 %
+// SLOWER, R1 = 8 (352, 384, 416, 480) 3 ... 5 % faster; a kernel gain of that size has been a step gain of a quarter of it
+// at best all round: off.)
+#ifndef PSFMC_COLS3G_PREFETCH
+#define PSFMC_COLS3G_PREFETCH 0
+#endif
+#ifndef PSFMC_COLS3G_PF_MAX_R1
+#define PSFMC_COLS3G_PF_MAX_R1 8
+#endif
+template <class S> constexpr bool cols3g_prefetch() { return PSFMC_COLS3G_PREFETCH != 0 && S::R1 <= PSFMC_COLS3G_PF_MAX_R1; }
 template <class S> constexpr bool cols3g_layout_ok(int rg_log2) { return S::L % 4 != 0 || S::L % (1 << rg_log2) == 0; }
 template <int NY> constexpr bool cols3g_side() { return Fft3gShape<NY>::kBuilt && NY > PSFMC_COLS3G_MIN; }
 
@@ -836,6 +847,72 @@ k_cols3g(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restr
     // PSFMC_COLS3G_SCALAR_BASE: a column's addresses as a scalar base + a 32-bit lane offset (see k_cols3f)
     const GroupRange gr0 = xcd_group_range((n_cols + WPB - 1) / WPB);
     const GroupRange gr = PSFMC_COLS3G_SCALAR_BASE ? scalar_range(gr0) : gr0;
+    if constexpr (cols3g_prefetch<S>() && CONVOLVE) {
+        // load pipeline (short columns: R1 <= 8 elements per lane): the wave's next column is loaded into a second
+        // register set between the kernel-spectrum multiply and the inverse transform of the current one
+        auto locate = [&](int grp, int& w, int& kx, int& c, bool& live) -> cd* {
+            int col = grp * WPB + wave;
+            live = col < n_cols;
+            col = live ? col : n_cols - 1;
+            c = col & 1;
+            const int pr = col >> 1;
+            kx = __builtin_amdgcn_readfirstlane(pr / n_w);
+            w = pr - kx * n_w;
+            if (live && skip && skip[w]) live = false;
+            return Tbuf + ((size_t)w * nxh + kx) * 2 * nyp + (c << rg_log2);     // (wave-uniform, in scalar registers)
+        };
+        auto el = [&](cd* base, unsigned ob, int a) -> cd* {
+            if constexpr (kAffine) return at_bytes(base, ob + (unsigned)(2 * L * a) * kCd);
+            else return base + row_off(L * a + tl);
+        };
+        cd nxt[R1];
+        int w_n = 0, kx_n = 0, c_n = 0;
+        bool live_n = false;
+        cd* base_n = Tbuf;
+        if (gr.first < gr.end) {
+            base_n = locate(gr.first, w_n, kx_n, c_n, live_n);
+            const unsigned ob = (unsigned)off_t * kCd;
+#pragma unroll
+            for (int a = 0; a < R1; ++a) nxt[a] = load_stream(el(base_n, ob, a));
+        }
+        for (int grp = gr.first; grp < gr.end; grp += gr.step) {
+            unsigned ob = (unsigned)off_t * kCd;
+            if constexpr (kAffine) asm volatile("" : "+v"(ob));
+            cd v[R1];
+#pragma unroll
+            for (int a = 0; a < R1; ++a) v[a] = nxt[a];
+            cd* base = base_n;
+            const int w = w_n, kx = kx_n, c = c_n;
+            const bool live = live_n;
+            cd o[NB3][R3];
+            fft_wave3g<S, -1>(v, o, w2, t, lds, tab);
+            __builtin_amdgcn_sched_barrier(0);
+            const int psf = __builtin_amdgcn_readfirstlane(live ? (int)prep[(size_t)w * plen + kPrepPsfIdx] : 0);
+            const cd* k = Kt + (((size_t)psf * nxh + kx) * 2 + c) * NY;
+#pragma unroll
+            for (int q = 0; q < NB3; ++q) {
+                const bool ok = fft3g_valid<S>(t, q);
+#pragma unroll
+                for (int k3 = 0; k3 < R3; ++k3) o[q][k3] = cmul(o[q][k3], k[ok ? fft3g_index<S>(t, q, k3) : 0]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (grp + gr.step < gr.end) {
+                base_n = locate(grp + gr.step, w_n, kx_n, c_n, live_n);
+#pragma unroll
+                for (int a = 0; a < R1; ++a) nxt[a] = load_stream(el(base_n, ob, a));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            fft_wave3g_inv<S>(o, v, t, lds, tab, tab_b);
+            __builtin_amdgcn_sched_barrier(0);
+            if (live && lane_in) {
+                unsigned os = (unsigned)off_t * kCd;
+                if constexpr (kAffine) asm volatile("" : "+v"(os));
+#pragma unroll
+                for (int a = 0; a < R1; ++a) *el(base, os, a) = v[a];
+            }
+        }
+        return;
+    }
     for (int grp = gr.first; grp < gr.end; grp += gr.step) {
         const int col = grp * WPB + wave;
         if (col >= n_cols) continue;                     // wave-uniform
