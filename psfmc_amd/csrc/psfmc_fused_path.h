@@ -800,6 +800,17 @@ template <class S> constexpr size_t fused_col3g_lds_bytes() {
 #ifndef PSFMC_COLS3G_SCALAR_BASE
 #define PSFMC_COLS3G_SCALAR_BASE 1
 #endif
+// The scalar base where 4 does not divide L (250, 294, 330, 350, 440, 500, 630: eight per-lane offsets instead of one),
+// alone (profiles/r4_cols3g_gen_offsets_probe.txt): 500 67.0 -> 52.7 us, 294 52.4 -> 49.8; 250 / 350 / 630 even; 330 and
+// 440 (L = 55: all eight offsets in use) 67.7 -> 82, 60.4 -> 70.6.  It also takes the 5 x 10 splits of 650 / 700 / 800
+// from 108 ... 115 to 65 ... 69 us -- level with, not ahead of, their two-stage kernels (70 / 63 / 54).  Whole step
+// (r4_cols3g_gen_offsets_step.txt): 500 +7.1 %, 294 inside the noise (-1.8 ... +1.1 %).  -1: 500.
+#ifndef PSFMC_COLS3G_GEN_OFFSETS
+#define PSFMC_COLS3G_GEN_OFFSETS -1
+#endif
+template <class S> constexpr bool cols3g_gen_offsets() {
+    return PSFMC_COLS3G_GEN_OFFSETS < 0 ? S::kN == 500 : PSFMC_COLS3G_GEN_OFFSETS != 0;
+}
 // k_cols3f's load pipeline in this kernel (short columns).  Alone -- tools/cols3g_shapes.hip,
 // profiles/r4_cols3g_prefetch_probe.txt: R1 = 5 ... 6 elements per lane (250, 288, 300, 336) 3 ... 10 % SLOWER, R1 = 8 (352,
 // 384, 416, 480) 3 ... 5 % faster; in the step (r4_cols3g_prefetch_step.txt, the R1 = 8 sides): 416 +3.5 %, 384 +1.2 %,
@@ -841,6 +852,9 @@ k_cols3g(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restr
     auto row_off = [&](int y) -> int { return 2 * y - (y & rg_mask); };      // element offset of row y in a column
     constexpr bool kAffine = L % 4 == 0;               // (row groups of 4 or, with 8 | L, 8 rows)
     const int off_t = row_off(tl);
+    unsigned boff[8];
+#pragma unroll
+    for (int j8 = 0; j8 < 8; ++j8) boff[j8] = (unsigned)(2 * tl - ((tl + j8) & rg_mask)) * kCd;
     const int n_cols = n_w * 2 * nxh;
     const int nyp = t_col_len(NY, rg_log2);
     // PSFMC_COLS3G_SCALAR_BASE: a column's addresses as a scalar base + a 32-bit lane offset (see k_cols3f)
@@ -927,6 +941,15 @@ k_cols3g(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restr
         if constexpr (PSFMC_COLS3G_SCALAR_BASE && kAffine) {
 #pragma unroll
             for (int a = 0; a < R1; ++a) v[a] = load_stream(at_bytes(base, ob + (unsigned)(2 * L * a) * kCd));
+        } else if constexpr (PSFMC_COLS3G_SCALAR_BASE && cols3g_gen_offsets<S>()) {
+            // 4 does not divide L: row L a + t = t + c with c a constant per register, and (row & rg_mask) depends on c
+            // only through c mod 8 -- eight per-lane byte offsets formed once (k_cols' scheme), one of them + an
+            // immediate per element on the scalar base
+            unsigned bo[8];
+#pragma unroll
+            for (int j8 = 0; j8 < 8; ++j8) { bo[j8] = boff[j8]; asm volatile("" : "+v"(bo[j8])); }
+#pragma unroll
+            for (int a = 0; a < R1; ++a) v[a] = load_stream(at_bytes(base, bo[(L * a) & 7] + (unsigned)(2 * L * a) * kCd));
         } else {
 #pragma unroll
             for (int a = 0; a < R1; ++a) v[a] = load_stream(base + in_off(a));
@@ -954,6 +977,12 @@ k_cols3g(cd* __restrict__ Tbuf, const cd* __restrict__ Kt, const double* __restr
                     asm volatile("" : "+v"(os));
 #pragma unroll
                     for (int a = 0; a < R1; ++a) *at_bytes(base, os + (unsigned)(2 * L * a) * kCd) = v[a];
+                } else if constexpr (PSFMC_COLS3G_SCALAR_BASE && cols3g_gen_offsets<S>()) {
+                    unsigned bo[8];
+#pragma unroll
+                    for (int j8 = 0; j8 < 8; ++j8) { bo[j8] = boff[j8]; asm volatile("" : "+v"(bo[j8])); }
+#pragma unroll
+                    for (int a = 0; a < R1; ++a) *at_bytes(base, bo[(L * a) & 7] + (unsigned)(2 * L * a) * kCd) = v[a];
                 } else {
 #pragma unroll
                     for (int a = 0; a < R1; ++a) base[in_off(a)] = v[a];
