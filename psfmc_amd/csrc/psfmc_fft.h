@@ -787,17 +787,28 @@ struct Fft3gPick { int r2, r3; };
 // two-stage kernels hold 21 ... 25 complex registers at one wave per SIMD, win 14 ... 25 % on it.
 constexpr Fft3gPick fft3g_pick(int n) {
     switch (n) {
+        // Round 4 re-surveyed the shapes (profiles/r4_cols3g_resurvey.txt: 233 variants of the 47 sides) once the column's
+        // addresses sat on a scalar base: round 3's ranking no longer held at thirteen sides.  Alone / whole step
+        // (r4_cols3g_resurvey_step.txt, same box, both libraries twice):
+        //   384 (4, 12) -> (8, 8) -17 % / +5.8 %     392 (4, 14) -> (7, 8) -31 % / +11.8 %    448 (4, 16) -> (8, 7) -17 % / +9.0 %
+        //   480 (4, 15) -> (6, 10) -11 % / +3.7 %    504 (4, 14) -> (7, 8) -6 % / +4.2 %      600 (5, 12) -> (6, 10) -12 % / +2.9 %
+        //   640, 704 (8, 8) -> (4, 16) -5 % / +2.7 %, +2.2 %    728, 784 (4, 14) -> (7, 8) -4 % / +1.4 %, +2.0 %
+        //   780 (4, 13) -> (6, 10) -8 % / +4.0 %
+        // taken; 676 (4, 13) -> (13, 4) and 768 (8, 8) -> (4, 16), -5 % alone, move the step by -0.8 % / -0.2 %: not taken.
         case 264: case 308: case 352: case 484: return {4, 11};
-        case 384: case 528: case 576: return {4, 12};
-        case 312: case 364: case 416: case 520: case 572: case 624: case 676: case 780: return {4, 13};
-        case 392: case 504: case 560: case 616: case 672: case 728: case 784: case 840: case 896: return {4, 14};
-        case 480: case 900: return {4, 15};
-        case 448: return {4, 16};
+        case 528: case 576: return {4, 12};
+        case 312: case 364: case 416: case 520: case 572: case 624: case 676: return {4, 13};
+        case 560: case 616: case 672: case 840: case 896: return {4, 14};
+        case 900: return {4, 15};
+        case 640: case 704: return {4, 16};
         case 330: case 440: return {5, 11};
         case 250: case 500: return {5, 10};
         case 294: return {7, 7};
-        case 600: case 660: case 720: return {5, 12};
-        case 512: case 640: case 704: case 768: case 832: case 960: case 1024: return {8, 8};
+        case 660: case 720: return {5, 12};
+        case 480: case 600: case 780: return {6, 10};
+        case 392: case 504: case 728: case 784: return {7, 8};
+        case 448: return {8, 7};
+        case 384: case 512: case 768: case 832: case 960: case 1024: return {8, 8};
         // round 4: sides above 1024 -- no two-stage shape (P, T <= 32) reaches them; all 64 lanes, R1 = 18 ... 32
         case 1152: case 1280: case 1536: case 2048: return {8, 8};
 #if PSFMC_COLS3G_ROUND4_SIDES

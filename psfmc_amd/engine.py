@@ -36,15 +36,16 @@ def nearest_fused_sides(n):
 # psfmc_fft.h fft3g_pick: the sides whose columns run on the general wave-wide three-stage engine, with
 # their (R2, R3) split of the wave's lanes
 _COLS3G_SHAPES = {}
-for _sides, _shape in (((264, 308, 352, 484), (4, 11)), ((384, 528, 576), (4, 12)),
-                       ((312, 364, 416, 520, 572, 624, 676, 780), (4, 13)),
-                       ((392, 504, 560, 616, 672, 728, 784, 840, 896), (4, 14)), ((480, 900), (4, 15)),
-                       ((448,), (4, 16)), ((330, 440), (5, 11)), ((250, 500), (5, 10)), ((294,), (7, 7)),
-                       ((600, 660, 720), (5, 12)),
-                       # round 4, second survey (csrc/psfmc_fft.h fft3g_pick)
+for _sides, _shape in (((264, 308, 352, 484), (4, 11)), ((528, 576), (4, 12)),
+                       ((312, 364, 416, 520, 572, 624, 676), (4, 13)),
+                       ((560, 616, 672, 840, 896), (4, 14)), ((900,), (4, 15)),
+                       ((640, 704), (4, 16)), ((330, 440), (5, 11)), ((250, 500), (5, 10)), ((294,), (7, 7)),
+                       ((660, 720), (5, 12)),
+                       # round 4: the re-surveyed shapes and the second survey's new sides (csrc/psfmc_fft.h fft3g_pick)
+                       ((480, 600, 780), (6, 10)), ((392, 504, 728, 784), (7, 8)), ((448,), (8, 7)),
                        ((280, 336), (7, 8)), ((288,), (6, 8)), ((300,), (5, 12)), ((350,), (5, 10)), ((360,), (6, 10)),
                        ((630,), (7, 9)),
-                       ((640, 704, 768, 832, 960, 1152, 1280, 1536, 2048), (8, 8))):
+                       ((384, 768, 832, 960, 1152, 1280, 1536, 2048), (8, 8))):
     for _n in _sides:
         _COLS3G_SHAPES[_n] = _shape
 
