@@ -96,7 +96,9 @@ constexpr Fft3gPick rows3_pick(int n) {
     switch (n) {
         // sides above 1024: the only row kernels there are (the two-stage shapes end at P = T = 32)
         case 1152: case 1280: case 1536: case 2048: return {8, 8};
-        // sides whose two-stage row shape holds 26 ... 30 complex registers per lane
+        // sides whose two-stage row shape holds 26 ... 30 complex registers per lane.  (The shapes the column kernel's
+        // re-survey preferred -- (7, 8), (6, 10), (13, 4) -- were tried here too, profiles/r4_rows3_inv_shapes.txt: the
+        // inverse kernel 0 ... +15 % SLOWER except 728 (-2 %), the step -3 ... +1 %.  These stay.)
         case 676: case 780: return {4, 13};
         case 728: case 784: case 840: return {4, 14};
         case 900: return {4, 15};
