@@ -746,7 +746,13 @@ def other_configs(args, torch, dev, local):
             ('config4_share_1024', 1024, 4, 256, "BASELINE config 4's per-GPU share: synthetic 1024x1024, 1 PointSource + "
                                                  '4 Sersic, 256 of the 2048 walkers'),
             ('embedded_170', 170, 1, 4096, 'a side the transforms are not built for (170x170, embedded), 1 PointSource + '
-                                           '1 Sersic, 4096 walkers')):
+                                           '1 Sersic, 4096 walkers'),
+            # not BASELINE configs: one mixed-radix side and one side above 1024, so that the driver's own run holds a
+            # number for each family of kernels (general two-stage rows + three-stage columns; one-row-per-wave rows)
+            ('general_300', 300, 1, 2048, 'a general side (300x300 = 15 x 20 rows, 5 x (5 x 12) columns), 1 PointSource + '
+                                          '1 Sersic, 2048 walkers'),
+            ('large_2048', 2048, 1, 64, 'a side above 1024 (2048x2048: one-row-per-wave three-stage row kernels, '
+                                        'k_cols3f columns), 1 PointSource + 1 Sersic, 64 walkers')):
         model, theta, fld = build_problem(args, local, size=size, sersic=sersic, walkers=walkers)
         eng = model.engine
         th = torch.from_numpy(theta).to(dev)
@@ -755,7 +761,7 @@ def other_configs(args, torch, dev, local):
         call = lambda: eng.logpost_theta_device(walkers, th.data_ptr(), 0, res.data_ptr(), stream.cuda_stream)
         per_call, n_calls = timed_calls(call, sync)
         got = res.cpu().numpy()
-        rel, n_chk = oracle_check(model, fld, sersic, theta, got)
+        rel, n_chk = oracle_check(model, fld, sersic, theta, got, count=2 if size > 1024 else 4)
         rec = {'workload': what + ', raw vectors resident in HBM -> log-posterior, fp64', 'value': walkers / per_call,
                'unit': 'evals/s', 'timed_s': per_call * n_calls, 'calls': n_calls, 'walkers_per_call': walkers,
                'finite_logposts': int(np.isfinite(got).sum()), 'check_vs_cpu_rel': rel, 'walkers_checked': n_chk,
