@@ -814,12 +814,13 @@ template <class S> constexpr bool cols3g_gen_offsets() {
 // k_cols3f's load pipeline in this kernel (short columns).  Alone -- tools/cols3g_shapes.hip,
 // profiles/r4_cols3g_prefetch_probe.txt: R1 = 5 ... 6 elements per lane (250, 288, 300, 336) 3 ... 10 % SLOWER, R1 = 8 (352,
 // 384, 416, 480) 3 ... 5 % faster; in the step (r4_cols3g_prefetch_step.txt, the R1 = 8 sides): 416 +3.5 %, 384 +1.2 %,
-// 352 / 440 / 480 +0.0 ... 0.2 %.  On at 384 and 416 (PSFMC_COLS3G_PREFETCH: -1 those two, 0 nowhere, 1 every R1 <= 8).
+// 352 / 440 / 480 +0.0 ... 0.2 %; with the re-surveyed shapes (r4_cols3g_prefetch_step2.txt) 384 still +2 %, 504 +2.5 %,
+// 392 / 448 / 480 -1 ... -4 %.  On at 384, 416 and 504 (PSFMC_COLS3G_PREFETCH: -1 those, 0 nowhere, 1 every R1 <= 8).
 #ifndef PSFMC_COLS3G_PREFETCH
 #define PSFMC_COLS3G_PREFETCH -1
 #endif
 template <class S> constexpr bool cols3g_prefetch() {
-    return PSFMC_COLS3G_PREFETCH < 0 ? (S::kN == 384 || S::kN == 416) : (PSFMC_COLS3G_PREFETCH != 0 && S::R1 <= 8);
+    return PSFMC_COLS3G_PREFETCH < 0 ? (S::kN == 384 || S::kN == 416 || S::kN == 504) : (PSFMC_COLS3G_PREFETCH != 0 && S::R1 <= 8);
 }
 template <class S> constexpr bool cols3g_layout_ok(int rg_log2) { return S::L % 4 != 0 || S::L % (1 << rg_log2) == 0; }
 template <int NY> constexpr bool cols3g_side() { return Fft3gShape<NY>::kBuilt && NY > PSFMC_COLS3G_MIN; }
