@@ -815,12 +815,14 @@ template <class S> constexpr bool cols3g_gen_offsets() {
 // profiles/r4_cols3g_prefetch_probe.txt: R1 = 5 ... 6 elements per lane (250, 288, 300, 336) 3 ... 10 % SLOWER, R1 = 8 (352,
 // 384, 416, 480) 3 ... 5 % faster; in the step (r4_cols3g_prefetch_step.txt, the R1 = 8 sides): 416 +3.5 %, 384 +1.2 %,
 // 352 / 440 / 480 +0.0 ... 0.2 %; with the re-surveyed shapes (r4_cols3g_prefetch_step2.txt) 384 still +2 %, 504 +2.5 %,
-// 392 / 448 / 480 -1 ... -4 %.  On at 384, 416 and 504 (PSFMC_COLS3G_PREFETCH: -1 those, 0 nowhere, 1 every R1 <= 8).
+// 392 / 448 / 480 -1 ... -4 %; at 9 ... 13 elements per lane (r4_cols3g_prefetch_step3.txt: eleven sides 500 ... 832) 660
+// +2.2 %, the others -2.3 ... +1.3 % = the noise.  On at 384, 416, 504 and 660 (PSFMC_COLS3G_PREFETCH: -1 those, 0 nowhere,
+// 1 every R1 <= 8).
 #ifndef PSFMC_COLS3G_PREFETCH
 #define PSFMC_COLS3G_PREFETCH -1
 #endif
 template <class S> constexpr bool cols3g_prefetch() {
-    return PSFMC_COLS3G_PREFETCH < 0 ? (S::kN == 384 || S::kN == 416 || S::kN == 504) : (PSFMC_COLS3G_PREFETCH != 0 && S::R1 <= 8);
+    return PSFMC_COLS3G_PREFETCH < 0 ? (S::kN == 384 || S::kN == 416 || S::kN == 504 || S::kN == 660) : (PSFMC_COLS3G_PREFETCH != 0 && S::R1 <= 8);
 }
 template <class S> constexpr bool cols3g_layout_ok(int rg_log2) { return S::L % 4 != 0 || S::L % (1 << rg_log2) == 0; }
 template <int NY> constexpr bool cols3g_side() { return Fft3gShape<NY>::kBuilt && NY > PSFMC_COLS3G_MIN; }
