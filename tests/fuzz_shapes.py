@@ -1,6 +1,6 @@
 """Shape fuzz (run by hand on a GPU box: python tests/fuzz_shapes.py <seed> <cases>): random (ny, nx) pairs of built sides,
 any even sides (embedded where not built) and sides above 1024 against short partners, random fields and component sets
-(test_gpu_random.random_case), the fused back end against the fp64 oracle.  Round 4: 520 cases, no mismatch."""
+(test_gpu_random.random_case), the fused back end against the fp64 oracle.  Round 4: 1420 cases, no mismatch (one ill-conditioned sum, within 2e-12 of the terms' magnitudes on both back ends)."""
 import sys, os
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # (this file lives in tests/: test infrastructure, the only place beside smoke() and the bench baseline that may use the oracle)
@@ -25,13 +25,20 @@ for i in range(n_cases):
     if not engine.fused_supports(shape[0], shape[1], case['psfs'][0].shape):
         continue
     field = orc.make_field(case['sci'], case['ivm'], case['psfs'], case['pivms'], mask=case['mask'], mag_zp=case['zp'])
-    want, _ = orc.evaluate(field, case['comps'], case['psf_index'], raw_dtype=np.float64)
+    want, imgs = orc.evaluate(field, case['comps'], case['psf_index'], raw_dtype=np.float64)
     want = want if np.isfinite(want) else -np.inf
+    # a log-likelihood near zero is a cancellation of terms thousands of times larger (case 137 of seed 21: 548 out of
+    # 232 434, both back ends 3e-7 from the oracle): the bound is relative to the sum of the terms' magnitudes as well
+    cond = 0.0
+    if np.isfinite(want):
+        g = ~field.bad_px
+        ivm = imgs['composite_ivm'][g]
+        cond = 0.5 * float(np.abs((field.sci - imgs['convolved_model'])[g] ** 2 * ivm).sum() + np.abs(np.log(0.5 / np.pi * ivm)).sum())
     n_free = 1 if len(case['psfs']) > 1 else 0
     theta = np.full((2, n_free), float(case['psf_index']))
     model = tgr.build(case, 'fused')
     got = model.log_likelihood_batch(theta)
-    ok = (got[0] == got[1]) and ((not np.isfinite(want) and got[0] == -np.inf) or (np.isfinite(want) and abs(got[0] - want) <= 2e-10 * abs(want)))
+    ok = (got[0] == got[1]) and ((not np.isfinite(want) and got[0] == -np.inf) or (np.isfinite(want) and abs(got[0] - want) <= max(2e-10 * abs(want), 5e-12 * cond)))
     print(shape, 'transform', (int(model.engine.get_option('transform_ny')), int(model.engine.get_option('transform_nx'))), 'ok' if ok else 'MISMATCH %r %r' % (got[0], want), flush=True)
     bad += 0 if ok else 1
     model.close()
